@@ -1,0 +1,128 @@
+/*
+ * pwc_hip.h -- C ABI of libpwc_hip.so: the MI355X (gfx950) PWC-Net inference ops.
+ *
+ * The reference (daigo0927/pwcnet) has no FFI layer: its op-level API is the Python
+ * of model.py / modules.py running stock TensorFlow-1.8 primitives.  Each entry point
+ * below replaces the TF sub-graph of one reference callable (file:line cited per
+ * function); pwcnet_amd/modules.py binds them with ctypes and re-exposes the
+ * reference's class names and call signatures.  INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions (all functions):
+ *   - tensors are NHWC float32 in device (HBM) memory, caller-owned; nothing is
+ *     allocated, freed or synchronised inside the library;
+ *   - a tensor argument is (pointer to its first channel, channel stride `*_cs` in
+ *     floats): pixel p, channel c lives at ptr[p * cs + c].  cs == C is a dense
+ *     tensor; cs > C addresses a channel slice of a wider tensor, which is how
+ *     tf.concat (modules.py:264,270,305) is made free;
+ *   - work is enqueued on `stream` (a hipStream_t; NULL = the default stream) and the
+ *     call returns immediately;
+ *   - return value: PWC_OK (0), a negative PWC_E* argument error, or a positive
+ *     hipError_t from the launch.  No exceptions, no global mutable state: the
+ *     functions are re-entrant and thread-safe on distinct streams.
+ */
+#ifndef PWC_HIP_H
+#define PWC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pwc_stream_t; /* hipStream_t */
+
+enum {
+    PWC_OK = 0,
+    PWC_EINVAL = -1,   /* null pointer / non-positive size */
+    PWC_EALIGN = -2,   /* pointer or channel stride not aligned as the kernel needs */
+    PWC_ERANGE = -3,   /* size exceeds what the kernel indexes (see each function) */
+    PWC_EUNSUPPORTED = -4
+};
+
+/* Library version (major*10000 + minor*100 + patch). */
+int pwc_version(void);
+/* Text for a return code of this library (negative codes) or of HIP (positive). */
+const char* pwc_error_string(int code);
+
+/* ---- a1: CostVolumeLayer.__call__ + get_cost/pad2d/crop2d, modules.py:158-204 ----
+ * out[n,y,x,(v+R)*(2R+1)+(h+R)] =
+ *     lrelu_slope( (1/C) * sum_c f0[n,y,x,c] * f1w[n,y+v,x+h,c] ),  0 outside the image;
+ * v = vertical shift (outer loop, modules.py:197), h = horizontal (inner, :198).
+ * Needs C % 4 == 0, f0/f1w 16-byte aligned with cs % 4 == 0; search_range in [1,4]. */
+int pwc_cost_volume_f32(const float* f0, int f0_cs, const float* f1w, int f1w_cs,
+                        float* out, int out_cs, int N, int H, int W, int C,
+                        int search_range, float slope, pwc_stream_t stream);
+
+/* ---- a2: WarpingLayer(warp_type='bilinear') = bilinear_warp, modules.py:99-137 ----
+ * out[n,y,x,:] = sum_{i,j} w_ij * x[n, clip(y+floor(fy)+i), clip(x+floor(fx)+j), :]
+ * with (fx,fy) = flow_scale * flow[n,y,x,0:2]; flow_scale restates the caller's
+ * `flows_up*self.scales[l]` (model.py:109).  Needs C % 4 == 0 and 16-byte alignment of
+ * x/out with cs % 4 == 0. */
+int pwc_warp_bilinear_f32(const float* x, int x_cs, const float* flow, int flow_cs,
+                          float flow_scale, float* out, int out_cs,
+                          int N, int H, int W, int C, pwc_stream_t stream);
+
+/* ---- a3: WarpingLayer(warp_type='nearest') = nearest_warp, modules.py:83-97 ----
+ * flow truncated toward zero (tf.cast int32, :85), added to the grid, clipped. */
+int pwc_warp_nearest_f32(const float* x, int x_cs, const float* flow, int flow_cs,
+                         float flow_scale, float* out, int out_cs,
+                         int N, int H, int W, int C, pwc_stream_t stream);
+
+/* ---- a2+a1 fused: model.py:109-112 (warp then cost volume) without materialising
+ * the warped feature map.  f1 is the UN-warped second feature map.  Same result as
+ * pwc_warp_bilinear_f32 followed by pwc_cost_volume_f32. */
+int pwc_warp_cost_volume_f32(const float* f0, int f0_cs, const float* f1, int f1_cs,
+                             const float* flow, int flow_cs, float flow_scale,
+                             float* out, int out_cs, int N, int H, int W, int C,
+                             int search_range, float slope, pwc_stream_t stream);
+
+/* ---- a4/a5/a6: tf.layers.Conv2D(Cout,(3,3),(s,s),'same',dilation_rate=d) [+
+ * tf.nn.leaky_relu(slope)] -- modules.py:62-67,267-268,274,306-324 ----
+ *
+ * Weight packing for the fp32-MFMA implicit-GEMM kernel.  `w_hwio` is the TF variable
+ * (3,3,Cin,Cout).  `cin_map` (length Cin_phys, device int32, may be NULL = identity on
+ * the first Cin entries, padding after) gives for every PHYSICAL input channel of the
+ * activation buffer the logical TF channel it holds, or -1 for a padding channel
+ * (its weights are packed as zero).  Cin_phys % 16 == 0.  The packed buffer holds
+ * pwc_conv3x3_packed_floats(Cin_phys, Cout) floats. */
+size_t pwc_conv3x3_packed_floats(int Cin_phys, int Cout);
+int pwc_conv3x3_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin, int Cin_phys,
+                         int Cout, float* packed, pwc_stream_t stream);
+
+/* y[n,oy,ox,co] = act(bias[co] + sum_{ty,tx,ci} x[n,oy*s-pt+ty*d,ox*s-pl+tx*d,ci] * w[ty,tx,ci,co])
+ * with TF 'SAME' padding (pad_total = max((out-1)*s + 2d+1 - in, 0), pad_before =
+ * pad_total/2: stride 2 on an even size pads bottom/right only).  apply_act=0 gives
+ * the activation-less flow heads.  Output is (N,ceil(H/s),ceil(W/s),Cout) at channel
+ * stride y_cs.  `tile` selects a tile configuration (-1 = automatic).
+ * Needs Cout % 16 == 0, x 16-byte aligned, x_cs % 4 == 0, x_cs >= Cin_phys, and every
+ * padding channel of x finite (they meet zero weights). */
+int pwc_conv3x3_f32(const float* x, int x_cs, const float* packed, const float* bias,
+                    float* y, int y_cs, int N, int H, int W, int Cin_phys, int Cout,
+                    int stride, int dilation, int apply_act, float slope, int tile,
+                    pwc_stream_t stream);
+
+/* Same convolution straight from the HWIO variable, any Cin/Cout, plus the optional
+ * residual add of modules.py:275-277 (`flows += flows_up_prev`) and modules.py:326
+ * (`flows + x`): y = act(conv) + residual.  Used for Cin = 3 (first extractor layer),
+ * Cout = 2 (flow heads) and as the in-library cross-check of the MFMA kernel. */
+int pwc_conv3x3_direct_f32(const float* x, int x_cs, const float* w_hwio, const float* bias,
+                           float* y, int y_cs, const float* residual, int res_cs,
+                           int N, int H, int W, int Cin, int Cout, int stride, int dilation,
+                           int apply_act, float slope, pwc_stream_t stream);
+
+/* ---- a7: tf.image.resize_bilinear (TF 1.8 legacy: src = dst*in/out, no half-pixel,
+ * no align-corners), modules.py:283-284 and model.py:127; y = resize(x) * mul. */
+int pwc_resize_bilinear_f32(const float* x, int x_cs, float* y, int y_cs,
+                            int N, int H, int W, int C, int OH, int OW, float mul,
+                            pwc_stream_t stream);
+
+/* ---- tf.concat helper (modules.py:264,305): dst[p, 0:C] = src[p, 0:C] for npix pixels. */
+int pwc_copy_channels_f32(const float* src, int src_cs, float* dst, int dst_cs,
+                          long npix, int C, pwc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PWC_HIP_H */

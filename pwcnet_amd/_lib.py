@@ -1,0 +1,88 @@
+"""ctypes binding of libpwc_hip.so (the C ABI declared in include/pwc_hip.h).
+
+The library is the ONLY compute path of this package: if it is missing or does not
+export every declared symbol, importing the ops fails loudly -- there is no CPU or
+eager-PyTorch fallback.  torch must be imported first so that the HIP runtime the
+library binds to (libamdhip64.so.7) is the one PyTorch already loaded.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (loads libamdhip64 before libpwc_hip.so)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libpwc_hip.so")
+SOURCES = ["conv3x3_mfma.hip", "conv3x3_direct.hip", "cost_volume.hip", "pwc_ops.hip"]
+HEADERS = ["pwc_common.h", os.path.join("..", "..", "include", "pwc_hip.h")]
+
+_vp, _i, _f, _l, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/pwc_hip.h one to one
+SIGNATURES = {
+    "pwc_version": (_i, []),
+    "pwc_error_string": (ctypes.c_char_p, [_i]),
+    "pwc_cost_volume_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "pwc_warp_bilinear_f32": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _vp]),
+    "pwc_warp_nearest_f32": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _vp]),
+    "pwc_warp_cost_volume_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "pwc_conv3x3_packed_floats": (_sz, [_i, _i]),
+    "pwc_conv3x3_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "pwc_conv3x3_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "pwc_conv3x3_direct_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "pwc_resize_bilinear_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "pwc_copy_channels_f32": (_i, [_vp, _i, _vp, _i, _l, _i, _vp]),
+}
+
+_lib = None
+
+
+class PwcHipError(RuntimeError):
+    pass
+
+
+def build_library(force=False, verbose=False):
+    """hipcc-compile the HIP sources for gfx950 into csrc/libpwc_hip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wno-pass-failed", *srcs, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises if it is absent (never falls back to another path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PwcHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). pwcnet_amd has no fallback compute path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise PwcHipError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().pwc_error_string(rc).decode()
+        raise PwcHipError(f"{what or 'pwc call'} failed: {msg} (code {rc})")
+
+
+def current_stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,42 @@
+// pwc_common.h -- shared device/host helpers for libpwc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pwc_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define PWC_WAVE 64
+
+static inline int pwc_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PWC_OK : (int)e;
+}
+
+static inline bool pwc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// TF 'SAME' padding of one axis for a 3-tap kernel (see include/pwc_hip.h, conv).
+static inline void pwc_same_pad(int in, int stride, int dil, int* out, int* before) {
+    int o = (in + stride - 1) / stride;
+    int total = (o - 1) * stride + 2 * dil + 1 - in;
+    if (total < 0) total = 0;
+    *out = o;
+    *before = total / 2;
+}
+
+__device__ __forceinline__ float pwc_lrelu(float v, float slope) {
+    // tf.nn.leaky_relu(x, alpha) = max(alpha*x, x)
+    return fmaxf(v, slope * v);
+}
+
+// Bijective XCD-aware remap of a linear workgroup id (MI355X: 8 XCDs, block b is
+// dispatched to XCD b % 8).  After the remap, the blocks that land on one XCD own a
+// contiguous range of logical tile ids, so neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ int pwc_xcd_remap(int b, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int xcd = b & 7, k = b >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}

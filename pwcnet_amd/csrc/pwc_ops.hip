@@ -1,0 +1,217 @@
+// pwc_ops.hip -- the HBM-bound pointwise/gather ops of the PWC-Net forward for gfx950:
+//   backward warping (bilinear / nearest), TF-legacy bilinear resize, channel-slice copy.
+// Every kernel maps consecutive lanes to consecutive 16-byte channel quads of one NHWC
+// pixel, so each wave instruction touches whole contiguous pixel records.
+#include "pwc_common.h"
+
+// ------------------------------------------------------------------ warp (a2 / a3)
+// WarpingLayer.__call__ -> bilinear_warp / nearest_warp, reference modules.py:83-154.
+struct WarpArgs {
+    const float* x;
+    const float* flow;
+    float* out;
+    int x_cs, flow_cs, out_cs;
+    int H, W, C4;     // C4 = C / 4
+    float flow_scale;
+    long total;       // N*H*W*C4
+};
+
+template <bool BILINEAR>
+__global__ __launch_bounds__(256) void warp_kernel(const WarpArgs a) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < a.total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int cq = (int)(idx % a.C4);
+        const long pix = idx / a.C4;
+        const int gx = (int)(pix % a.W);
+        const long r = pix / a.W;
+        const int gy = (int)(r % a.H);
+        const long n = r / a.H;
+        const float* fp = a.flow + (size_t)pix * a.flow_cs;
+        const float fx = fp[0] * a.flow_scale, fy = fp[1] * a.flow_scale;
+        const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs + cq * 4;
+        f32x4 v;
+        if (BILINEAR) {
+            // modules.py:107-137: weights from un-clipped floors, corners clipped independently
+            const float fx0 = floorf(fx), fy0 = floorf(fy);
+            const float fx1 = fx0 + 1.f, fy1 = fy0 + 1.f;
+            const float hl = (float)(a.H - 1), wl = (float)(a.W - 1);
+            const int y0 = (int)fminf(fmaxf((float)gy + fy0, 0.f), hl);
+            const int y1 = (int)fminf(fmaxf((float)gy + fy1, 0.f), hl);
+            const int x0 = (int)fminf(fmaxf((float)gx + fx0, 0.f), wl);
+            const int x1 = (int)fminf(fmaxf((float)gx + fx1, 0.f), wl);
+            const float c00 = (fy1 - fy) * (fx1 - fx), c01 = (fy1 - fy) * (fx - fx0);
+            const float c10 = (fy - fy0) * (fx1 - fx), c11 = (fy - fy0) * (fx - fx0);
+            const f32x4 v00 = *reinterpret_cast<const f32x4*>(xn + ((size_t)y0 * a.W + x0) * a.x_cs);
+            const f32x4 v01 = *reinterpret_cast<const f32x4*>(xn + ((size_t)y0 * a.W + x1) * a.x_cs);
+            const f32x4 v10 = *reinterpret_cast<const f32x4*>(xn + ((size_t)y1 * a.W + x0) * a.x_cs);
+            const f32x4 v11 = *reinterpret_cast<const f32x4*>(xn + ((size_t)y1 * a.W + x1) * a.x_cs);
+            v = c00 * v00 + c01 * v01 + c10 * v10 + c11 * v11;
+        } else {
+            // modules.py:85-92: int32 cast truncates toward zero, then clip
+            int yy = gy + (int)fy, xx = gx + (int)fx;
+            yy = min(max(yy, 0), a.H - 1);
+            xx = min(max(xx, 0), a.W - 1);
+            v = *reinterpret_cast<const f32x4*>(xn + ((size_t)yy * a.W + xx) * a.x_cs);
+        }
+        *reinterpret_cast<f32x4*>(a.out + (size_t)pix * a.out_cs + cq * 4) = v;
+    }
+}
+
+static int warp_common(bool bilinear, const float* x, int x_cs, const float* flow, int flow_cs,
+                       float flow_scale, float* out, int out_cs, int N, int H, int W, int C,
+                       pwc_stream_t stream) {
+    if (!x || !flow || !out) return PWC_EINVAL;
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return PWC_EINVAL;
+    if (x_cs < C || out_cs < C || flow_cs < 2) return PWC_EINVAL;
+    if ((C & 3) || (x_cs & 3) || (out_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(out)) return PWC_EALIGN;
+    WarpArgs a;
+    a.x = x; a.flow = flow; a.out = out;
+    a.x_cs = x_cs; a.flow_cs = flow_cs; a.out_cs = out_cs;
+    a.H = H; a.W = W; a.C4 = C / 4; a.flow_scale = flow_scale;
+    a.total = (long)N * H * W * a.C4;
+    long blocks = (a.total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (bilinear)
+        hipLaunchKernelGGL(warp_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(warp_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return pwc_launch_status();
+}
+
+extern "C" int pwc_warp_bilinear_f32(const float* x, int x_cs, const float* flow, int flow_cs,
+                                     float flow_scale, float* out, int out_cs, int N, int H, int W, int C,
+                                     pwc_stream_t stream) {
+    return warp_common(true, x, x_cs, flow, flow_cs, flow_scale, out, out_cs, N, H, W, C, stream);
+}
+
+extern "C" int pwc_warp_nearest_f32(const float* x, int x_cs, const float* flow, int flow_cs,
+                                    float flow_scale, float* out, int out_cs, int N, int H, int W, int C,
+                                    pwc_stream_t stream) {
+    return warp_common(false, x, x_cs, flow, flow_cs, flow_scale, out, out_cs, N, H, W, C, stream);
+}
+
+// ------------------------------------------------------------------ resize (a7)
+// tf.image.resize_bilinear, TF 1.8, align_corners=False (modules.py:283-284, model.py:127):
+//   src = dst * (in/out); lo = floor(src); hi = min(lo+1, in-1); t = src - lo
+//   top = tl + (tr-tl)*tx; bot = bl + (br-bl)*tx; out = (top + (bot-top)*ty) * mul
+struct ResizeArgs {
+    const float* x;
+    float* y;
+    int x_cs, y_cs;
+    int H, W, C, OH, OW;
+    float sy, sx, mul;
+    long total;   // N*OH*OW*CV  (CV = C/4 for the vector kernel, C for the scalar one)
+};
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void resize_kernel(const ResizeArgs a) {
+    const int CV = VEC4 ? a.C / 4 : a.C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < a.total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(idx % CV);
+        const long pix = idx / CV;
+        const int ox = (int)(pix % a.OW);
+        const long r = pix / a.OW;
+        const int oy = (int)(r % a.OH);
+        const long n = r / a.OH;
+        const float fy = (float)oy * a.sy, fx = (float)ox * a.sx;
+        const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+        const int y1 = min(y0 + 1, a.H - 1), x1 = min(x0 + 1, a.W - 1);
+        const float yl = fy - (float)y0, xl = fx - (float)x0;
+        const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs + (VEC4 ? cv * 4 : cv);
+        const float* ptl = xn + ((size_t)y0 * a.W + x0) * a.x_cs;
+        const float* ptr = xn + ((size_t)y0 * a.W + x1) * a.x_cs;
+        const float* pbl = xn + ((size_t)y1 * a.W + x0) * a.x_cs;
+        const float* pbr = xn + ((size_t)y1 * a.W + x1) * a.x_cs;
+        float* po = a.y + (size_t)pix * a.y_cs + (VEC4 ? cv * 4 : cv);
+        if (VEC4) {
+            const f32x4 tl = *reinterpret_cast<const f32x4*>(ptl), tr = *reinterpret_cast<const f32x4*>(ptr);
+            const f32x4 bl = *reinterpret_cast<const f32x4*>(pbl), br = *reinterpret_cast<const f32x4*>(pbr);
+            const f32x4 top = tl + (tr - tl) * xl;
+            const f32x4 bot = bl + (br - bl) * xl;
+            *reinterpret_cast<f32x4*>(po) = (top + (bot - top) * yl) * a.mul;
+        } else {
+            const float top = *ptl + (*ptr - *ptl) * xl;
+            const float bot = *pbl + (*pbr - *pbl) * xl;
+            *po = (top + (bot - top) * yl) * a.mul;
+        }
+    }
+}
+
+extern "C" int pwc_resize_bilinear_f32(const float* x, int x_cs, float* y, int y_cs, int N, int H, int W,
+                                       int C, int OH, int OW, float mul, pwc_stream_t stream) {
+    if (!x || !y) return PWC_EINVAL;
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return PWC_EINVAL;
+    if (x_cs < C || y_cs < C) return PWC_EINVAL;
+    ResizeArgs a;
+    a.x = x; a.y = y; a.x_cs = x_cs; a.y_cs = y_cs;
+    a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW;
+    a.sy = (float)H / (float)OH; a.sx = (float)W / (float)OW; a.mul = mul;
+    const bool vec4 = (C % 4 == 0) && (x_cs % 4 == 0) && (y_cs % 4 == 0) && pwc_aligned16(x) && pwc_aligned16(y);
+    a.total = (long)N * OH * OW * (vec4 ? C / 4 : C);
+    long blocks = (a.total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (vec4)
+        hipLaunchKernelGGL(resize_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(resize_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return pwc_launch_status();
+}
+
+// ------------------------------------------------------------------ channel-slice copy
+// tf.concat (modules.py:264,305) when an input arrives as its own tensor: copies C
+// channels of every pixel into a channel slice of the destination.
+struct CopyArgs {
+    const float* src;
+    float* dst;
+    int src_cs, dst_cs, CV;
+    long total;
+};
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const CopyArgs a) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < a.total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(idx % a.CV);
+        const long pix = idx / a.CV;
+        if (VEC4)
+            *reinterpret_cast<f32x4*>(a.dst + (size_t)pix * a.dst_cs + cv * 4) =
+                *reinterpret_cast<const f32x4*>(a.src + (size_t)pix * a.src_cs + cv * 4);
+        else
+            a.dst[(size_t)pix * a.dst_cs + cv] = a.src[(size_t)pix * a.src_cs + cv];
+    }
+}
+
+extern "C" int pwc_copy_channels_f32(const float* src, int src_cs, float* dst, int dst_cs, long npix, int C,
+                                     pwc_stream_t stream) {
+    if (!src || !dst || npix <= 0 || C <= 0 || src_cs < C || dst_cs < C) return PWC_EINVAL;
+    const bool vec4 = (C % 4 == 0) && (src_cs % 4 == 0) && (dst_cs % 4 == 0) && pwc_aligned16(src) &&
+                      pwc_aligned16(dst);
+    CopyArgs a;
+    a.src = src; a.dst = dst; a.src_cs = src_cs; a.dst_cs = dst_cs;
+    a.CV = vec4 ? C / 4 : C;
+    a.total = npix * a.CV;
+    long blocks = (a.total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (vec4)
+        hipLaunchKernelGGL(copy_channels_kernel<true>, dim3((unsigned)blocks), dim3(256), 0,
+                           (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(copy_channels_kernel<false>, dim3((unsigned)blocks), dim3(256), 0,
+                           (hipStream_t)stream, a);
+    return pwc_launch_status();
+}
+
+// ------------------------------------------------------------------ misc
+extern "C" int pwc_version(void) { return 100; /* 0.1.0 */ }
+
+extern "C" const char* pwc_error_string(int code) {
+    switch (code) {
+        case PWC_OK: return "ok";
+        case PWC_EINVAL: return "invalid argument (null pointer, non-positive size or stride < channels)";
+        case PWC_EALIGN: return "pointer or channel stride not aligned as the kernel requires";
+        case PWC_ERANGE: return "tensor too large for the kernel's 32-bit indices";
+        case PWC_EUNSUPPORTED: return "unsupported configuration";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown pwc error";
+    }
+}

@@ -1,0 +1,172 @@
+"""PWCDCNet -- host-side mirror of reference model.py:74-138 on the HIP ops.
+
+Same constructor kwargs, call signature and return values as the reference class; the
+forward is eager (each op is enqueued on torch's current HIP stream) instead of a
+TF graph.  Inside ``__call__`` the modules' zero-copy ``_run`` forms are composed:
+
+  * both images go through the extractor as ONE stacked 2N batch (shared weights,
+    reference model.py:97-98);
+  * per level one zero-initialised buffer holds the estimator input
+    [cv | f0 | flow_up | feat_up] (+ the dense-connection conv outputs when use_dc);
+    the cost-volume kernel, the x2 resizes of the previous level and the convs write
+    straight into its channel slices, so no tf.concat copy exists;
+  * the bilinear warp (model.py:109) is fused into the cost-volume kernel, the
+    `flows_up * scales[l]` multiply into its flow read.
+"""
+import torch
+
+from . import _lib
+from .modules import (ContextNetwork, CostVolumeLayer, FeaturePyramidExtractor_custom,
+                      OpticalFlowEstimator_custom, VariableStore, View, WarpingLayer, _copy_channels,
+                      _resize, as_view, sub_view, variable_scope)
+from .weights import ChannelLayout, SCALES
+
+
+class PWCDCNet(object):
+    def __init__(self, num_levels=6, search_range=4, warp_type="bilinear", use_dc=False,
+                 output_level=4, name="pwcdcnet", seed=0, fuse_warp=True):
+        self.num_levels = num_levels
+        self.s_range = search_range
+        self.warp_type = warp_type
+        self.use_dc = use_dc
+        assert output_level < num_levels, "Should set output_level < num_levels"
+        self.output_level = output_level
+        self.name = name
+        self.fuse_warp = fuse_warp
+
+        self.fp_extractor = FeaturePyramidExtractor_custom(self.num_levels)
+        self.warp_layer = WarpingLayer(self.warp_type)
+        self.cv_layer = CostVolumeLayer(search_range)
+        self.of_estimators = [OpticalFlowEstimator_custom(use_dc=self.use_dc, name=f"optflow_{l}")
+                              for l in range(self.num_levels)]
+        self.context = ContextNetwork(name="context")
+        # Upscale factors from deep -> shallow level (reference model.py:93)
+        self.scales = list(SCALES)
+
+        _lib.lib()  # fail now, loudly, if the HIP library is missing
+        self.store = VariableStore(seed=seed)
+        self._buffers = {}
+
+    # ------------------------------------------------------------------ variables
+    @property
+    def vars(self):
+        return [v for v in self.store.vars.values() if self.name in v.name]
+
+    def load_weights(self, weights):
+        """weights: {'<name>/<scope>/conv2d[_k]/kernel' | '.../bias': array} (the
+        reference checkpoint's variable names, without the ':0')."""
+        for k, v in weights.items():
+            self.store.assign(k, v)
+
+    # ------------------------------------------------------------------ buffers
+    def _zeros(self, tag, shape, device):
+        key = (tag,) + tuple(shape) + (str(device),)
+        b = self._buffers.get(key)
+        if b is None:
+            b = torch.zeros(shape, dtype=torch.float32, device=device)
+            self._buffers[key] = b
+        return b
+
+    # ------------------------------------------------------------------ forward
+    def __call__(self, images_0, images_1, with_features=False, reuse=False):
+        iv0, images_0 = as_view(images_0, "images_0")
+        iv1, images_1 = as_view(images_1, "images_1")
+        assert iv0[2:] == iv1[2:], "image batches must have equal shapes"
+        dev = images_0.device
+        N = iv0.N
+        with variable_scope(self.name, store=self.store):
+            stacked = self.fp_extractor._run([iv0, iv1], dev)[::-1]   # deep -> shallow, 2N batch
+            pyramid_0 = [f[:N] for f in stacked]
+
+            flows_pyramid = []
+            fu_map = None          # physical->logical map of the feat_up segment
+            nxt = None             # (buffer tensor, layout) prepared for the current level
+            for l, F in enumerate(stacked):
+                _, h, w, C = F.shape
+                f0 = View(F.data_ptr(), C, N, h, w, C)
+                f1 = View(F.data_ptr() + 4 * N * h * w * C, C, N, h, w, C)
+                est = self.of_estimators[l]
+                is_out = (l == self.output_level)
+
+                if nxt is None:
+                    lay = est._layout((2 * self.s_range + 1) ** 2, C, l > 0, fu_map)
+                    E_t, E_off, cx = self._level_buffer(l, lay, N, h, w, dev, is_out)
+                else:
+                    E_t, E_off, lay, cx = nxt
+                E = View(E_t.data_ptr() + 4 * E_off, E_t.shape[3], N, h, w, lay.n_phys)
+
+                # Warping + cost volume (model.py:105-112)
+                cv_out = sub_view(E, lay.offset("cv"), (2 * self.s_range + 1) ** 2)
+                if l == 0:
+                    self.cv_layer._run(f0, f1, cv_out)
+                else:
+                    flow_v = sub_view(E, lay.offset("flow"), 2)
+                    if self.warp_type == "bilinear" and self.fuse_warp:
+                        self.cv_layer._run(f0, f1, cv_out, flow=flow_v, flow_scale=self.scales[l])
+                    else:
+                        f1w_t = torch.empty((N, h, w, C), dtype=torch.float32, device=dev)
+                        f1w = View(f1w_t.data_ptr(), C, N, h, w, C)
+                        self.warp_layer._run(f1, flow_v, f1w, flow_scale=self.scales[l])
+                        self.cv_layer._run(f0, f1w, cv_out)
+                _copy_channels(f0, sub_view(E, lay.offset("f0"), C), C)
+
+                flows_t = torch.empty((N, h, w, 2), dtype=torch.float32, device=dev)
+                flows_v = View(flows_t.data_ptr(), 2, N, h, w, 2)
+                if not is_out:
+                    # Optical flow estimation + x2 upsampling into the next level's buffer
+                    # (model.py:114-116, modules.py:282-285)
+                    if self.use_dc:
+                        est._run(E, lay, flows_v)
+                        feat_v, nfu = View(E.ptr, E.cs, N, h, w, lay.n_phys), list(lay.phys2log)
+                    else:
+                        feat_v, _keep = est._run(E, lay, flows_v)
+                        nfu = list(range(feat_v.C))
+                    Fn = stacked[l + 1]
+                    _, h2, w2, C2 = Fn.shape
+                    assert (h2, w2) == (2 * h, 2 * w), "pyramid levels must double in size"
+                    nlay = self.of_estimators[l + 1]._layout((2 * self.s_range + 1) ** 2, C2, True, nfu)
+                    nE_t, nE_off, ncx = self._level_buffer(l + 1, nlay, N, h2, w2, dev,
+                                                           l + 1 == self.output_level)
+                    nE = View(nE_t.data_ptr() + 4 * nE_off, nE_t.shape[3], N, h2, w2, nlay.n_phys)
+                    _resize(flows_v, sub_view(nE, nlay.offset("flow"), 2))
+                    _resize(feat_v, sub_view(nE, nlay.offset("feat_up"), feat_v.C))
+                    nxt = (nE_t, nE_off, nlay, ncx)
+                    flows_pyramid.append(flows_t)
+                    continue
+
+                # At output level (model.py:117-132)
+                cx_t, cx_lay = cx
+                CX = View(cx_t.data_ptr(), cx_lay.n_phys, N, h, w, cx_lay.n_phys)
+                ctx_flow = sub_view(CX, cx_lay.offset("flow"), 2)
+                if self.use_dc:
+                    est._run(E, lay, ctx_flow)
+                else:
+                    est._run(E, lay, ctx_flow,
+                             feat_out=sub_view(CX, cx_lay.offset("features"), est.filters[-1]))
+                self.context._run(CX, cx_lay, flows_v)
+                flows_pyramid.append(flows_t)
+                upscale = 2 ** (self.num_levels - self.output_level)
+                flows_final = torch.empty((N, h * upscale, w * upscale, 2), dtype=torch.float32, device=dev)
+                _resize(flows_v, View(flows_final.data_ptr(), 2, N, h * upscale, w * upscale, 2), mul=20.0)
+                if with_features:
+                    return flows_final, flows_pyramid, pyramid_0
+                else:
+                    return flows_final, flows_pyramid
+
+    def _level_buffer(self, l, lay, N, h, w, dev, is_out):
+        """Zero-initialised estimator buffer of level l.  At the output level with dense
+        connections the estimator's buffer IS the `features` segment of the context
+        network's input buffer ([flows | features], modules.py:305)."""
+        if not is_out:
+            return self._zeros(f"est{l}", (N, h, w, lay.n_phys), dev), 0, None
+        cx_lay = ChannelLayout()
+        cx_lay.add("flow", 2)
+        if self.use_dc:
+            cx_lay.add("features", lay.n_phys, log_map=list(lay.phys2log))
+        else:
+            cx_lay.add("features", self.of_estimators[l].filters[-1])
+        cx_lay.finish(16)
+        cx_t = self._zeros(f"ctx{l}", (N, h, w, cx_lay.n_phys), dev)
+        if self.use_dc:
+            return cx_t, cx_lay.offset("features"), (cx_t, cx_lay)
+        return self._zeros(f"est{l}", (N, h, w, lay.n_phys), dev), 0, (cx_t, cx_lay)

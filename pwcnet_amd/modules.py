@@ -1,0 +1,494 @@
+"""Host-side mirror of the reference's modules.py op classes on top of libpwc_hip.so.
+
+Same class names, constructor kwargs, call signatures and NHWC float32 tensor
+conventions as reference modules.py:42-326 (FeaturePyramidExtractor_custom,
+WarpingLayer, CostVolumeLayer, OpticalFlowEstimator_custom, ContextNetwork); torch-ROCm
+tensors are only memory handles (data_ptr + strides) for the HIP kernels.
+
+Variables follow TensorFlow's lazy-creation model: a module creates (or re-uses, by
+name) its ``<scope>/conv2d[_k]/{kernel,bias}`` variables in a VariableStore on first
+call, numbered per call like tf.layers does inside a re-entered variable scope -- this
+is what makes both pyramid extractions share one weight set (reference model.py:97-98).
+
+Every public ``__call__`` accepts/returns ordinary logical tensors.  The ``_run*``
+methods are the zero-copy forms PWCDCNet composes: producers write straight into the
+channel slices of the consumer's buffer (ChannelLayout), so tf.concat costs nothing.
+"""
+import collections
+import contextlib
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .weights import FILTERS_FP, FILTERS_OF, CONTEXT, ChannelLayout
+
+View = collections.namedtuple("View", "ptr cs N H W C")
+
+
+# ---------------------------------------------------------------- tensor plumbing
+
+def _check_tensor(t, what):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{what}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise _lib.PwcHipError(f"{what}: tensor is on {t.device}; pwcnet_amd runs on the GPU only")
+    if t.dtype != torch.float32 or t.dim() != 4:
+        raise ValueError(f"{what}: expected a 4-D float32 NHWC tensor, got {t.dtype} {tuple(t.shape)}")
+
+
+def _pixel_dense(t):
+    N, H, W, C = t.shape
+    s = t.stride()
+    cs = s[2]
+    return (s[3] == 1 or C == 1) and cs >= C and s[1] == W * cs and s[0] == H * W * cs
+
+
+def as_view(t, what="tensor"):
+    """(ptr, channel stride) of an NHWC tensor whose pixels are laid out densely
+    (a channel slice of a wider buffer qualifies); anything else is made contiguous."""
+    _check_tensor(t, what)
+    if not _pixel_dense(t):
+        t = t.contiguous()
+    N, H, W, C = t.shape
+    return View(t.data_ptr(), t.stride(2), N, H, W, C), t
+
+
+def sub_view(v, off, C):
+    return View(v.ptr + 4 * off, v.cs, v.N, v.H, v.W, C)
+
+
+def _same_out(size, stride):
+    return -(-size // stride)
+
+
+def _p(ptr):
+    return _lib.ctypes.c_void_p(ptr)
+
+
+# ---------------------------------------------------------------- variables
+
+class Variable:
+    """A named model variable (mirrors the bits of tf.Variable the reference touches:
+    `.name`, `.shape`)."""
+
+    def __init__(self, name, value):
+        self.name = name + ":0"
+        self.key = name
+        self.value = value
+
+    @property
+    def shape(self):
+        return tuple(self.value.shape)
+
+    def __repr__(self):
+        return f"<Variable {self.name} shape={self.shape}>"
+
+
+class VariableStore:
+    """name -> Variable.  Creation follows tf.layers.Conv2D defaults: kernel
+    glorot_uniform, bias zeros."""
+
+    def __init__(self, seed=0, device="cuda"):
+        self.vars = collections.OrderedDict()
+        self.device = device
+        self._rng = np.random.RandomState(seed)
+        self.version = 0
+
+    def get(self, name, shape, kind):
+        v = self.vars.get(name)
+        if v is not None:
+            if tuple(v.shape) != tuple(shape):
+                raise ValueError(f"variable {name} has shape {v.shape}, requested {tuple(shape)}")
+            return v
+        if kind == "kernel":
+            limit = math.sqrt(6.0 / (9 * shape[2] + 9 * shape[3]))
+            val = self._rng.uniform(-limit, limit, size=shape).astype(np.float32)
+        else:
+            val = np.zeros(shape, np.float32)
+        v = Variable(name, torch.from_numpy(val).to(self.device))
+        self.vars[name] = v
+        return v
+
+    def assign(self, name, value):
+        t = torch.as_tensor(np.ascontiguousarray(value, dtype=np.float32)).to(self.device)
+        if name in self.vars:
+            if tuple(self.vars[name].shape) != tuple(t.shape):
+                raise ValueError(f"assign {name}: shape {tuple(t.shape)} != {self.vars[name].shape}")
+            self.vars[name].value = t
+        else:
+            self.vars[name] = Variable(name, t)
+        self.version += 1
+
+
+_DEFAULT_STORE = None
+_SCOPE = []
+_STORE_STACK = []
+
+
+def default_store():
+    global _DEFAULT_STORE
+    if _STORE_STACK:
+        return _STORE_STACK[-1]
+    if _DEFAULT_STORE is None:
+        _DEFAULT_STORE = VariableStore()
+    return _DEFAULT_STORE
+
+
+@contextlib.contextmanager
+def variable_scope(name, store=None):
+    """Minimal counterpart of tf.variable_scope: prefixes variable names, optionally
+    selects the VariableStore used inside."""
+    _SCOPE.append(name)
+    if store is not None:
+        _STORE_STACK.append(store)
+    try:
+        yield
+    finally:
+        _SCOPE.pop()
+        if store is not None:
+            _STORE_STACK.pop()
+
+
+def _scoped(name):
+    return "/".join(_SCOPE + [name])
+
+
+# ---------------------------------------------------------------- conv layer
+
+class _ConvRunner:
+    """Runs the convs of one module call; numbers them conv2d, conv2d_1, ... like
+    tf.layers does inside a (re-entered) variable scope."""
+
+    def __init__(self, owner):
+        self.owner = owner
+        self.k = 0
+        self.scope = _scoped(owner.name)
+        self.store = default_store()
+
+    def conv(self, x, cout, y=None, stride=1, dilation=1, slope=0.1, cin_map=None,
+             cin_logical=None, residual=None, tile=-1):
+        """x: View over the PHYSICAL input channels.  cin_map: physical->logical map (or
+        None = identity).  Returns (View y, tensor or None)."""
+        name = self.scope + "/conv2d" + ("" if self.k == 0 else f"_{self.k}")
+        self.k += 1
+        cin = x.C if cin_logical is None else cin_logical
+        kern = self.store.get(name + "/kernel", (3, 3, cin, cout), "kernel")
+        bias = self.store.get(name + "/bias", (cout,), "bias")
+        Ho, Wo = _same_out(x.H, stride), _same_out(x.W, stride)
+        y_t = None
+        if y is None:
+            y_t = torch.empty((x.N, Ho, Wo, cout), dtype=torch.float32, device=kern.value.device)
+            y = View(y_t.data_ptr(), cout, x.N, Ho, Wo, cout)
+        assert (y.N, y.H, y.W, y.C) == (x.N, Ho, Wo, cout), (y, x, stride)
+        L = _lib.lib()
+        s = _lib.current_stream()
+        act = 0 if slope is None else 1
+        sl = 0.0 if slope is None else float(slope)
+        use_mfma = (cout % 16 == 0 and x.C % 16 == 0 and x.cs % 4 == 0 and x.ptr % 16 == 0
+                    and residual is None)
+        cache = self.owner._cache
+        if use_mfma:
+            key = (name, "mfma", x.C, None if cin_map is None else cin_map.tobytes(), self.store.version)
+            packed = cache.get(key)
+            if packed is None:
+                nfl = L.pwc_conv3x3_packed_floats(x.C, cout)
+                packed = torch.empty((nfl,), dtype=torch.float32, device=kern.value.device)
+                cm = None
+                if cin_map is not None:
+                    assert len(cin_map) == x.C
+                    cm = torch.from_numpy(np.ascontiguousarray(cin_map, np.int32)).to(kern.value.device)
+                _lib.check(L.pwc_conv3x3_pack_f32(_p(kern.value.data_ptr()),
+                                                  _p(cm.data_ptr()) if cm is not None else None,
+                                                  cin, x.C, cout, _p(packed.data_ptr()), s), "conv3x3 pack")
+                cache[key] = packed
+                cache[key + ("cm",)] = cm
+            _lib.check(L.pwc_conv3x3_f32(_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()),
+                                         _p(y.ptr), y.cs, x.N, x.H, x.W, x.C, cout, stride, dilation,
+                                         act, sl, tile, s), f"conv3x3 {name}")
+        else:
+            w = kern.value
+            if cin_map is not None:
+                key = (name, "direct", x.C, cin_map.tobytes(), self.store.version)
+                w = cache.get(key)
+                if w is None:
+                    idx = torch.from_numpy(np.ascontiguousarray(cin_map, np.int64)).to(kern.value.device)
+                    w = torch.zeros((3, 3, x.C, cout), dtype=torch.float32, device=kern.value.device)
+                    valid = idx >= 0
+                    w[:, :, valid, :] = kern.value[:, :, idx[valid], :]
+                    w = w.contiguous()
+                    cache[key] = w
+            elif x.C != cin:
+                raise ValueError(f"{name}: input has {x.C} channels, kernel expects {cin}")
+            r_ptr, r_cs = (None, 0) if residual is None else (_p(residual.ptr), residual.cs)
+            _lib.check(L.pwc_conv3x3_direct_f32(_p(x.ptr), x.cs, _p(w.data_ptr()), _p(bias.value.data_ptr()),
+                                                _p(y.ptr), y.cs, r_ptr, r_cs, x.N, x.H, x.W, x.C, cout,
+                                                stride, dilation, act, sl, s), f"conv3x3_direct {name}")
+        return y, y_t
+
+
+class _Module:
+    def __init__(self, name):
+        self.name = name
+        self._cache = {}
+
+
+def _copy_channels(src, dst, C):
+    """dst[..., 0:C] = src[..., 0:C] (both Views over the same pixel grid)."""
+    assert (src.N, src.H, src.W) == (dst.N, dst.H, dst.W)
+    _lib.check(_lib.lib().pwc_copy_channels_f32(_p(src.ptr), src.cs, _p(dst.ptr), dst.cs,
+                                                src.N * src.H * src.W, C, _lib.current_stream()),
+               "copy_channels")
+
+
+def _resize(src, dst, mul=1.0):
+    _lib.check(_lib.lib().pwc_resize_bilinear_f32(_p(src.ptr), src.cs, _p(dst.ptr), dst.cs, src.N, src.H,
+                                                  src.W, src.C, dst.H, dst.W, float(mul),
+                                                  _lib.current_stream()), "resize_bilinear")
+
+
+def resize_bilinear(x, size, mul=1.0):
+    """tf.image.resize_bilinear(x, size) * mul with TF-1.8 legacy sampling (reference
+    modules.py:283-284, model.py:127)."""
+    xv, x = as_view(x, "resize_bilinear input")
+    out = torch.empty((xv.N, int(size[0]), int(size[1]), xv.C), dtype=torch.float32, device=x.device)
+    _resize(xv, View(out.data_ptr(), xv.C, xv.N, int(size[0]), int(size[1]), xv.C), mul)
+    return out
+
+
+# ---------------------------------------------------------------- extractor (a6)
+
+class FeaturePyramidExtractor_custom(_Module):
+    """Feature pyramid extractor (reference modules.py:42-71): per level a stride-2 conv
+    and two stride-1 convs, all 3x3 + leaky_relu(0.1); returns deep -> shallow."""
+
+    def __init__(self, num_levels=6, name="fp_extractor"):
+        super().__init__(name)
+        self.num_levels = num_levels
+        self.filters = list(FILTERS_FP)
+
+    def _run(self, image_views, device):
+        """image_views: Views of one or two image batches that share the weights; they
+        are convolved into ONE stacked batch (first layer per input, the remaining 17
+        layers once on the stack).  Returns the list of stacked feature tensors,
+        shallow -> deep."""
+        run = _ConvRunner(self)
+        v0 = image_views[0]
+        n_tot = sum(v.N for v in image_views)
+        feats = []
+        x = None
+        for l in range(self.num_levels):
+            f = self.filters[l]
+            if l == 0:
+                Ho, Wo = _same_out(v0.H, 2), _same_out(v0.W, 2)
+                y_t = torch.empty((n_tot, Ho, Wo, f), dtype=torch.float32, device=device)
+                n_off = 0
+                for iv in image_views:
+                    yv = View(y_t.data_ptr() + 4 * n_off * Ho * Wo * f, f, iv.N, Ho, Wo, f)
+                    run.k = 0
+                    run.conv(iv, f, y=yv, stride=2)
+                    n_off += iv.N
+                x = View(y_t.data_ptr(), f, n_tot, Ho, Wo, f)
+            else:
+                x, y_t = run.conv(x, f, stride=2)
+            x, t1 = run.conv(x, f)
+            x, t2 = run.conv(x, f)
+            feats.append(t2)
+        return feats
+
+    def __call__(self, images, reuse=True):
+        iv, images = as_view(images, "images")
+        feats = self._run([iv], images.device)
+        return feats[::-1]
+
+
+# ---------------------------------------------------------------- warping (a2 / a3)
+
+class WarpingLayer(_Module):
+    """Backward warping by a per-pixel flow (reference modules.py:140-154)."""
+
+    def __init__(self, warp_type="nearest", name="warping"):
+        super().__init__(name)
+        self.warp = warp_type
+
+    def _run(self, x, flow, out, flow_scale=1.0):
+        assert self.warp in ["nearest", "bilinear"]
+        L = _lib.lib()
+        fn = L.pwc_warp_bilinear_f32 if self.warp == "bilinear" else L.pwc_warp_nearest_f32
+        _lib.check(fn(_p(x.ptr), x.cs, _p(flow.ptr), flow.cs, float(flow_scale), _p(out.ptr), out.cs,
+                      x.N, x.H, x.W, x.C, _lib.current_stream()), f"warp_{self.warp}")
+
+    def __call__(self, x, flow):
+        assert self.warp in ["nearest", "bilinear"]
+        xv, x = as_view(x, "x")
+        fv, flow = as_view(flow, "flow")
+        assert (fv.N, fv.H, fv.W, fv.C) == (xv.N, xv.H, xv.W, 2), "flow must be (N,H,W,2)"
+        out = torch.empty((xv.N, xv.H, xv.W, xv.C), dtype=torch.float32, device=x.device)
+        self._run(xv, fv, View(out.data_ptr(), xv.C, xv.N, xv.H, xv.W, xv.C))
+        return out
+
+
+# ---------------------------------------------------------------- cost volume (a1)
+
+class CostVolumeLayer(_Module):
+    """Cost volume (reference modules.py:185-204): (2R+1)^2 shifted channel-mean dot
+    products, vertical shift outer / horizontal inner, leaky_relu(0.1)."""
+
+    def __init__(self, search_range=4, name="cost_volume"):
+        super().__init__(name)
+        self.s_range = search_range
+
+    def _run(self, f0, f1, out, flow=None, flow_scale=1.0):
+        """flow given: f1 is the UN-warped map and the bilinear warp is fused in."""
+        L = _lib.lib()
+        s = _lib.current_stream()
+        if flow is None:
+            rc = L.pwc_cost_volume_f32(_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(out.ptr), out.cs,
+                                       f0.N, f0.H, f0.W, f0.C, self.s_range, 0.1, s)
+        else:
+            rc = L.pwc_warp_cost_volume_f32(_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(flow.ptr), flow.cs,
+                                            float(flow_scale), _p(out.ptr), out.cs, f0.N, f0.H, f0.W, f0.C,
+                                            self.s_range, 0.1, s)
+        _lib.check(rc, "cost_volume")
+
+    def __call__(self, features_0, features_0from1):
+        f0, features_0 = as_view(features_0, "features_0")
+        f1, features_0from1 = as_view(features_0from1, "features_0from1")
+        assert f0[2:] == f1[2:], "feature maps must have equal shapes"
+        D = (2 * self.s_range + 1) ** 2
+        out = torch.empty((f0.N, f0.H, f0.W, D), dtype=torch.float32, device=features_0.device)
+        self._run(f0, f1, View(out.data_ptr(), D, f0.N, f0.H, f0.W, D))
+        return out
+
+
+# ---------------------------------------------------------------- flow estimator (a4)
+
+class OpticalFlowEstimator_custom(_Module):
+    """Optical flow estimator (reference modules.py:227-285)."""
+
+    def __init__(self, use_dc=False, name="of_estimator"):
+        super().__init__(name)
+        self.filters = list(FILTERS_OF)
+        self.use_dc = use_dc
+
+    # -- layout of the buffer holding the (growing) `features` tensor
+    def _layout(self, c_cv, c_f0, has_flow, fu_map):
+        lay = ChannelLayout()
+        if self.use_dc:
+            for k in reversed(range(len(self.filters))):
+                lay.add(f"conv{k}", self.filters[k])
+        lay.add("cv", c_cv)
+        if c_f0:
+            lay.add("f0", c_f0)
+        if has_flow:
+            lay.add("flow", 2)
+        if fu_map is not None:
+            lay.add("feat_up", len(fu_map), log_map=list(fu_map))
+        return lay.finish(16)
+
+    def _run(self, buf, lay, flows_out, feat_out=None):
+        """buf: View of the (N,h,w,lay.n_phys) buffer whose cv/f0/flow/feat_up segments
+        are already filled (padding channels zero).  Writes `flows` (2 ch) to flows_out.
+        non-DC: the 32-channel features go to feat_out (a View) -- DC: they are `buf`."""
+        run = _ConvRunner(self)
+        res = sub_view(buf, lay.offset("flow"), 2) if "flow" in lay.segments else None
+        if self.use_dc:
+            n_conv = sum(self.filters)
+            start = lay.offset("cv")
+            done = 0
+            for k, f in enumerate(self.filters):
+                off = lay.offset(f"conv{k}")
+                x = sub_view(buf, start, lay.n_phys - start)
+                cm = lay.cin_map(start, logical_base=n_conv - done)
+                run.conv(x, f, y=sub_view(buf, off, f), cin_map=cm, cin_logical=lay.n_logical - (n_conv - done))
+                start, done = off, done + f
+            head_in = buf
+            run.conv(View(buf.ptr, buf.cs, buf.N, buf.H, buf.W, lay.n_phys), 2, y=flows_out, slope=None,
+                     cin_map=lay.cin_map(0, 0), cin_logical=lay.n_logical, residual=res)
+            return head_in
+        x = View(buf.ptr, buf.cs, buf.N, buf.H, buf.W, lay.n_phys)
+        keep = []
+        cm, cl = lay.cin_map(0, 0), lay.n_logical
+        for k, f in enumerate(self.filters):
+            y = feat_out if (k == len(self.filters) - 1 and feat_out is not None) else None
+            x, t = run.conv(x, f, y=y, cin_map=cm, cin_logical=cl)
+            keep.append(t)
+            cm, cl = None, None
+        run.conv(x, 2, y=flows_out, slope=None, residual=res)
+        return x, keep[-1]
+
+    def __call__(self, cv, features_0=None, flows_up_prev=None, features_up_prev=None, is_output=False):
+        cvv, cv = as_view(cv, "cv")
+        dev = cv.device
+        ins = [("cv", cvv)]
+        for nm, t in (("f0", features_0), ("flow", flows_up_prev), ("feat_up", features_up_prev)):
+            if t is not None:
+                v, _t = as_view(t, nm)
+                assert (v.N, v.H, v.W) == (cvv.N, cvv.H, cvv.W)
+                ins.append((nm, v))
+        d = dict(ins)
+        lay = self._layout(cvv.C, d["f0"].C if "f0" in d else 0, "flow" in d,
+                           list(range(d["feat_up"].C)) if "feat_up" in d else None)
+        buf_t = torch.zeros((cvv.N, cvv.H, cvv.W, lay.n_phys), dtype=torch.float32, device=dev)
+        buf = View(buf_t.data_ptr(), lay.n_phys, cvv.N, cvv.H, cvv.W, lay.n_phys)
+        for nm, v in ins:
+            _copy_channels(v, sub_view(buf, lay.offset(nm), v.C), v.C)
+        flows = torch.empty((cvv.N, cvv.H, cvv.W, 2), dtype=torch.float32, device=dev)
+        fv = View(flows.data_ptr(), 2, cvv.N, cvv.H, cvv.W, 2)
+        if self.use_dc:
+            self._run(buf, lay, fv)
+            features = _gather_logical(buf_t, lay)
+        else:
+            _, features = self._run(buf, lay, fv)
+        if is_output:
+            return flows, features
+        h, w = cvv.H, cvv.W
+        return flows, resize_bilinear(flows, (2 * h, 2 * w)), resize_bilinear(features, (2 * h, 2 * w))
+
+
+def _gather_logical(buf_t, lay):
+    """Logical (TF channel order) copy of a physical buffer -- index_select on the
+    channel axis; only used by the public, non-fused call paths."""
+    p2l = np.asarray(lay.phys2log)
+    phys = np.nonzero(p2l >= 0)[0]
+    order = phys[np.argsort(p2l[phys], kind="stable")]
+    idx = torch.from_numpy(order.astype(np.int64)).to(buf_t.device)
+    return buf_t.index_select(3, idx).contiguous()
+
+
+# ---------------------------------------------------------------- context network (a5)
+
+class ContextNetwork(_Module):
+    """Context module (reference modules.py:290-326): 7 dilated 3x3 convs on
+    concat[flows, features], residual add of `flows`."""
+
+    def __init__(self, name="context"):
+        super().__init__(name)
+
+    def _run(self, buf, lay, out):
+        """buf: View of the (N,h,w,lay.n_phys) buffer with `flow` and `features` filled."""
+        run = _ConvRunner(self)
+        x = View(buf.ptr, buf.cs, buf.N, buf.H, buf.W, lay.n_phys)
+        cm, cl = lay.cin_map(0, 0), lay.n_logical
+        keep = []
+        for f, d in CONTEXT[:-1]:
+            x, t = run.conv(x, f, dilation=d, cin_map=cm, cin_logical=cl)
+            keep.append(t)
+            cm, cl = None, None
+        run.conv(x, 2, y=out, slope=None, residual=sub_view(buf, lay.offset("flow"), 2))
+
+    def __call__(self, flows, features):
+        fl, flows = as_view(flows, "flows")
+        ft, features = as_view(features, "features")
+        lay = ChannelLayout()
+        lay.add("flow", 2)
+        lay.add("features", ft.C)
+        lay.finish(16)
+        buf_t = torch.zeros((fl.N, fl.H, fl.W, lay.n_phys), dtype=torch.float32, device=flows.device)
+        buf = View(buf_t.data_ptr(), lay.n_phys, fl.N, fl.H, fl.W, lay.n_phys)
+        _copy_channels(fl, sub_view(buf, 0, 2), 2)
+        _copy_channels(ft, sub_view(buf, lay.offset("features"), ft.C), ft.C)
+        out = torch.empty((fl.N, fl.H, fl.W, 2), dtype=torch.float32, device=flows.device)
+        self._run(buf, lay, View(out.data_ptr(), 2, fl.N, fl.H, fl.W, 2))
+        return out

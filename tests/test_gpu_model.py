@@ -1,0 +1,198 @@
+"""GPU parity tests, module and model level: the host classes that mirror the reference's
+model.py / modules.py API against the CPU oracle (same seeded inputs and weights).
+
+Tolerance for the end-to-end forward is the one BASELINE.json's north_star states:
+max-abs 1e-3 per flow component on `flows_final` (pixels), i.e. 5e-5 on the px/20
+pyramid flows.  Module-level tolerances are tighter (1e-5 relative).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pa():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU (torch.cuda.is_available() is False)")
+    import pwcnet_amd
+    return pwcnet_amd
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    return np.random.RandomState(seed).uniform(lo, hi, size=shape).astype(np.float32)
+
+
+def gpu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(got, exp, rel=1e-5, floor=1e-6):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got
+    assert got.shape == exp.shape, (got.shape, exp.shape)
+    tol = max(floor, rel * float(np.abs(exp).max()))
+    err = float(np.abs(got - exp).max())
+    assert err <= tol, f"max abs err {err:.3e} > tol {tol:.3e}"
+
+
+def make_net(pa, use_dc=False, **kw):
+    w = util.model_weights(use_dc)
+    net = pa.PWCDCNet(use_dc=use_dc, **kw)
+    net.load_weights(w)
+    return net, w
+
+
+# ------------------------------------------------------------------ modules (public API)
+def test_extractor_module(pa):
+    from pwcnet_amd.modules import VariableStore, variable_scope
+    w = util.model_weights(False)
+    store = VariableStore()
+    for k, v in w.items():
+        store.assign(k, v)
+    im0, _ = util.images(2, 64, 128)
+    with variable_scope("pwcdcnet", store=store):
+        pyr = pa.FeaturePyramidExtractor_custom()(gpu(im0), reuse=False)
+    exp = orc.OraclePWCDCNet(w).extractor(im0)
+    assert [tuple(p.shape) for p in pyr] == [e.shape for e in exp]
+    for p, e in zip(pyr, exp):
+        close(p, e)
+
+
+@pytest.mark.parametrize("use_dc", [False, True])
+@pytest.mark.parametrize("level", [0, 2])
+def test_estimator_module(pa, use_dc, level):
+    from pwcnet_amd.modules import VariableStore, variable_scope
+    from pwcnet_amd import weights as W
+    w = util.model_weights(use_dc)
+    store = VariableStore()
+    for k, v in w.items():
+        store.assign(k, v)
+    C = W.pyramid_channels()[level]
+    N, h, wd = 2, 6 * 2 ** level, 10 * 2 ** level
+    cv, f0 = rnd((N, h, wd, 81), 40), rnd((N, h, wd, C), 41)
+    fl = fu = None
+    if level > 0:
+        fl = rnd((N, h, wd, 2), 42)
+        fu = rnd((N, h, wd, W.estimator_feature_channels(level - 1, use_dc)), 43)
+    onet = orc.OraclePWCDCNet(w, use_dc=use_dc)
+    e_flows, e_fup, e_featup = onet.estimator(level, cv, f0, fl, fu, False)
+    g = [None if a is None else gpu(a) for a in (cv, f0, fl, fu)]
+    with variable_scope("pwcdcnet", store=store):
+        est = pa.OpticalFlowEstimator_custom(use_dc=use_dc, name=f"optflow_{level}")
+        flows, fup, featup = est(*g)
+        flows2, feats2 = est(*g, is_output=True)
+    close(flows, e_flows)
+    close(fup, e_fup)
+    close(featup, e_featup)
+    close(flows2, e_flows)
+    _, e_feats = onet.estimator(level, cv, f0, fl, fu, True)
+    close(feats2, e_feats)
+
+
+def test_context_module(pa):
+    from pwcnet_amd.modules import VariableStore, variable_scope
+    w = util.model_weights(False)
+    store = VariableStore()
+    for k, v in w.items():
+        store.assign(k, v)
+    flows, feats = rnd((1, 40, 56, 2), 44), rnd((1, 40, 56, 32), 45)
+    with variable_scope("pwcdcnet", store=store):
+        out = pa.ContextNetwork(name="context")(gpu(flows), gpu(feats))
+    close(out, orc.OraclePWCDCNet(w).context(flows, feats))
+
+
+def test_lazy_variable_creation_names_and_count(pa):
+    net = pa.PWCDCNet()
+    im0, im1 = util.images(1, 64, 64)
+    net(gpu(im0), gpu(im1))
+    names = [v.name for v in net.vars]
+    assert len(names) == 110 and sum(int(np.prod(v.shape)) for v in net.vars) == 5029868
+    assert "pwcdcnet/fp_extractor/conv2d/kernel:0" in names and "pwcdcnet/fp_extractor/conv2d_17/bias:0" in names
+    assert "pwcdcnet/optflow_4/conv2d_5/kernel:0" in names and "pwcdcnet/context/conv2d_6/kernel:0" in names
+    assert not any("optflow_5" in n for n in names)          # never called at output_level 4
+    with pytest.raises(AssertionError):
+        pa.PWCDCNet(num_levels=4, output_level=4)            # reference model.py:82
+
+
+# ------------------------------------------------------------------ end to end
+@pytest.mark.parametrize("use_dc", [False, True])
+def test_e2e_golden_64x128(pa, use_dc, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"e2e_64x128_dc{int(use_dc)}.npz"))
+    net, _ = make_net(pa, use_dc)
+    final, pyr = net(gpu(g["images_0"]), gpu(g["images_1"]))
+    assert final.shape == (1, 64, 128, 2) and len(pyr) == 5
+    err = float(np.abs(final.cpu().numpy() - g["flows_final"]).max())
+    assert err <= 1e-3, err
+    for l, p in enumerate(pyr):
+        assert float(np.abs(p.cpu().numpy() - g[f"flows_{l}"]).max()) <= 5e-5
+    assert float(np.abs(g["flows_final"]).max()) > 0.5      # the comparison is not vacuous
+
+
+def test_e2e_batch_and_features_vs_oracle(pa):
+    net, w = make_net(pa, False)
+    im0, im1 = util.smooth_images(2, 128, 192, seed=11, shift=(-4, 2))
+    final, pyr, feats = net(gpu(im0), gpu(im1), with_features=True)
+    e_final, e_pyr, e_feats = orc.OraclePWCDCNet(w)(im0, im1, with_features=True)
+    assert float(np.abs(final.cpu().numpy() - e_final).max()) <= 1e-3
+    for p, e in zip(pyr, e_pyr):
+        assert float(np.abs(p.cpu().numpy() - e).max()) <= 5e-5
+    for f, e in zip(feats, e_feats):
+        close(f, e)
+    # EPE (reference losses.py:11-13) between HIP and oracle flows
+    assert orc.epe(e_final, final.cpu().numpy()) <= 1e-4
+
+
+def test_e2e_unfused_warp_and_nearest_variants(pa):
+    im0, im1 = util.smooth_images(1, 64, 128, seed=12)
+    net_f, w = make_net(pa, False)
+    net_u, _ = make_net(pa, False, fuse_warp=False)
+    a, _ = net_f(gpu(im0), gpu(im1))
+    b, _ = net_u(gpu(im0), gpu(im1))
+    assert float((a - b).abs().max()) <= 2e-4
+    net_n, _ = make_net(pa, False, warp_type="nearest")
+    c, _ = net_n(gpu(im0), gpu(im1))
+    e, _ = orc.OraclePWCDCNet(w, warp_type="nearest")(im0, im1)
+    # nearest warping is discontinuous in the flow: allow isolated pixels to flip
+    d = np.abs(c.cpu().numpy() - e)
+    assert float(np.median(d)) <= 1e-4 and float((d > 1e-3).mean()) < 0.02
+
+
+def test_e2e_deterministic_and_buffer_reuse(pa):
+    net, _ = make_net(pa, False)
+    im0, im1 = util.smooth_images(1, 64, 128, seed=13)
+    a, pa_ = net(gpu(im0), gpu(im1))
+    a = a.clone()
+    other0, other1 = util.images(1, 64, 128, seed=99)
+    net(gpu(other0), gpu(other1))
+    b, _ = net(gpu(im0), gpu(im1))
+    assert torch.equal(a, b)
+
+
+def test_e2e_full_size_448x1024_vs_oracle(pa):
+    """BASELINE config shape (one 448x1024 Sintel-shaped pair) against the oracle."""
+    net, w = make_net(pa, False)
+    im0, im1 = util.smooth_images(1, 448, 1024, seed=14, shift=(5, -3))
+    final, pyr = net(gpu(im0), gpu(im1))
+    e_final, e_pyr = orc.OraclePWCDCNet(w)(im0, im1)
+    err = float(np.abs(final.cpu().numpy() - e_final).max())
+    assert err <= 1e-3, err
+    assert final.shape == (1, 448, 1024, 2)
+    assert [tuple(p.shape[1:3]) for p in pyr] == [(7, 16), (14, 32), (28, 64), (56, 128), (112, 256)]
+
+
+def test_e2e_batch8_matches_single_pair(pa):
+    """size-independent property at the bench batch: pair i of a batch of 8 equals the
+    same pair run alone (pairs are independent)."""
+    net, _ = make_net(pa, False)
+    im0, im1 = util.smooth_images(8, 128, 256, seed=15)
+    f8, _ = net(gpu(im0), gpu(im1))
+    f8 = f8.clone()
+    for i in (0, 5, 7):
+        f1, _ = net(gpu(im0[i:i + 1]), gpu(im1[i:i + 1]))
+        assert float((f8[i:i + 1] - f1).abs().max()) <= 1e-5

@@ -1,0 +1,333 @@
+"""GPU parity tests, op level: every HIP kernel (called through the C ABI via the
+pwcnet_amd host classes / ctypes) against the CPU oracle on the same seeded inputs.
+
+Tolerances (floating point, fp32 everywhere): the kernels sum in a different order than
+the oracle, so results are compared with atol scaled to the magnitude of the sums:
+1e-5 relative to max|y| for convolutions/correlations, 1e-6 for gathers/lerps.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pa():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU (torch.cuda.is_available() is False)")
+    import pwcnet_amd
+    from pwcnet_amd import _lib
+    _lib.lib()
+    return pwcnet_amd
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    return np.random.RandomState(seed).uniform(lo, hi, size=shape).astype(np.float32)
+
+
+def gpu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def close(got, exp, rel=1e-5, floor=1e-6):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got
+    tol = max(floor, rel * float(np.abs(exp).max()))
+    err = float(np.abs(got - exp).max())
+    assert got.shape == exp.shape
+    assert err <= tol, f"max abs err {err:.3e} > tol {tol:.3e}"
+
+
+# ------------------------------------------------------------------ library surface
+def test_library_loaded_and_version(pa):
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    assert L.pwc_version() >= 100
+    assert b"align" in L.pwc_error_string(-2)
+    # the .so is in-tree (the driver records which native libraries the tests load)
+    assert os.path.dirname(_lib.LIB_PATH).endswith(os.path.join("pwcnet_amd", "csrc"))
+
+
+def test_argument_errors_are_reported_not_crashes(pa):
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    x = torch.zeros(1, 4, 4, 6, device="cuda")   # C = 6 is not a multiple of 4
+    o = torch.zeros(1, 4, 4, 81, device="cuda")
+    rc = L.pwc_cost_volume_f32(_p(x), 6, _p(x), 6, _p(o), 81, 1, 4, 4, 6, 4, 0.1, None)
+    assert rc == -2
+    rc = L.pwc_cost_volume_f32(None, 8, _p(x), 8, _p(o), 81, 1, 4, 4, 8, 4, 0.1, None)
+    assert rc == -1
+    with pytest.raises(_lib.PwcHipError):
+        _lib.check(rc, "cost_volume")
+    with pytest.raises(_lib.PwcHipError):
+        pa.CostVolumeLayer()(torch.zeros(1, 4, 4, 8), torch.zeros(1, 4, 4, 8))   # CPU tensors
+
+
+# ------------------------------------------------------------------ conv (MFMA implicit GEMM)
+def run_conv_mfma(x, k, b, stride, dil, slope, tile=-1, cin_map=None, cin_phys=None, y_cs=None):
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    N, H, W, cs = x.shape
+    cin, cout = k.shape[2], k.shape[3]
+    cin_phys = cs if cin_phys is None else cin_phys
+    xg, kg, bg = gpu(x), gpu(k), gpu(b)
+    packed = torch.empty(L.pwc_conv3x3_packed_floats(cin_phys, cout), device="cuda")
+    cm = None if cin_map is None else gpu(np.asarray(cin_map, np.int32))
+    _lib.check(L.pwc_conv3x3_pack_f32(_p(kg), _p(cm) if cm is not None else None, cin, cin_phys, cout,
+                                      _p(packed), None))
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    y_cs = cout if y_cs is None else y_cs
+    y = torch.full((N, Ho, Wo, y_cs), -7.0, device="cuda")
+    _lib.check(L.pwc_conv3x3_f32(_p(xg), cs, _p(packed), _p(bg), _p(y), y_cs, N, H, W, cin_phys, cout,
+                                 stride, dil, 0 if slope is None else 1, 0.0 if slope is None else slope,
+                                 tile, None))
+    torch.cuda.synchronize()
+    return y
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,stride,dil", [
+    (2, 12, 20, 16, 16, 1, 1), (2, 12, 20, 16, 32, 2, 1), (1, 24, 40, 32, 64, 1, 1),
+    (1, 14, 22, 96, 96, 2, 1), (1, 28, 64, 128, 128, 1, 1), (3, 7, 16, 192, 192, 1, 1),
+    (1, 40, 48, 48, 128, 1, 1), (1, 40, 48, 128, 128, 1, 2), (1, 40, 48, 128, 96, 1, 8),
+    (1, 40, 48, 96, 64, 1, 16), (1, 17, 33, 64, 32, 1, 1), (1, 9, 5, 32, 16, 2, 1),
+    (2, 56, 128, 160, 128, 1, 1)])
+def test_conv_mfma_vs_oracle(pa, N, H, W, cin, cout, stride, dil):
+    x = rnd((N, H, W, cin), 1)
+    k = rnd((3, 3, cin, cout), 2) * (1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 3) * 0.1
+    y = run_conv_mfma(x, k, b, stride, dil, 0.1)
+    close(y, orc.conv3x3(x, k, b, stride, dil, 0.1))
+
+
+@pytest.mark.parametrize("tile", list(range(15)))
+def test_conv_mfma_every_tile_config(pa, tile):
+    bn = [128, 96, 64, 32, 16, 128, 96, 64, 32, 16, 128, 96, 64, 32, 16][tile]
+    cout = {128: 128, 96: 192, 64: 64, 32: 32, 16: 48}[bn]
+    for cin in (16, 64):            # KC = 16 and KC = 32 instantiations
+        x = rnd((2, 19, 37, cin), 4 + tile)
+        k = rnd((3, 3, cin, cout), 5) * (1.0 / np.sqrt(9 * cin))
+        b = rnd((cout,), 6) * 0.1
+        y = run_conv_mfma(x, k, b, 1, 1, 0.1, tile=tile)
+        close(y, orc.conv3x3(x, k, b, 1, 1, 0.1))
+
+
+def test_conv_mfma_physical_layout_padding_and_strided_output(pa):
+    """estimator-style input: logical 147 channels scattered in a 160-channel buffer
+    (segments aligned to 4, zero padding channels), output into a channel slice."""
+    from pwcnet_amd.weights import estimator_layout
+    lay = estimator_layout(4, False)
+    assert (lay.n_phys, lay.n_logical) == (160, 147)
+    xl = rnd((1, 20, 24, lay.n_logical), 7)
+    p2l = np.asarray(lay.phys2log)
+    xp = np.zeros((1, 20, 24, lay.n_phys), np.float32)
+    xp[..., p2l >= 0] = xl[..., p2l[p2l >= 0]]
+    k = rnd((3, 3, 147, 128), 8) * 0.03
+    b = rnd((128,), 9) * 0.1
+    y = run_conv_mfma(xp, k, b, 1, 1, 0.1, cin_map=lay.cin_map(), y_cs=144)
+    exp = orc.conv3x3(xl, k, b, 1, 1, 0.1)
+    close(y[..., :128], exp)
+    assert float(y[..., 128:].min()) == -7.0 and float(y[..., 128:].max()) == -7.0   # untouched
+    # linear (no activation) variant
+    y2 = run_conv_mfma(xp, k, b, 1, 1, None, cin_map=lay.cin_map())
+    close(y2, orc.conv3x3(xl, k, b, 1, 1, None))
+
+
+def test_conv_mfma_linearity_full_size(pa):
+    """BASELINE-size property (oracle too slow to brute-force every layer at 8x448x1024):
+    conv(a*x1 + x2) - conv(0) is linear; checked on the 147->128 layer at 112x256, N=8."""
+    N, H, W, cin, cout = 8, 112, 256, 160, 128
+    k = rnd((3, 3, cin, cout), 10) * 0.03
+    b = rnd((cout,), 11) * 0.1
+    x1, x2 = rnd((N, H, W, cin), 12), rnd((N, H, W, cin), 13)
+    y0 = run_conv_mfma(np.zeros_like(x1), k, b, 1, 1, None)
+    y1 = run_conv_mfma(x1, k, b, 1, 1, None) - y0
+    y2 = run_conv_mfma(x2, k, b, 1, 1, None) - y0
+    y12 = run_conv_mfma(2.0 * x1 + x2, k, b, 1, 1, None) - y0
+    err = float((y12 - (2.0 * y1 + y2)).abs().max())
+    assert err <= 2e-5 * float(y12.abs().max()) + 1e-6
+    # and one image row band against the oracle
+    exp = orc.conv3x3(x1[:1], k, b, 1, 1, None)
+    close(run_conv_mfma(x1[:1], k, b, 1, 1, None), exp)
+
+
+# ------------------------------------------------------------------ conv (direct)
+def run_conv_direct(x, k, b, stride, dil, slope, residual=None):
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    N, H, W, cs = x.shape
+    cin, cout = k.shape[2], k.shape[3]
+    xg, kg, bg = gpu(x), gpu(k), gpu(b)
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    y = torch.empty((N, Ho, Wo, cout), device="cuda")
+    rg = None if residual is None else gpu(residual)
+    _lib.check(L.pwc_conv3x3_direct_f32(_p(xg), cs, _p(kg), _p(bg), _p(y), cout,
+                                        _p(rg) if rg is not None else None,
+                                        0 if rg is None else residual.shape[3], N, H, W, cin, cout, stride, dil,
+                                        0 if slope is None else 1, 0.0 if slope is None else slope, None))
+    torch.cuda.synchronize()
+    return y
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,stride,dil,slope", [
+    (2, 32, 64, 3, 16, 2, 1, 0.1), (1, 17, 23, 3, 16, 2, 1, 0.1), (2, 16, 24, 32, 2, 1, 1, None),
+    (1, 9, 11, 5, 7, 1, 2, 0.1), (1, 12, 12, 8, 13, 2, 1, None), (1, 10, 14, 36, 4, 1, 1, 0.1)])
+def test_conv_direct_vs_oracle(pa, N, H, W, cin, cout, stride, dil, slope):
+    x = rnd((N, H, W, cin), 14)
+    k = rnd((3, 3, cin, cout), 15) * (1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 16) * 0.1
+    close(run_conv_direct(x, k, b, stride, dil, slope), orc.conv3x3(x, k, b, stride, dil, slope))
+
+
+def test_conv_direct_residual_flow_head(pa):
+    x = rnd((2, 14, 18, 32), 17)
+    k = rnd((3, 3, 32, 2), 18) * 0.05
+    b = rnd((2,), 19) * 0.1
+    res = rnd((2, 14, 18, 2), 20)
+    close(run_conv_direct(x, k, b, 1, 1, None, residual=res), orc.conv3x3(x, k, b, 1, 1, None, residual=res))
+
+
+def test_conv_direct_equals_mfma(pa):
+    x = rnd((1, 21, 30, 64), 21)
+    k = rnd((3, 3, 64, 32), 22) * 0.05
+    b = rnd((32,), 23) * 0.1
+    a = run_conv_direct(x, k, b, 1, 1, 0.1)
+    m = run_conv_mfma(x, k, b, 1, 1, 0.1)
+    close(m, a.cpu().numpy())
+
+
+# ------------------------------------------------------------------ cost volume
+@pytest.mark.parametrize("N,H,W,C,R", [
+    (2, 7, 16, 192, 4), (2, 14, 32, 128, 4), (1, 28, 64, 96, 4), (1, 56, 128, 64, 4), (2, 20, 70, 32, 4),
+    (1, 5, 3, 8, 4), (1, 9, 130, 16, 4), (1, 12, 20, 4, 4), (1, 11, 37, 32, 2), (1, 8, 66, 16, 1),
+    (1, 8, 66, 24, 3)])
+def test_cost_volume_vs_oracle(pa, N, H, W, C, R):
+    f0, f1 = rnd((N, H, W, C), 24), rnd((N, H, W, C), 25)
+    cv = pa.CostVolumeLayer(R)(gpu(f0), gpu(f1))
+    close(cv, orc.cost_volume(f0, f1, R), rel=2e-6, floor=2e-7)
+
+
+def test_cost_volume_golden_and_strided_io(pa, golden_dir):
+    g = np.load(os.path.join(golden_dir, "ops_small.npz"))
+    close(pa.CostVolumeLayer(4)(gpu(g["cv_f0"]), gpu(g["cv_f1"])), g["cv_out"], rel=2e-6, floor=2e-7)
+    # inputs as channel slices of wider buffers, output into a slice (out_cs = 84)
+    from pwcnet_amd.modules import View, sub_view
+    N, H, W, C = g["cv_f0"].shape
+    big0 = torch.zeros(N, H, W, C + 8, device="cuda"); big0[..., 4:4 + C] = gpu(g["cv_f0"])
+    big1 = torch.zeros(N, H, W, C + 4, device="cuda"); big1[..., :C] = gpu(g["cv_f1"])
+    out = torch.full((N, H, W, 84), 5.0, device="cuda")
+    v0 = sub_view(View(big0.data_ptr(), C + 8, N, H, W, C + 8), 4, C)
+    v1 = View(big1.data_ptr(), C + 4, N, H, W, C)
+    pa.CostVolumeLayer(4)._run(v0, v1, View(out.data_ptr(), 84, N, H, W, 81))
+    close(out[..., :81], g["cv_out"], rel=2e-6, floor=2e-7)
+    assert float(out[..., 81:].min()) == 5.0
+
+
+def test_cost_volume_known_answers_gpu(pa):
+    f = rnd((1, 16, 16, 32), 15)
+    v, h = 2, -3
+    shifted = np.zeros_like(f)
+    shifted[:, v:, : 16 + h] = f[:, : 16 - v, -h:]
+    cv = pa.CostVolumeLayer(4)(gpu(f), gpu(shifted)).cpu().numpy()
+    assert int(np.argmax(cv[0, 6, 8])) == (v + 4) * 9 + (h + 4)
+    c = (f * shifted).mean(axis=3)
+    np.testing.assert_allclose(cv[..., 40], np.maximum(c, 0.1 * c), atol=1e-6)
+    assert cv[0, 0, 0, 0] == 0.0
+
+
+def test_cost_volume_full_size_properties(pa):
+    """BASELINE size (N=8, 112x256x32): symmetry property cv(f0,f1)[y,x,(v,h)] ==
+    cv(f1,f0)[y+v,x+h,(-v,-h)] and a row band against the oracle."""
+    N, H, W, C = 8, 112, 256, 32
+    f0, f1 = rnd((N, H, W, C), 26), rnd((N, H, W, C), 27)
+    a = pa.CostVolumeLayer(4)(gpu(f0), gpu(f1)).cpu().numpy()
+    b = pa.CostVolumeLayer(4)(gpu(f1), gpu(f0)).cpu().numpy()
+    for (v, h) in [(0, 0), (4, -4), (-3, 2), (1, 4)]:
+        d, dm = (v + 4) * 9 + (h + 4), (-v + 4) * 9 + (-h + 4)
+        ys, xs = slice(max(0, -v), H - max(0, v)), slice(max(0, -h), W - max(0, h))
+        yd, xd = slice(max(0, v), H - max(0, -v)), slice(max(0, h), W - max(0, -h))
+        np.testing.assert_allclose(a[:, ys, xs, d], b[:, yd, xd, dm], atol=1e-6)
+    exp = orc.cost_volume(f0[3:4], f1[3:4], 4)
+    np.testing.assert_allclose(a[3:4], exp, atol=1e-6)
+
+
+# ------------------------------------------------------------------ warp
+@pytest.mark.parametrize("wt", ["bilinear", "nearest"])
+@pytest.mark.parametrize("N,H,W,C", [(2, 14, 32, 128), (1, 56, 128, 64), (2, 9, 11, 4), (1, 28, 64, 96)])
+def test_warp_vs_oracle(pa, wt, N, H, W, C):
+    x = rnd((N, H, W, C), 28)
+    flow = util.flow_field(N, H, W, seed=29)
+    out = pa.WarpingLayer(wt)(gpu(x), gpu(flow))
+    exp = orc.warp(x, flow, wt)
+    if wt == "nearest":
+        np.testing.assert_array_equal(out.cpu().numpy(), exp)
+    else:
+        close(out, exp, rel=2e-6, floor=2e-6)
+
+
+def test_warp_golden_and_known_answers(pa, golden_dir):
+    g = np.load(os.path.join(golden_dir, "ops_small.npz"))
+    close(pa.WarpingLayer("bilinear")(gpu(g["warp_x"]), gpu(g["warp_flow"])), g["warp_bilinear"], rel=2e-6, floor=2e-6)
+    np.testing.assert_array_equal(pa.WarpingLayer("nearest")(gpu(g["warp_x"]), gpu(g["warp_flow"])).cpu().numpy(),
+                                  g["warp_nearest"])
+    x = rnd((1, 8, 12, 8), 30)
+    zero = np.zeros((1, 8, 12, 2), np.float32)
+    np.testing.assert_array_equal(pa.WarpingLayer("bilinear")(gpu(x), gpu(zero)).cpu().numpy(), x)
+    flow = zero.copy(); flow[..., 0], flow[..., 1] = 2.0, -3.0
+    exp = x[:, np.clip(np.arange(8) - 3, 0, 7)][:, :, np.clip(np.arange(12) + 2, 0, 11)]
+    np.testing.assert_array_equal(pa.WarpingLayer("bilinear")(gpu(x), gpu(flow)).cpu().numpy(), exp)
+    with pytest.raises(AssertionError):
+        pa.WarpingLayer("cubic")(gpu(x), gpu(flow))   # reference modules.py:149
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 14, 32, 128), (1, 28, 70, 32), (1, 56, 128, 64), (1, 6, 9, 16)])
+def test_fused_warp_cost_volume_vs_oracle(pa, N, H, W, C):
+    from pwcnet_amd.modules import View
+    f0, f1 = rnd((N, H, W, C), 31), rnd((N, H, W, C), 32)
+    flow = util.flow_field(N, H, W, seed=33) / 5.0
+    exp = orc.cost_volume(f0, orc.warp(f1, flow, "bilinear", flow_scale=5.0), 4)
+    g0, g1, gf = gpu(f0), gpu(f1), gpu(flow)
+    out = torch.empty((N, H, W, 81), device="cuda")
+    pa.CostVolumeLayer(4)._run(View(g0.data_ptr(), C, N, H, W, C), View(g1.data_ptr(), C, N, H, W, C),
+                               View(out.data_ptr(), 81, N, H, W, 81),
+                               flow=View(gf.data_ptr(), 2, N, H, W, 2), flow_scale=5.0)
+    close(out, exp, rel=4e-6, floor=4e-7)
+
+
+# ------------------------------------------------------------------ resize / copy
+@pytest.mark.parametrize("N,H,W,C,OH,OW,mul", [
+    (2, 7, 16, 2, 14, 32, 1.0), (2, 7, 16, 32, 14, 32, 1.0), (1, 112, 256, 2, 448, 1024, 20.0),
+    (1, 5, 6, 3, 10, 12, 1.0), (1, 4, 4, 8, 4, 4, 1.0), (1, 6, 10, 736, 12, 20, 1.0)])
+def test_resize_vs_oracle(pa, N, H, W, C, OH, OW, mul):
+    x = rnd((N, H, W, C), 34)
+    close(pa.resize_bilinear(gpu(x), (OH, OW), mul), orc.resize_bilinear(x, (OH, OW), mul), rel=1e-6, floor=1e-6)
+
+
+def test_resize_known_answer_and_golden(pa, golden_dir):
+    x = np.arange(4, dtype=np.float32).reshape(1, 1, 4, 1)
+    y = pa.resize_bilinear(gpu(x), (1, 8)).cpu().numpy().ravel()
+    np.testing.assert_array_equal(y, [0, .5, 1, 1.5, 2, 2.5, 3, 3])
+    g = np.load(os.path.join(golden_dir, "ops_small.npz"))
+    close(pa.resize_bilinear(gpu(g["rs_x"]), (12, 20)), g["rs_x2"], rel=1e-6, floor=1e-6)
+
+
+def test_copy_channels(pa):
+    from pwcnet_amd.modules import View, _copy_channels, sub_view
+    src = gpu(rnd((2, 5, 7, 33), 35))
+    dst = torch.zeros(2, 5, 7, 48, device="cuda")
+    _copy_channels(View(src.data_ptr(), 33, 2, 5, 7, 33), sub_view(View(dst.data_ptr(), 48, 2, 5, 7, 48), 3, 33), 33)
+    torch.cuda.synchronize()
+    assert torch.equal(dst[..., 3:36], src) and float(dst[..., :3].abs().max()) == 0 and float(dst[..., 36:].abs().max()) == 0
+    src4 = gpu(rnd((2, 5, 7, 32), 36))
+    _copy_channels(View(src4.data_ptr(), 32, 2, 5, 7, 32), sub_view(View(dst.data_ptr(), 48, 2, 5, 7, 48), 8, 32), 32)
+    torch.cuda.synchronize()
+    assert torch.equal(dst[..., 8:40], src4)

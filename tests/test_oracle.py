@@ -1,0 +1,207 @@
+"""CPU tests that pin the oracle (oracle/pwc_oracle.c + oracle/oracle.py).
+
+The reference ships no tests or vectors and cannot run here (TF 1.8 absent), so the
+oracle is PARITY UNPINNED against the reference itself; what pins it instead:
+  * a second, literal numpy restatement of the reference's op sequences
+    (oracle/np_literal.py), compared op by op;
+  * torch CPU ops with the semantics spelled out (asymmetric SAME pad, border-replicate
+    grid_sample in pixel units);
+  * the known-answer tests of SURVEY.md 8(c).2;
+  * the committed golden vectors (regression pin for everything downstream).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import np_literal as lit
+from oracle import oracle as orc
+from tests import util
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    return np.random.RandomState(seed).uniform(lo, hi, size=shape).astype(np.float32)
+
+
+# ------------------------------------------------------------------ conv
+@pytest.mark.parametrize("stride,dil,H,W,cin,cout", [
+    (1, 1, 9, 11, 5, 7), (2, 1, 8, 12, 3, 16), (2, 1, 7, 9, 4, 6), (1, 2, 13, 10, 6, 4),
+    (1, 16, 20, 24, 3, 2), (1, 4, 6, 5, 8, 8), (1, 1, 1, 1, 4, 4)])
+def test_conv_c_vs_literal_and_torch(stride, dil, H, W, cin, cout):
+    x = rnd((2, H, W, cin), 1)
+    k = rnd((3, 3, cin, cout), 2)
+    b = rnd((cout,), 3)
+    y = orc.conv3x3(x, k, b, stride, dil, slope=None)
+    y_lit = lit.conv3x3_same(x, k, b, stride, dil)
+    assert y.shape == y_lit.shape
+    np.testing.assert_allclose(y, y_lit, rtol=0, atol=2e-5)
+    # torch: explicit TF-SAME padding (pad_before = total//2), then VALID conv
+    _, pt, pb = lit.tf_same_pads(H, stride, dil)
+    _, pl, pr = lit.tf_same_pads(W, stride, dil)
+    xt = F.pad(torch.from_numpy(x).permute(0, 3, 1, 2), (pl, pr, pt, pb))
+    yt = F.conv2d(xt, torch.from_numpy(k).permute(3, 2, 0, 1), torch.from_numpy(b), stride=stride, dilation=dil)
+    np.testing.assert_allclose(y, yt.permute(0, 2, 3, 1).numpy(), rtol=0, atol=2e-5)
+
+
+def test_conv_stride2_even_pads_bottom_right_only():
+    # the classic trap: symmetric padding=1 is NOT what TF does for stride 2
+    x = rnd((1, 8, 8, 2), 5)
+    k = rnd((3, 3, 2, 3), 6)
+    b = np.zeros(3, np.float32)
+    y = orc.conv3x3(x, k, b, 2, 1, slope=None)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    kt = torch.from_numpy(k).permute(3, 2, 0, 1)
+    good = F.conv2d(F.pad(xt, (0, 1, 0, 1)), kt, stride=2).permute(0, 2, 3, 1).numpy()
+    bad = F.conv2d(xt, kt, stride=2, padding=1).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(y, good, atol=2e-5)
+    assert np.abs(y - bad).max() > 1e-2
+
+
+def test_conv_activation_residual_and_channel_slice():
+    x = rnd((1, 6, 7, 10), 7)
+    k = rnd((3, 3, 4, 2), 8)
+    b = rnd((2,), 9)
+    res = rnd((1, 6, 7, 2), 10)
+    base = orc.conv3x3(np.ascontiguousarray(x[..., 3:7]), k, b, slope=None)
+    sl = orc.conv3x3(x, k, b, slope=None, cin_slice=(3, 7))
+    np.testing.assert_array_equal(base, sl)
+    act = orc.conv3x3(np.ascontiguousarray(x[..., 3:7]), k, b, slope=0.1)
+    np.testing.assert_allclose(act, np.maximum(base, 0.1 * base), atol=1e-7)
+    r = orc.conv3x3(np.ascontiguousarray(x[..., 3:7]), k, b, slope=None, residual=res)
+    np.testing.assert_allclose(r, base + res, atol=1e-7)
+
+
+# ------------------------------------------------------------------ cost volume
+@pytest.mark.parametrize("H,W,C,R", [(7, 16, 8, 4), (5, 6, 3, 4), (9, 10, 4, 2), (3, 3, 2, 4)])
+def test_cost_volume_c_vs_literal(H, W, C, R):
+    f0, f1 = rnd((2, H, W, C), 11), rnd((2, H, W, C), 12)
+    cv = orc.cost_volume(f0, f1, R)
+    cv_lit = lit.cost_volume(f0, f1, R)
+    assert cv.shape == (2, H, W, (2 * R + 1) ** 2)
+    np.testing.assert_allclose(cv, cv_lit, rtol=0, atol=1e-6)
+
+
+def test_cost_volume_known_answers():
+    R, D = 4, 9
+    f0, f1 = rnd((1, 12, 14, 6), 13), rnd((1, 12, 14, 6), 14)
+    cv = orc.cost_volume(f0, f1, R)
+    # centre channel (v=h=0) is lrelu(mean_c f0*f1)
+    c = (f0 * f1).mean(axis=3)
+    np.testing.assert_allclose(cv[..., 40], np.maximum(c, 0.1 * c), atol=1e-6)
+    # constant features a, b: interior = a*b, out-of-image shifts = 0
+    a, b = 0.5, -0.25
+    cvc = orc.cost_volume(np.full((1, 12, 14, 4), a, np.float32), np.full((1, 12, 14, 4), b, np.float32), R)
+    np.testing.assert_allclose(cvc[0, 5, 6], 0.1 * a * b, atol=1e-7)      # a*b < 0 -> leaky branch
+    assert cvc[0, 0, 0, 0] == 0.0                      # v=-4,h=-4 at the top-left corner
+    assert cvc[0, 0, 0, 80] != 0.0                     # v=+4,h=+4 is inside
+    assert cvc[0, 11, 13, 80] == 0.0                   # ... and outside at bottom-right
+    # index convention: pairs f0[y,x] with f1[y+v,x+h]; channel (v+4)*9+(h+4), v outer
+    f = rnd((1, 16, 16, 32), 15)      # zero-mean: the self-match sum of squares dominates
+    v, h = 2, -3
+    shifted = np.zeros_like(f)
+    shifted[:, v:, : 16 + h] = f[:, : 16 - v, -h:]      # shifted[y+v, x+h] = f[y, x]
+    cvs = orc.cost_volume(f, shifted, R)
+    assert int(np.argmax(cvs[0, 6, 8])) == (v + R) * D + (h + R)
+
+
+# ------------------------------------------------------------------ warp
+def test_warp_c_vs_literal_and_grid_sample():
+    N, H, W, C = 2, 10, 12, 4
+    x = rnd((N, H, W, C), 16)
+    flow = util.flow_field(N, H, W, seed=17)
+    out = orc.warp(x, flow, "bilinear")
+    np.testing.assert_allclose(out, lit.bilinear_warp(x, flow), rtol=0, atol=1e-5)
+    # grid_sample(border, align_corners=True) in pixel units is the same sampling rule
+    gy, gx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    sx = (gx[None] + flow[..., 0]) / (W - 1) * 2 - 1
+    sy = (gy[None] + flow[..., 1]) / (H - 1) * 2 - 1
+    grid = torch.from_numpy(np.stack([sx, sy], axis=-1).astype(np.float32))
+    ref = F.grid_sample(torch.from_numpy(x).permute(0, 3, 1, 2), grid, mode="bilinear",
+                        padding_mode="border", align_corners=True).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5)
+
+
+def test_warp_known_answers():
+    x = rnd((1, 8, 9, 3), 18)
+    zero = np.zeros((1, 8, 9, 2), np.float32)
+    np.testing.assert_array_equal(orc.warp(x, zero, "bilinear"), x)
+    np.testing.assert_array_equal(orc.warp(x, zero, "nearest"), x)
+    # integer flow = pure shift with edge replication
+    flow = np.zeros((1, 8, 9, 2), np.float32)
+    flow[..., 0], flow[..., 1] = 2.0, -3.0
+    exp = x[:, np.clip(np.arange(8) - 3, 0, 7)][:, :, np.clip(np.arange(9) + 2, 0, 8)]
+    np.testing.assert_array_equal(orc.warp(x, flow, "bilinear"), exp)
+    np.testing.assert_array_equal(orc.warp(x, flow, "nearest"), exp)
+    # flow_scale restates `flows_up * scales[l]`
+    np.testing.assert_array_equal(orc.warp(x, flow / 5.0, "bilinear", flow_scale=5.0), exp)
+    # nearest truncates toward zero: -0.9 -> 0, 1.9 -> 1 (not rounding)
+    f2 = np.zeros((1, 8, 9, 2), np.float32)
+    f2[..., 0], f2[..., 1] = -0.9, 1.9
+    exp2 = x[:, np.clip(np.arange(8) + 1, 0, 7)]
+    np.testing.assert_array_equal(orc.warp(x, f2, "nearest"), exp2)
+    np.testing.assert_array_equal(lit.nearest_warp(x, f2), exp2)
+
+
+# ------------------------------------------------------------------ resize
+def test_resize_legacy_known_answer_and_literal():
+    x = np.arange(4, dtype=np.float32).reshape(1, 1, 4, 1)
+    y = orc.resize_bilinear(x, (1, 8))
+    np.testing.assert_array_equal(y.ravel(), [0, .5, 1, 1.5, 2, 2.5, 3, 3])
+    x = rnd((2, 5, 7, 3), 19)
+    for (oh, ow) in [(10, 14), (20, 28), (5, 7)]:
+        np.testing.assert_allclose(orc.resize_bilinear(x, (oh, ow)), lit.resize_bilinear_legacy(x, (oh, ow)),
+                                   rtol=0, atol=1e-6)
+    np.testing.assert_allclose(orc.resize_bilinear(x, (20, 28), mul=20.0),
+                               lit.resize_bilinear_legacy(x, (20, 28)) * 20.0, rtol=0, atol=1e-5)
+    # differs from both torch interpolate modes (it is neither half-pixel nor align-corners)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    for ac in (False, True):
+        t = F.interpolate(xt, size=(10, 14), mode="bilinear", align_corners=ac).permute(0, 2, 3, 1).numpy()
+        assert np.abs(t - orc.resize_bilinear(x, (10, 14))).max() > 1e-3
+
+
+# ------------------------------------------------------------------ assembly
+def test_param_count_and_shapes_match_checkpoint_layout():
+    from pwcnet_amd import weights as W
+    specs = W.conv_specs()
+    assert len(specs) == 55 and W.num_parameters(specs) == 5029868
+    assert W.num_parameters(W.conv_specs(use_dc=True)) == 40182338
+    cin_first = [c for n, c, _ in specs if n.endswith("/conv2d") and "optflow" in n]
+    assert cin_first == [273, 243, 211, 179, 147]
+    assert [c for n, c, _ in specs if n.endswith("context/conv2d")] == [34]
+
+
+def test_model_structure_small():
+    """no residual at level 0, flow heads linear, pyramid ordering / shapes."""
+    w = util.model_weights(False)
+    net = orc.OraclePWCDCNet(w)
+    im0, im1 = util.images(1, 64, 128)
+    final, pyr, feats = net(im0, im1, with_features=True)
+    assert final.shape == (1, 64, 128, 2)
+    assert [p.shape[1:3] for p in pyr] == [(1, 2), (2, 4), (4, 8), (8, 16), (16, 32)]
+    assert [f.shape[3] for f in feats] == [192, 128, 96, 64, 32, 16]
+    # flows_final = x4 legacy resize of the last pyramid flow, times 20 (model.py:125-127)
+    np.testing.assert_allclose(final, orc.resize_bilinear(pyr[-1], (64, 128), mul=20.0), atol=0)
+
+
+@pytest.mark.parametrize("use_dc", [False, True])
+def test_e2e_matches_golden(use_dc, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"e2e_64x128_dc{int(use_dc)}.npz"))
+    w = util.model_weights(use_dc)
+    net = orc.OraclePWCDCNet(w, use_dc=use_dc)
+    final, pyr = net(g["images_0"], g["images_1"])
+    np.testing.assert_allclose(final, g["flows_final"], rtol=0, atol=1e-4)
+    for l, p in enumerate(pyr):
+        np.testing.assert_allclose(p, g[f"flows_{l}"], rtol=0, atol=5e-6)
+
+
+def test_ops_match_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ops_small.npz"))
+    np.testing.assert_allclose(orc.cost_volume(g["cv_f0"], g["cv_f1"], 4), g["cv_out"], atol=1e-6)
+    np.testing.assert_allclose(orc.warp(g["warp_x"], g["warp_flow"], "bilinear"), g["warp_bilinear"], atol=1e-6)
+    np.testing.assert_array_equal(orc.warp(g["warp_x"], g["warp_flow"], "nearest"), g["warp_nearest"])
+    np.testing.assert_allclose(orc.resize_bilinear(g["rs_x"], (12, 20)), g["rs_x2"], atol=1e-6)
+    np.testing.assert_allclose(orc.conv3x3(g["conv_x"], g["conv_k"], g["conv_b"], 2, 1, 0.1), g["conv_s2"], atol=1e-5)
+    np.testing.assert_allclose(orc.conv3x3(g["conv_x"], g["conv_k"], g["conv_b"], 1, 4, 0.1), g["conv_d4"], atol=1e-5)
