@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- image-pairs/sec of the PWC-Net forward at 448x1024 on N MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py`,
+  one rank per GPU.  A step = one PWCDCNet forward over this rank's batch of synthetic
+  pairs (default 8 x 448x1024, BASELINE.json configs[1]); inputs are resident in HBM
+  before the timed region.  Pairs shard across ranks with no data-path collective
+  (weak scaling); one RCCL all-gather of per-rank stats per run.  Rank 0 prints ONE
+  JSON line.
+
+Extra objects in the line:
+  roofline      dominant kernel (by summed duration): algorithmic flops / HIP-event
+                duration measured over the timed region, vs the fp32-MFMA peak;
+  roofline_hbm  the cost-volume (+fused warp) kernel against the HBM peak;
+  kernels       per-kernel launches / ms per step;
+  cpu_baseline  the CPU oracle (oracle/, a port -- the TF reference cannot run) timed on
+                the host cores on whole 448x1024 pairs, N=1 / rank 0 only;
+  parity        max-abs / EPE of flows_final between the HIP path and the oracle on the
+                cpu_baseline pair.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 chip peak
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="pairs per GPU per step")
+    ap.add_argument("--height", type=int, default=448)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--use-dc", action="store_true", help="dense-connection estimator (configs[3])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget")
+    ap.add_argument("--no-op-timing", action="store_true", help="skip the per-launch HIP events")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    import pwcnet_amd
+    from pwcnet_amd import weights as W
+    from pwcnet_amd.profiler import OpTimer
+    from pwcnet_amd.sharding import gather_stats
+
+    # identical seeded glorot-uniform weights on every rank
+    specs = W.conv_specs(use_dc=args.use_dc)
+    wts = W.init_weights(specs, seed=0)
+    net = pwcnet_amd.PWCDCNet(use_dc=args.use_dc)
+    net.load_weights(wts)
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    B, H, Wd = args.batch, args.height, args.width
+    im0 = torch.rand((B, H, Wd, 3), generator=g, device=dev, dtype=torch.float32)
+    im1 = torch.rand((B, H, Wd, 3), generator=g, device=dev, dtype=torch.float32)
+
+    for _ in range(args.warmup):
+        net(im0, im1)
+    torch.cuda.synchronize()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    timer = None if args.no_op_timing else OpTimer()
+    sync_all()
+    t0 = time.perf_counter()
+    if timer is not None:
+        with timer:
+            for _ in range(args.steps):
+                out = net(im0, im1)
+    else:
+        for _ in range(args.steps):
+            out = net(im0, im1)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    stats = gather_stats(dict(pairs=float(B * args.steps), seconds=elapsed), dist, dev)
+    max_elapsed = max(s["seconds"] for s in stats)
+    total_pairs = sum(s["pairs"] for s in stats)
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    line = {
+        "metric": "image_pairs_per_sec_448x1024" if (H, Wd) == (448, 1024) else f"image_pairs_per_sec_{H}x{Wd}",
+        "value": total_pairs / max_elapsed,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * max_elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (uniform[0,1) images, seeded glorot-uniform weights; trained weights absent)",
+        "config": {
+            "workload": (f"batch={B} {H}x{Wd} random-init PWC-Net (PWCDCNet use_dc={args.use_dc}) forward "
+                         f"per GPU on {world}xMI355X"
+                         + (" = BASELINE.json configs[1]" if (B, H, Wd, args.use_dc) == (8, 448, 1024, False) else "")),
+            "global_batch": B * world,
+            "height": H,
+            "width": Wd,
+            "parallelism": f"dp{world}: pairs sharded across ranks, no data-path collective",
+        },
+    }
+
+    if timer is not None:
+        summ = timer.summary()
+        kernels = {}
+        for k, d in summ.items():
+            kernels[k] = {"launches_per_step": d["launches"] / args.steps,
+                          "ms_per_step": d["ms"] / args.steps,
+                          "avg_us": 1e3 * d["ms"] / d["launches"],
+                          "tflops": (d["flops"] / (d["ms"] * 1e-3) / 1e12) if d["ms"] > 0 else 0.0,
+                          "gbs": (d["bytes"] / (d["ms"] * 1e-3) / 1e9) if d["ms"] > 0 else 0.0}
+        dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        dk, dd = dom
+        ach = dd["flops"] / (dd["ms"] * 1e-3) / 1e12
+        line["roofline"] = {"kernel": dk, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                            "avg_launch_us": 1e3 * dd["ms"] / dd["launches"],
+                            "launches_per_step": dd["launches"] / args.steps}
+        conv_ms = sum(d["ms"] for k, d in summ.items() if k.startswith("conv3x3_mfma"))
+        conv_fl = sum(d["flops"] for k, d in summ.items() if k.startswith("conv3x3_mfma"))
+        if conv_ms > 0:
+            a2 = conv_fl / (conv_ms * 1e-3) / 1e12
+            line["roofline_all_mfma_convs"] = {"bound": "mfma", "achieved": a2, "peak": PEAK_F32_MFMA_TFLOPS,
+                                               "unit": "TFLOP/s", "frac": a2 / PEAK_F32_MFMA_TFLOPS,
+                                               "ms_per_step": conv_ms / args.steps}
+        cv = [(k, d) for k, d in summ.items() if k.startswith("cost_volume")]
+        if cv:
+            ms = sum(d["ms"] for _, d in cv)
+            by = sum(d["bytes"] for _, d in cv)
+            a3 = by / (ms * 1e-3) / 1e9
+            line["roofline_hbm"] = {"kernel": "+".join(k for k, _ in cv), "bound": "hbm", "achieved": a3,
+                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a3 / PEAK_HBM_GBS,
+                                    "traffic": None, "ms_per_step": ms / args.steps}
+        line["kernels"] = kernels
+        line["gpu_busy_ms_per_step"] = sum(d["ms"] for d in summ.values()) / args.steps
+
+    if world == 1 and not args.no_cpu_baseline:
+        line.update(cpu_baseline_and_parity(net, wts, args, dev))
+
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_and_parity(net, wts, args, dev):
+    """Times the CPU oracle (oracle/: C restatement, OpenMP over the host cores) on whole
+    pairs of the bench shape, and compares the HIP forward with it on the first pair."""
+    from oracle import oracle as orc
+    H, Wd = args.height, args.width
+    onet = orc.OraclePWCDCNet(wts, use_dc=args.use_dc)
+    rng = np.random.RandomState(4321)
+    n_done, t_cpu, first = 0, 0.0, None
+    while t_cpu < args.cpu_seconds and n_done < 8:
+        a = rng.uniform(0, 1, size=(1, H, Wd, 3)).astype(np.float32)
+        b = rng.uniform(0, 1, size=(1, H, Wd, 3)).astype(np.float32)
+        t0 = time.perf_counter()
+        e_final, _ = onet(a, b)
+        t_cpu += time.perf_counter() - t0
+        n_done += 1
+        if first is None:
+            first = (a, b, e_final)
+    a, b, e_final = first
+    final, _ = net(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev))
+    got = final.cpu().numpy()
+    return {
+        "cpu_baseline": {"value": n_done / t_cpu, "unit": "pairs/s", "cores": orc.num_threads(), "kind": "port",
+                         "host_cpu_count": os.cpu_count(),
+                         "sample": f"{n_done} whole {H}x{Wd} pair(s), {t_cpu:.1f} s of CPU time; oracle/ C "
+                                   "restatement (OpenMP), same weights; the TF-1.8 reference cannot run here"},
+        "parity": {"max_abs_flows_final": float(np.abs(got - e_final).max()),
+                   "epe": orc.epe(e_final, got), "tolerance": 1e-3,
+                   "max_abs_flow_value": float(np.abs(e_final).max())},
+    }
+
+
+if __name__ == "__main__":
+    main()

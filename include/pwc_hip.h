@@ -103,6 +103,10 @@ int pwc_conv3x3_f32(const float* x, int x_cs, const float* packed, const float* 
                     int stride, int dilation, int apply_act, float slope, int tile,
                     pwc_stream_t stream);
 
+/* Introspection: the tile configuration pwc_conv3x3_f32(tile = -1) picks for M output
+ * pixels; returns the tile id (>= 0) and its workgroup tile BM x BN and k-chunk KC. */
+int pwc_conv3x3_select_tile(int M, int Cout, int Cin_phys, int* bm, int* bn, int* kc);
+
 /* Same convolution straight from the HWIO variable, any Cin/Cout, plus the optional
  * residual add of modules.py:275-277 (`flows += flows_up_prev`) and modules.py:326
  * (`flows + x`): y = act(conv) + residual.  Used for Cin = 3 (first extractor layer),

@@ -287,6 +287,15 @@ static int pick_tile(int M, int Cout_pad) {
     return by_bn[row][2];
 }
 
+extern "C" int pwc_conv3x3_select_tile(int M, int Cout, int Cin_phys, int* bm, int* bn, int* kc) {
+    if (M <= 0 || Cout <= 0 || Cin_phys <= 0) return PWC_EINVAL;
+    const int tile = pick_tile(M, (Cout + 15) & ~15);
+    if (bm) *bm = g_tiles[tile].BM;
+    if (bn) *bn = g_tiles[tile].BN;
+    if (kc) *kc = (Cin_phys % 32 == 0) ? 32 : 16;
+    return tile;
+}
+
 extern "C" size_t pwc_conv3x3_packed_floats(int Cin_phys, int Cout) {
     if (Cin_phys <= 0 || Cout <= 0) return 0;
     const int Cout_pad = (Cout + 15) & ~15;

@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .profiler import timed
 from .weights import FILTERS_FP, FILTERS_OF, CONTEXT, ChannelLayout
 
 View = collections.namedtuple("View", "ptr cs N H W C")
@@ -204,9 +205,13 @@ class _ConvRunner:
                                                   cin, x.C, cout, _p(packed.data_ptr()), s), "conv3x3 pack")
                 cache[key] = packed
                 cache[key + ("cm",)] = cm
-            _lib.check(L.pwc_conv3x3_f32(_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()),
-                                         _p(y.ptr), y.cs, x.N, x.H, x.W, x.C, cout, stride, dilation,
-                                         act, sl, tile, s), f"conv3x3 {name}")
+            flops = 2.0 * x.N * Ho * Wo * 9 * cin * cout     # algorithmic: logical Cin, no padding
+            with timed(_mfma_kernel_name(L, x.N * Ho * Wo, cout, x.C, tile), flops,
+                       4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout)):
+                rc = L.pwc_conv3x3_f32(_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()),
+                                       _p(y.ptr), y.cs, x.N, x.H, x.W, x.C, cout, stride, dilation,
+                                       act, sl, tile, s)
+            _lib.check(rc, f"conv3x3 {name}")
         else:
             w = kern.value
             if cin_map is not None:
@@ -222,10 +227,21 @@ class _ConvRunner:
             elif x.C != cin:
                 raise ValueError(f"{name}: input has {x.C} channels, kernel expects {cin}")
             r_ptr, r_cs = (None, 0) if residual is None else (_p(residual.ptr), residual.cs)
-            _lib.check(L.pwc_conv3x3_direct_f32(_p(x.ptr), x.cs, _p(w.data_ptr()), _p(bias.value.data_ptr()),
-                                                _p(y.ptr), y.cs, r_ptr, r_cs, x.N, x.H, x.W, x.C, cout,
-                                                stride, dilation, act, sl, s), f"conv3x3_direct {name}")
+            with timed(f"conv3x3_direct_kernel<cout={cout}>", 2.0 * x.N * Ho * Wo * 9 * cin * cout,
+                       4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout)):
+                rc = L.pwc_conv3x3_direct_f32(_p(x.ptr), x.cs, _p(w.data_ptr()), _p(bias.value.data_ptr()),
+                                              _p(y.ptr), y.cs, r_ptr, r_cs, x.N, x.H, x.W, x.C, cout,
+                                              stride, dilation, act, sl, s)
+            _lib.check(rc, f"conv3x3_direct {name}")
         return y, y_t
+
+
+def _mfma_kernel_name(L, M, cout, cin_phys, tile):
+    if tile >= 0:
+        return f"conv3x3_mfma_kernel<tile{tile}>"
+    bm, bn, kc = _lib.ctypes.c_int(), _lib.ctypes.c_int(), _lib.ctypes.c_int()
+    L.pwc_conv3x3_select_tile(M, cout, cin_phys, bm, bn, kc)
+    return f"conv3x3_mfma_kernel<{bm.value}x{bn.value},KC{kc.value}>"
 
 
 class _Module:
@@ -237,15 +253,19 @@ class _Module:
 def _copy_channels(src, dst, C):
     """dst[..., 0:C] = src[..., 0:C] (both Views over the same pixel grid)."""
     assert (src.N, src.H, src.W) == (dst.N, dst.H, dst.W)
-    _lib.check(_lib.lib().pwc_copy_channels_f32(_p(src.ptr), src.cs, _p(dst.ptr), dst.cs,
-                                                src.N * src.H * src.W, C, _lib.current_stream()),
-               "copy_channels")
+    npix = src.N * src.H * src.W
+    with timed("copy_channels_kernel", 0.0, 8.0 * npix * C):
+        rc = _lib.lib().pwc_copy_channels_f32(_p(src.ptr), src.cs, _p(dst.ptr), dst.cs, npix, C,
+                                              _lib.current_stream())
+    _lib.check(rc, "copy_channels")
 
 
 def _resize(src, dst, mul=1.0):
-    _lib.check(_lib.lib().pwc_resize_bilinear_f32(_p(src.ptr), src.cs, _p(dst.ptr), dst.cs, src.N, src.H,
-                                                  src.W, src.C, dst.H, dst.W, float(mul),
-                                                  _lib.current_stream()), "resize_bilinear")
+    with timed("resize_kernel", 0.0, 4.0 * src.C * src.N * (src.H * src.W + dst.H * dst.W)):
+        rc = _lib.lib().pwc_resize_bilinear_f32(_p(src.ptr), src.cs, _p(dst.ptr), dst.cs, src.N, src.H,
+                                                src.W, src.C, dst.H, dst.W, float(mul),
+                                                _lib.current_stream())
+    _lib.check(rc, "resize_bilinear")
 
 
 def resize_bilinear(x, size, mul=1.0):
@@ -316,8 +336,10 @@ class WarpingLayer(_Module):
         assert self.warp in ["nearest", "bilinear"]
         L = _lib.lib()
         fn = L.pwc_warp_bilinear_f32 if self.warp == "bilinear" else L.pwc_warp_nearest_f32
-        _lib.check(fn(_p(x.ptr), x.cs, _p(flow.ptr), flow.cs, float(flow_scale), _p(out.ptr), out.cs,
-                      x.N, x.H, x.W, x.C, _lib.current_stream()), f"warp_{self.warp}")
+        with timed(f"warp_kernel<{self.warp}>", 0.0, 4.0 * x.N * x.H * x.W * (2 * x.C + 2)):
+            rc = fn(_p(x.ptr), x.cs, _p(flow.ptr), flow.cs, float(flow_scale), _p(out.ptr), out.cs,
+                    x.N, x.H, x.W, x.C, _lib.current_stream())
+        _lib.check(rc, f"warp_{self.warp}")
 
     def __call__(self, x, flow):
         assert self.warp in ["nearest", "bilinear"]
@@ -343,13 +365,19 @@ class CostVolumeLayer(_Module):
         """flow given: f1 is the UN-warped map and the bilinear warp is fused in."""
         L = _lib.lib()
         s = _lib.current_stream()
+        D = (2 * self.s_range + 1) ** 2
+        npix = f0.N * f0.H * f0.W
+        flops = 2.0 * npix * D * f0.C
         if flow is None:
-            rc = L.pwc_cost_volume_f32(_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(out.ptr), out.cs,
-                                       f0.N, f0.H, f0.W, f0.C, self.s_range, 0.1, s)
+            with timed(f"cost_volume_kernel<R{self.s_range}>", flops, 4.0 * npix * (2 * f0.C + D)):
+                rc = L.pwc_cost_volume_f32(_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(out.ptr), out.cs,
+                                           f0.N, f0.H, f0.W, f0.C, self.s_range, 0.1, s)
         else:
-            rc = L.pwc_warp_cost_volume_f32(_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(flow.ptr), flow.cs,
-                                            float(flow_scale), _p(out.ptr), out.cs, f0.N, f0.H, f0.W, f0.C,
-                                            self.s_range, 0.1, s)
+            with timed(f"cost_volume_kernel<R{self.s_range},fused_warp>", flops,
+                       4.0 * npix * (2 * f0.C + 2 + D)):
+                rc = L.pwc_warp_cost_volume_f32(_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(flow.ptr), flow.cs,
+                                                float(flow_scale), _p(out.ptr), out.cs, f0.N, f0.H, f0.W,
+                                                f0.C, self.s_range, 0.1, s)
         _lib.check(rc, "cost_volume")
 
     def __call__(self, features_0, features_0from1):

@@ -1,0 +1,67 @@
+"""Per-launch HIP-event timing of the ops (used by bench.py for the roofline figures).
+
+When a timer is installed (``with OpTimer() as t:``) every kernel launch issued by
+pwcnet_amd.modules is bracketed by two events recorded on torch's current stream -- the
+stream the launch itself goes to -- and tagged with its kernel name and its ALGORITHMIC
+work (flops and bytes as DESIGN.md defines them).  No synchronisation happens until
+``summary()``.
+"""
+import collections
+import contextlib
+
+import torch
+
+_ACTIVE = None
+
+
+def active():
+    return _ACTIVE
+
+
+class OpTimer:
+    def __init__(self):
+        self.records = []   # (kernel, flops, bytes, start event, end event)
+
+    def __enter__(self):
+        global _ACTIVE
+        self._prev = _ACTIVE
+        _ACTIVE = self
+        return self
+
+    def __exit__(self, *exc):
+        global _ACTIVE
+        _ACTIVE = self._prev
+        return False
+
+    @contextlib.contextmanager
+    def launch(self, kernel, flops=0.0, nbytes=0.0):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        try:
+            yield
+        finally:
+            e.record()
+            self.records.append((kernel, float(flops), float(nbytes), s, e))
+
+    def summary(self):
+        """{kernel: dict(launches, ms, flops, bytes)} -- synchronises the device."""
+        torch.cuda.synchronize()
+        out = collections.OrderedDict()
+        for k, fl, by, s, e in self.records:
+            d = out.setdefault(k, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += fl
+            d["bytes"] += by
+        return out
+
+
+@contextlib.contextmanager
+def timed(kernel, flops=0.0, nbytes=0.0):
+    t = _ACTIVE
+    if t is None:
+        yield
+    else:
+        with t.launch(kernel, flops, nbytes):
+            yield

@@ -30,7 +30,7 @@ def rnd(shape, seed, lo=-1.0, hi=1.0):
 
 
 def gpu(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
 
 
 def close(got, exp, rel=1e-5, floor=1e-6):

@@ -33,7 +33,7 @@ def rnd(shape, seed, lo=-1.0, hi=1.0):
 
 
 def gpu(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
 
 
 def _p(t):
@@ -82,7 +82,7 @@ def run_conv_mfma(x, k, b, stride, dil, slope, tile=-1, cin_map=None, cin_phys=N
     cin_phys = cs if cin_phys is None else cin_phys
     xg, kg, bg = gpu(x), gpu(k), gpu(b)
     packed = torch.empty(L.pwc_conv3x3_packed_floats(cin_phys, cout), device="cuda")
-    cm = None if cin_map is None else gpu(np.asarray(cin_map, np.int32))
+    cm = None if cin_map is None else torch.from_numpy(np.asarray(cin_map, np.int32)).cuda()
     _lib.check(L.pwc_conv3x3_pack_f32(_p(kg), _p(cm) if cm is not None else None, cin, cin_phys, cout,
                                       _p(packed), None))
     Ho, Wo = -(-H // stride), -(-W // stride)
@@ -103,7 +103,7 @@ def run_conv_mfma(x, k, b, stride, dil, slope, tile=-1, cin_map=None, cin_phys=N
     (2, 56, 128, 160, 128, 1, 1)])
 def test_conv_mfma_vs_oracle(pa, N, H, W, cin, cout, stride, dil):
     x = rnd((N, H, W, cin), 1)
-    k = rnd((3, 3, cin, cout), 2) * (1.0 / np.sqrt(9 * cin))
+    k = rnd((3, 3, cin, cout), 2) * float(1.0 / np.sqrt(9 * cin))
     b = rnd((cout,), 3) * 0.1
     y = run_conv_mfma(x, k, b, stride, dil, 0.1)
     close(y, orc.conv3x3(x, k, b, stride, dil, 0.1))
@@ -115,7 +115,7 @@ def test_conv_mfma_every_tile_config(pa, tile):
     cout = {128: 128, 96: 192, 64: 64, 32: 32, 16: 48}[bn]
     for cin in (16, 64):            # KC = 16 and KC = 32 instantiations
         x = rnd((2, 19, 37, cin), 4 + tile)
-        k = rnd((3, 3, cin, cout), 5) * (1.0 / np.sqrt(9 * cin))
+        k = rnd((3, 3, cin, cout), 5) * float(1.0 / np.sqrt(9 * cin))
         b = rnd((cout,), 6) * 0.1
         y = run_conv_mfma(x, k, b, 1, 1, 0.1, tile=tile)
         close(y, orc.conv3x3(x, k, b, 1, 1, 0.1))
@@ -183,7 +183,7 @@ def run_conv_direct(x, k, b, stride, dil, slope, residual=None):
     (1, 9, 11, 5, 7, 1, 2, 0.1), (1, 12, 12, 8, 13, 2, 1, None), (1, 10, 14, 36, 4, 1, 1, 0.1)])
 def test_conv_direct_vs_oracle(pa, N, H, W, cin, cout, stride, dil, slope):
     x = rnd((N, H, W, cin), 14)
-    k = rnd((3, 3, cin, cout), 15) * (1.0 / np.sqrt(9 * cin))
+    k = rnd((3, 3, cin, cout), 15) * float(1.0 / np.sqrt(9 * cin))
     b = rnd((cout,), 16) * 0.1
     close(run_conv_direct(x, k, b, stride, dil, slope), orc.conv3x3(x, k, b, stride, dil, slope))
 
