@@ -1,0 +1,187 @@
+"""CPU tests of the host logic: C-ABI surface, variable inventory, channel layouts,
+checkpoint bundle reader/writer, pair sharding (incl. a world-size-2 gloo run)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from pwcnet_amd import _lib, ckpt, sharding
+from pwcnet_amd import weights as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    """Every function include/pwc_hip.h declares is exported by the built .so and bound
+    in _lib.SIGNATURES (no compute call is made: there is no GPU here)."""
+    header = open(os.path.join(ROOT, "include", "pwc_hip.h")).read()
+    declared = set(re.findall(r"\b(pwc_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name)
+    assert L.pwc_version() >= 100
+    assert L.pwc_error_string(-1).decode().startswith("invalid argument")
+    # pure host-side helpers are callable without a GPU
+    assert L.pwc_conv3x3_packed_floats(160, 128) == 9 * 160 * 128
+    bm, bn, kc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert L.pwc_conv3x3_select_tile(8 * 112 * 256, 128, 160, bm, bn, kc) >= 0
+    assert (bm.value, bn.value, kc.value) == (128, 128, 32)
+    # argument validation happens before any launch
+    assert L.pwc_cost_volume_f32(None, 4, None, 4, None, 81, 1, 4, 4, 4, 4, 0.1, None) == -1
+    assert L.pwc_conv3x3_f32(None, 16, None, None, None, 16, 1, 4, 4, 16, 16, 1, 1, 1, 0.1, -1, None) == -1
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pwcnet_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("SURVEY", ""), f"{f} mentions the oracle"
+
+
+def test_cpu_tensors_are_rejected_not_computed_elsewhere():
+    import torch
+    import pwcnet_amd
+    with pytest.raises(_lib.PwcHipError):
+        pwcnet_amd.WarpingLayer("bilinear")(torch.zeros(1, 4, 4, 4), torch.zeros(1, 4, 4, 2))
+
+
+# ------------------------------------------------------------------ inventory / layouts
+def test_conv_specs_match_checkpoint_index(golden_dir):
+    _, entries = ckpt.read_index(os.path.join(golden_dir, "model_600.ckpt.index"))
+    assert len(entries) == 333
+    mv = ckpt.model_variables(entries)
+    specs = W.conv_specs()
+    assert len(mv) == 2 * len(specs) == 110
+    for name, cin, cout in specs:
+        assert mv[name + "/kernel"].shape == (3, 3, cin, cout) and mv[name + "/kernel"].dtype == ckpt.DT_FLOAT
+        assert mv[name + "/bias"].shape == (cout,)
+    assert sum(int(np.prod(e.shape)) for e in mv.values()) == W.num_parameters(specs) == 5029868
+    assert max(e.offset + e.size for e in entries.values()) == 60358428
+    assert entries["Variable"].dtype == ckpt.DT_INT32 and entries["Variable"].shape == ()
+    assert "pwcdcnet/optflow_5/conv2d/kernel" not in entries
+
+
+def test_estimator_channel_counts():
+    assert [W.estimator_in_channels(l, False) for l in range(5)] == [273, 243, 211, 179, 147]
+    assert [W.estimator_in_channels(l, True) for l in range(5)] == [273, 932, 1559, 2154, 2717]
+    assert [W.estimator_feature_channels(l, True) for l in range(5)] == [721, 1380, 2007, 2602, 3165]
+    assert W.num_parameters(W.conv_specs(use_dc=True)) == 40182338
+
+
+@pytest.mark.parametrize("use_dc", [False, True])
+def test_layouts_are_aligned_bijective_and_zero_padded(use_dc):
+    for l in range(5):
+        lay = W.estimator_layout(l, use_dc)
+        p2l = np.asarray(lay.phys2log)
+        assert lay.n_phys % 16 == 0 and lay.n_logical == W.estimator_feature_channels(l, use_dc) if use_dc \
+            else lay.n_logical == W.estimator_in_channels(l, use_dc)
+        assert sorted(p2l[p2l >= 0].tolist()) == list(range(lay.n_logical))      # bijection onto logical
+        for name, (off, ln) in lay.segments.items():
+            assert off % 4 == 0
+        if use_dc:
+            # conv k reads the suffix that starts where conv k-1 wrote / where cv starts
+            starts = [lay.offset("cv")] + [lay.offset(f"conv{k}") for k in range(5)]
+            assert all(s % 16 == 0 for s in starts)
+            done = 0
+            for k in range(5):
+                m = lay.cin_map(starts[k], logical_base=448 - done)
+                cin = lay.n_logical - (448 - done)
+                assert sorted(m[m >= 0].tolist()) == list(range(cin))
+                done += W.FILTERS_OF[k]
+    cx = W.context_layout(use_dc)
+    assert cx.n_logical == (3167 if use_dc else 34) and cx.offset("features") == 4
+
+
+def test_layout_reorders_like_tf_concat():
+    lay = W.estimator_layout(2, False)                      # [cv81 | f0 96 | flow 2 | feat_up 32]
+    p2l = np.asarray(lay.phys2log)
+    assert list(p2l[:81]) == list(range(81)) and list(p2l[81:84]) == [-1] * 3
+    off = lay.offset("f0")
+    assert off == 84 and list(p2l[off:off + 96]) == list(range(81, 177))
+    assert list(p2l[lay.offset("flow"):lay.offset("flow") + 4]) == [177, 178, -1, -1]
+    assert list(p2l[lay.offset("feat_up"):lay.offset("feat_up") + 32]) == list(range(179, 211))
+
+
+def test_glorot_init_is_seeded_and_bounded():
+    specs = W.conv_specs()
+    a, b = W.init_weights(specs, seed=0), W.init_weights(specs, seed=0)
+    k = "pwcdcnet/optflow_4/conv2d/kernel"
+    assert np.array_equal(a[k], b[k]) and a[k].shape == (3, 3, 147, 128)
+    assert np.abs(a[k]).max() <= np.sqrt(6.0 / (9 * 147 + 9 * 128)) and not np.any(a["pwcdcnet/context/conv2d/bias"])
+    assert not np.array_equal(a[k], W.init_weights(specs, seed=1)[k])
+
+
+# ------------------------------------------------------------------ checkpoint bundle
+def test_bundle_round_trip_and_crc(tmp_path):
+    specs = W.conv_specs()[:4] + W.conv_specs()[-2:]
+    w = W.randomize_biases(W.init_weights(specs, seed=3))
+    prefix = str(tmp_path / "model_1.ckpt")
+    ckpt.save_weights(prefix, w)
+    back = ckpt.load_weights(prefix)
+    assert set(back) == set(w)
+    for k in w:
+        np.testing.assert_array_equal(back[k], w[k])
+    # corrupt one byte of the data file -> CRC failure
+    with open(prefix + ".data-00000-of-00001", "r+b") as f:
+        f.seek(100); b = f.read(1); f.seek(100); f.write(bytes([b[0] ^ 0xFF]))
+    with pytest.raises(ValueError, match="CRC32C"):
+        ckpt.load_weights(prefix)
+    # corrupt the index -> block CRC failure
+    raw = bytearray(open(prefix + ".index", "rb").read()); raw[10] ^= 0xFF
+    open(prefix + ".index", "wb").write(bytes(raw))
+    with pytest.raises(ValueError):
+        ckpt.read_index(prefix + ".index")
+
+
+def test_reference_index_without_data_blob_reports_missing(golden_dir):
+    with pytest.raises(FileNotFoundError, match="data-00000-of-00001"):
+        ckpt.load_weights(os.path.join(golden_dir, "model_600.ckpt"))
+    assert ckpt.crc32c(b"123456789") == 0xE3069283          # CRC-32C check value
+
+
+# ------------------------------------------------------------------ sharding
+def test_shard_range_partitions():
+    for n, world in [(64, 8), (8, 8), (10, 4), (3, 8), (0, 2)]:
+        parts = [sharding.shard_range(n, world, r) for r in range(world)]
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in parts]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_range(8, 2, 2)
+    assert sharding.gather_stats({"pairs": 8.0, "seconds": 1.5}) == [{"pairs": 8.0, "seconds": 1.5}]
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from pwcnet_amd import sharding
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+lo, hi = sharding.shard_range(10, w, r)
+stats = sharding.gather_stats({"pairs": float(hi - lo), "seconds": 1.0 + r, "lo": float(lo)}, dist, "cpu")
+assert len(stats) == w and [s["seconds"] for s in stats] == [1.0 + i for i in range(w)]
+assert sum(s["pairs"] for s in stats) == 10 and stats[r]["lo"] == lo
+if r == 0:
+    print("GATHER_OK", max(s["seconds"] for s in stats), sum(s["pairs"] for s in stats))
+dist.destroy_process_group()
+"""
+
+
+def test_gather_stats_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29617", str(script), ROOT],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "GATHER_OK 2.0 10.0" in out.stdout
