@@ -93,7 +93,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    timer = None if args.no_op_timing else OpTimer()
+    # Untimed profile pass: every launch bracketed by HIP events -> per-kernel table and the
+    # dominant kernel.  (An event pair per launch costs ~19 % of the step on MI355X, so the
+    # timed region below instruments only the dominant kernel and the correlation/warp
+    # kernels -- a handful of launches per step.)
+    full = None
+    dominant = None
+    if not args.no_op_timing:
+        full = OpTimer()
+        with full:
+            for _ in range(min(args.steps, 5)):
+                net(im0, im1)
+        full_summary = full.summary()
+        full_steps = min(args.steps, 5)
+        dominant = max(full_summary.items(), key=lambda kv: kv[1]["ms"])[0]
+
+    timer = None if args.no_op_timing else OpTimer(only=(dominant, "cost_volume", "warp_kernel"))
     sync_all()
     t0 = time.perf_counter()
     if timer is not None:
@@ -139,38 +154,46 @@ def main():
     }
 
     if timer is not None:
-        summ = timer.summary()
+        summ = timer.summary()          # events recorded INSIDE the timed region
+        dd = summ[dominant]
+        ach = dd["flops"] / (dd["ms"] * 1e-3) / 1e12
+        line["roofline"] = {"kernel": dominant, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                            "avg_launch_us": 1e3 * dd["ms"] / dd["launches"],
+                            "launches_per_step": dd["launches"] / args.steps,
+                            "flops_per_launch": dd["flops"] / dd["launches"],
+                            "measured": "HIP events around each launch of this kernel, inside the timed region"}
+        hb = [(k, d) for k, d in summ.items() if k.startswith(("cost_volume", "warp_kernel"))]
+        if hb:
+            ms = sum(d["ms"] for _, d in hb)
+            by = sum(d["bytes"] for _, d in hb)
+            a3 = by / (ms * 1e-3) / 1e9
+            line["roofline_hbm"] = {"kernel": "+".join(k for k, _ in hb), "bound": "hbm", "achieved": a3,
+                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a3 / PEAK_HBM_GBS,
+                                    "traffic": None, "ms_per_step": ms / args.steps,
+                                    "per_kernel": {k: {"avg_us": 1e3 * d["ms"] / d["launches"],
+                                                       "gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9}
+                                                   for k, d in hb},
+                                    "measured": "HIP events inside the timed region; bytes = N*h*w*(2C+81)*4 "
+                                                "(cost volume) and N*h*w*(2C+2)*4 (warp), all 5 pyramid levels"}
+        # per-kernel table from the untimed, fully instrumented profile pass
         kernels = {}
-        for k, d in summ.items():
-            kernels[k] = {"launches_per_step": d["launches"] / args.steps,
-                          "ms_per_step": d["ms"] / args.steps,
+        for k, d in full_summary.items():
+            kernels[k] = {"launches_per_step": d["launches"] / full_steps,
+                          "ms_per_step": d["ms"] / full_steps,
                           "avg_us": 1e3 * d["ms"] / d["launches"],
                           "tflops": (d["flops"] / (d["ms"] * 1e-3) / 1e12) if d["ms"] > 0 else 0.0,
                           "gbs": (d["bytes"] / (d["ms"] * 1e-3) / 1e9) if d["ms"] > 0 else 0.0}
-        dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
-        dk, dd = dom
-        ach = dd["flops"] / (dd["ms"] * 1e-3) / 1e12
-        line["roofline"] = {"kernel": dk, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                            "avg_launch_us": 1e3 * dd["ms"] / dd["launches"],
-                            "launches_per_step": dd["launches"] / args.steps}
-        conv_ms = sum(d["ms"] for k, d in summ.items() if k.startswith("conv3x3_mfma"))
-        conv_fl = sum(d["flops"] for k, d in summ.items() if k.startswith("conv3x3_mfma"))
+        conv_ms = sum(d["ms"] for k, d in full_summary.items() if k.startswith("conv3x3_mfma"))
+        conv_fl = sum(d["flops"] for k, d in full_summary.items() if k.startswith("conv3x3_mfma"))
         if conv_ms > 0:
             a2 = conv_fl / (conv_ms * 1e-3) / 1e12
             line["roofline_all_mfma_convs"] = {"bound": "mfma", "achieved": a2, "peak": PEAK_F32_MFMA_TFLOPS,
                                                "unit": "TFLOP/s", "frac": a2 / PEAK_F32_MFMA_TFLOPS,
-                                               "ms_per_step": conv_ms / args.steps}
-        cv = [(k, d) for k, d in summ.items() if k.startswith("cost_volume")]
-        if cv:
-            ms = sum(d["ms"] for _, d in cv)
-            by = sum(d["bytes"] for _, d in cv)
-            a3 = by / (ms * 1e-3) / 1e9
-            line["roofline_hbm"] = {"kernel": "+".join(k for k, _ in cv), "bound": "hbm", "achieved": a3,
-                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a3 / PEAK_HBM_GBS,
-                                    "traffic": None, "ms_per_step": ms / args.steps}
+                                               "ms_per_step": conv_ms / full_steps,
+                                               "measured": "untimed profile pass (every launch instrumented)"}
         line["kernels"] = kernels
-        line["gpu_busy_ms_per_step"] = sum(d["ms"] for d in summ.values()) / args.steps
+        line["gpu_busy_ms_per_step_profile_pass"] = sum(d["ms"] for d in full_summary.values()) / full_steps
 
     if world == 1 and not args.no_cpu_baseline:
         line.update(cpu_baseline_and_parity(net, wts, args, dev))

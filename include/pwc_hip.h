@@ -95,17 +95,27 @@ int pwc_conv3x3_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin, i
  * with TF 'SAME' padding (pad_total = max((out-1)*s + 2d+1 - in, 0), pad_before =
  * pad_total/2: stride 2 on an even size pads bottom/right only).  apply_act=0 gives
  * the activation-less flow heads.  Output is (N,ceil(H/s),ceil(W/s),Cout) at channel
- * stride y_cs.  `tile` selects a tile configuration (-1 = automatic).
+ * stride y_cs.
+ * Launch plan: `tile` = -1 lets the library choose (large M: big tiles for the full
+ * rounds of workgroups + a smaller-tile tail launch; small M: the 9 taps are split over
+ * 3 or 9 workgroup groups whose partial sums go through `workspace` and are summed in a
+ * fixed order by a reduce kernel -- deterministic).  tile >= 0 forces one tile
+ * configuration; `split` = 0 (library decides), 1 (never), 3 or 9.  `workspace` is
+ * caller-owned scratch of `workspace_floats` floats (pwc_conv3x3_workspace_floats gives
+ * the worst case); NULL disables the tap split.
  * Needs Cout % 16 == 0, x 16-byte aligned, x_cs % 4 == 0, x_cs >= Cin_phys, and every
  * padding channel of x finite (they meet zero weights). */
 int pwc_conv3x3_f32(const float* x, int x_cs, const float* packed, const float* bias,
                     float* y, int y_cs, int N, int H, int W, int Cin_phys, int Cout,
-                    int stride, int dilation, int apply_act, float slope, int tile,
-                    pwc_stream_t stream);
+                    int stride, int dilation, int apply_act, float slope, int tile, int split,
+                    float* workspace, size_t workspace_floats, pwc_stream_t stream);
+size_t pwc_conv3x3_workspace_floats(int M, int Cout);
 
-/* Introspection: the tile configuration pwc_conv3x3_f32(tile = -1) picks for M output
- * pixels; returns the tile id (>= 0) and its workgroup tile BM x BN and k-chunk KC. */
-int pwc_conv3x3_select_tile(int M, int Cout, int Cin_phys, int* bm, int* bn, int* kc);
+/* Introspection: the plan pwc_conv3x3_f32(tile = -1) uses for M output pixels:
+ * plan4 = {main tile id, tail tile id or -1, pixels covered by the main launch, tap split};
+ * pwc_conv3x3_tile_shape gives a tile id's workgroup tile BM x BN. */
+int pwc_conv3x3_plan(int M, int Cout, int Cin_phys, int* plan4);
+int pwc_conv3x3_tile_shape(int tile, int* bm, int* bn);
 
 /* Same convolution straight from the HWIO variable, any Cin/Cout, plus the optional
  * residual add of modules.py:275-277 (`flows += flows_up_prev`) and modules.py:326

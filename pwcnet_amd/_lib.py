@@ -29,8 +29,10 @@ SIGNATURES = {
     "pwc_warp_cost_volume_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_conv3x3_packed_floats": (_sz, [_i, _i]),
     "pwc_conv3x3_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
-    "pwc_conv3x3_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
-    "pwc_conv3x3_select_tile": (_i, [_i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "pwc_conv3x3_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
+    "pwc_conv3x3_workspace_floats": (_sz, [_i, _i]),
+    "pwc_conv3x3_plan": (_i, [_i, _i, _i, ctypes.POINTER(_i)]),
+    "pwc_conv3x3_tile_shape": (_i, [_i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "pwc_conv3x3_direct_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_resize_bilinear_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_copy_channels_f32": (_i, [_vp, _i, _vp, _i, _l, _i, _vp]),
@@ -51,7 +53,9 @@ def build_library(force=False, verbose=False):
         if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -fno-slp-vectorize: hipcc otherwise packs the scalar fp32 FMA chains of the
+    # correlation kernel into v_pk_fma_f32 pairs (hundreds of v_mov shuffles, VGPR spills)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
            "-Wno-pass-failed", *srcs, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))

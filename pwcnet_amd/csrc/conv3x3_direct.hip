@@ -78,6 +78,116 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const DirectArgs a)
     }
 }
 
+// ---------------------------------------------------------------- Cin = 3 (first layer)
+// modules.py:62, l = 0: 3 -> 16 channels, stride 2, on the full-resolution images: the
+// HBM-bound head of the extractor (reads 12 B, writes 64 B per output pixel).  Lane =
+// (output pixel, 4-channel quad): consecutive lanes store consecutive 16 bytes, so the
+// NHWC output is written in whole contiguous lines; the 27 x Cout weights sit in LDS.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_smallcin_kernel(const DirectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wlds[];   // [27*CIN/3... = 9*CIN][Cout]
+    const int nw = 9 * CIN * a.Cout;
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) wlds[i] = a.w[i];
+    __syncthreads();
+    const int qpp = a.Cout >> 2;
+    const long total = a.M * qpp;
+    const long HoWo = (long)a.Ho * a.Wo;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
+         gid += (long)gridDim.x * blockDim.x) {
+        const int cq = (int)(gid % qpp);
+        const long m = gid / qpp;
+        const int n = (int)(m / HoWo);
+        const int rem = (int)(m - (long)n * HoWo);
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(a.bias + cq * 4);
+        const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+            const int iy = oy * a.stride - a.pad_t + ty * a.dil;
+            const bool yok = (unsigned)iy < (unsigned)a.H;
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const int ix = ox * a.stride - a.pad_l + tx * a.dil;
+                const bool ok = yok && ((unsigned)ix < (unsigned)a.W);
+                const float* xp = xn + ((size_t)(ok ? iy : 0) * a.W + (ok ? ix : 0)) * a.x_cs;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const float xv = ok ? xp[ci] : 0.f;
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wlds + ((ty * 3 + tx) * CIN + ci) * a.Cout + cq * 4);
+                    acc += xv * w4;
+                }
+            }
+        }
+        if (a.apply_act) {
+            acc[0] = pwc_lrelu(acc[0], a.slope); acc[1] = pwc_lrelu(acc[1], a.slope);
+            acc[2] = pwc_lrelu(acc[2], a.slope); acc[3] = pwc_lrelu(acc[3], a.slope);
+        }
+        *reinterpret_cast<f32x4*>(a.y + (size_t)m * a.y_cs + cq * 4) = acc;
+    }
+}
+
+// ---------------------------------------------------------------- Cout = 2 flow heads
+// modules.py:274 / :324 (+ residual adds :275-277, :326) with Cin = 32: 8 lanes share one
+// output pixel, lane q holds input channels 4q..4q+3 (one coalesced 128-byte read per
+// pixel tap) and its 9 x 4 x 2 weights in VGPRs; the 8 partial sums are combined with
+// wave shuffles; persistent grid-stride loop over pixel groups.
+__global__ __launch_bounds__(256) void conv3x3_head2_c32_kernel(const DirectArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int q = lane & 7;
+    float w0[9][4], w1[9][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* wp = a.w + ((size_t)tap * 32 + q * 4 + e) * 2;
+            w0[tap][e] = wp[0];
+            w1[tap][e] = wp[1];
+        }
+    const float b0 = a.bias[0], b1 = a.bias[1];
+    const long HoWo = (long)a.Ho * a.Wo;
+    const long ngroups = (a.M + 7) / 8;                 // 8 pixels per wave iteration
+    const long wave_id = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long g = wave_id; g < ngroups; g += nwaves) {
+        const long m = g * 8 + (lane >> 3);
+        const bool mok = m < a.M;
+        const long mm = mok ? m : 0;
+        const int n = (int)(mm / HoWo);
+        const int rem = (int)(mm - (long)n * HoWo);
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs + q * 4;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+            const int iy = oy * a.stride - a.pad_t + ty * a.dil;
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const int ix = ox * a.stride - a.pad_l + tx * a.dil;
+                const bool ok = mok && ((unsigned)iy < (unsigned)a.H) && ((unsigned)ix < (unsigned)a.W);
+                f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+                if (ok) xv = *reinterpret_cast<const f32x4*>(xn + ((size_t)iy * a.W + ix) * a.x_cs);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s0 = fmaf(xv[e], w0[ty * 3 + tx][e], s0);
+                    s1 = fmaf(xv[e], w1[ty * 3 + tx][e], s1);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) {
+            s0 += __shfl_xor(s0, d);
+            s1 += __shfl_xor(s1, d);
+        }
+        if (q == 0 && mok) {
+            float v0 = s0 + b0, v1 = s1 + b1;
+            if (a.apply_act) { v0 = pwc_lrelu(v0, a.slope); v1 = pwc_lrelu(v1, a.slope); }
+            if (a.res) { v0 += a.res[(size_t)m * a.res_cs]; v1 += a.res[(size_t)m * a.res_cs + 1]; }
+            a.y[(size_t)m * a.y_cs] = v0;
+            a.y[(size_t)m * a.y_cs + 1] = v1;
+        }
+    }
+}
+
 extern "C" int pwc_conv3x3_direct_f32(const float* x, int x_cs, const float* w_hwio, const float* bias,
                                       float* y, int y_cs, const float* residual, int res_cs, int N, int H,
                                       int W, int Cin, int Cout, int stride, int dilation, int apply_act,
@@ -97,6 +207,20 @@ extern "C" int pwc_conv3x3_direct_f32(const float* x, int x_cs, const float* w_h
     const bool vec4 = (Cin % 4 == 0) && (x_cs % 4 == 0) && pwc_aligned16(x);
     const unsigned gx = (unsigned)((a.M + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
+    if (Cin == 3 && Cout % 4 == 0 && Cout <= 64 && !residual && (y_cs & 3) == 0 && pwc_aligned16(y) &&
+        pwc_aligned16(bias)) {
+        long blocks = (a.M * (Cout >> 2) + 255) / 256;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        hipLaunchKernelGGL(conv3x3_smallcin_kernel<3>, dim3((unsigned)blocks), dim3(256),
+                           (size_t)27 * Cout * sizeof(float), s, a);
+        return pwc_launch_status();
+    }
+    if (Cout == 2 && Cin == 32 && vec4) {
+        long blocks = (a.M + 31) / 32;            // 32 pixels per 256-thread block iteration
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL(conv3x3_head2_c32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        return pwc_launch_status();
+    }
 #define PWC_DIRECT(CT)                                                                              \
     do {                                                                                            \
         dim3 grid(gx, (unsigned)((Cout + CT - 1) / CT));                                            \

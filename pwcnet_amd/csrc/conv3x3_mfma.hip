@@ -38,11 +38,18 @@ struct ConvArgs {
     float slope;
     int M;      // N*Ho*Wo output pixels
     int y_vec4; // y pointer/stride allow float4 stores
+    int m_begin, m_end;   // pixel range of this launch (tail launches use a smaller tile)
+    int taps_per_split;   // 9 (no split), 3 or 1: blockIdx.z owns taps [z*tps, (z+1)*tps)
+    float* ws;            // split-K: raw partial sums ws[z][pixel][Cout_pad] (no bias/act)
+    int xcd_remap;        // consecutive pixel tiles on the same XCD (shared halo rows hit its L2)
 };
 
 __device__ __forceinline__ int swz4(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
-template <int WM, int WN, int WGM, int WGN, int KC>
+// ABL: ablation switch for scripts/exp_conv_ablate.hip only (0 in every shipped
+// instantiation): 1 = no global loads in the k loop, 2 = no LDS store / barrier,
+// 3 = both (MFMA + ds_read only).
+template <int WM, int WN, int WGM, int WGN, int KC, int ABL = 0>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
     constexpr int BM = 16 * WM * WGM;
@@ -62,8 +69,9 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
     const int lane = t & 63;
     const int wave = t >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
-    const int m0 = blockIdx.x * BM;
+    const int m0 = a.m_begin + (a.xcd_remap ? pwc_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x) * BM;
     const int n0 = blockIdx.y * BN;
+    const int tap0 = blockIdx.z * a.taps_per_split;
 
     // ---- per-thread A-load bookkeeping (fixed over the k loop)
     const int a_ch = t % CPP;          // 16-byte chunk within the pixel's KC channels
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
     for (int i = 0; i < A_LD; ++i) {
         const int row = a_row0 + i * PIX_STEP;
         const int m = m0 + row;
-        const bool ok = (row < BM) && (m < a.M);
+        const bool ok = (row < BM) && (m < a.m_end);
         const int mm = ok ? m : 0;
         const int n_img = mm / HoWo;
         const int rem = mm - n_img * HoWo;
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
     }
 
     const int CC = a.Cin_phys / KC; // stages per tap
-    const int S = 9 * CC;
+    const int S = a.taps_per_split * CC;
     const int nc16 = a.Cin_phys >> 4;
 
     f32x4 ra[A_LD], rb[B_LD];
@@ -147,8 +155,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
     const int fq = lane >> 4;            // k-slot
     const int f_off = fr * 16 + ((fq ^ swz4(fr)) << 2);
 
-    int tap = 0, cc = 0;
-    load_stage(0, 0);
+    int tap = tap0, cc = 0;
+    load_stage(tap0, 0);
     store_stage(0);
     __syncthreads();
 
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
         int ntap = tap, ncc = cc + 1;
         if (ncc == CC) { ncc = 0; ntap = tap + 1; }
         const bool more = (s + 1 < S);
-        if (more) load_stage(ntap, ncc);
+        if (more && !(ABL & 1)) load_stage(ntap, ncc);
 
         const float* Ab = smem + buf * STAGE;
         const float* Bb = Ab + BM * KC;
@@ -178,12 +186,29 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
                     for (int m = 0; m < WM; ++m)
                         acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][k], xf[m][k], acc[n][m], 0, 0, 0);
         }
-        if (more) store_stage(buf ^ 1);
-        __syncthreads();
+        if (!(ABL & 2)) {
+            if (more) store_stage(buf ^ 1);
+            __syncthreads();
+        }
         tap = ntap;
         cc = ncc;
     }
 
+    if (a.ws) {
+        // ---- split-K epilogue: raw partial sums to the workspace slab of this tap group
+        float* slab = a.ws + (size_t)blockIdx.z * a.M * a.Cout_pad;
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int co = n0 + (wn * WN + n) * 16 + fq * 4;
+            if (co >= a.Cout_pad) continue;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) {
+                const int pix = m0 + (wm * WM + m) * 16 + fr;
+                if (pix < a.m_end) *reinterpret_cast<f32x4*>(slab + (size_t)pix * a.Cout_pad + co) = acc[n][m];
+            }
+        }
+        return;
+    }
     // ---- epilogue: bias + leaky-relu, NHWC float4 stores (4 consecutive couts per lane)
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
@@ -193,7 +218,186 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int m = 0; m < WM; ++m) {
             const int pix = m0 + (wm * WM + m) * 16 + fr;
-            if (pix >= a.M) continue;
+            if (pix >= a.m_end) continue;
+            f32x4 v = acc[n][m] + b4;
+            if (a.apply_act) {
+                v[0] = pwc_lrelu(v[0], a.slope);
+                v[1] = pwc_lrelu(v[1], a.slope);
+                v[2] = pwc_lrelu(v[2], a.slope);
+                v[3] = pwc_lrelu(v[3], a.slope);
+            }
+            float* dst = a.y + (size_t)pix * a.y_cs + co;
+            if (a.y_vec4) {
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+                dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- LDS-DMA variant
+// Same tiling, LDS image and MFMA loop as conv3x3_mfma_kernel, but both operand tiles go
+// HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write pass): one
+// wave instruction fills one 16-row x 64-byte block (1 KiB, lane-linear).  The XOR swizzle
+// of the activation rows is applied on the SOURCE side (lane l fetches chunk
+// (l&3) ^ swz(row) of its pixel, a permutation inside the pixel's 64-byte segment); the
+// weight image is pre-swizzled by the packer.  Out-of-image taps (zero padding) and
+// rows past the end read a 16-byte zero page instead.
+__device__ float pwc_zero_page[4];
+
+template <int WM, int WN, int WGM, int WGN, int KC>
+__global__ __launch_bounds__(256) void conv3x3_mfma_glds_kernel(const ConvArgs a) {
+    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    constexpr int BM = 16 * WM * WGM;
+    constexpr int BN = 16 * WN * WGN;
+    constexpr int KG = KC / 16;
+    constexpr int NBA = (BM / 16) * KG;          // 1-KiB blocks of the activation tile
+    constexpr int NBB = (BN / 16) * KG;          // ... of the weight tile
+    constexpr int A_PW = (NBA + 3) / 4;          // blocks per wave
+    constexpr int B_PW = (NBB + 3) / 4;
+    constexpr int STAGE = (BM + BN) * KC;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = a.m_begin + (a.xcd_remap ? pwc_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x) * BM;
+    const int n0 = blockIdx.y * BN;
+    const int tap0 = blockIdx.z * a.taps_per_split;
+    const int lrow = lane >> 2, lslot = lane & 3;
+
+    // ---- activation blocks owned by this wave: block b = wave + 4*i -> (kgroup g, 16-row group rb)
+    const float* a_base[A_PW];
+    int a_iy0[A_PW], a_ix0[A_PW];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < A_PW; ++i) {
+        const int b = wave + 4 * i;
+        const int g = b / (BM / 16), rb = b % (BM / 16);
+        const int row = rb * 16 + lrow;
+        const int m = m0 + row;
+        const bool ok = (b < NBA) && (m < a.m_end);
+        const int mm = ok ? m : 0;
+        const int n_img = mm / HoWo;
+        const int rem = mm - n_img * HoWo;
+        const int oy = rem / a.Wo;
+        const int ox = rem - oy * a.Wo;
+        const int j = lslot ^ swz4(row);
+        a_base[i] = a.x + (size_t)n_img * a.H * a.W * a.x_cs + g * 16 + j * 4;
+        a_iy0[i] = ok ? oy * a.stride - a.pad_t : -(1 << 28);
+        a_ix0[i] = ox * a.stride - a.pad_l;
+    }
+    int b_src[B_PW];
+    bool b_ok[B_PW];
+#pragma unroll
+    for (int i = 0; i < B_PW; ++i) {
+        const int b = wave + 4 * i;
+        const int g = b / (BN / 16), rb = b % (BN / 16);
+        const int row = rb * 16 + lrow;
+        b_ok[i] = (b < NBB) && (n0 + row < a.Cout_pad);
+        b_src[i] = (g * a.Cout_pad + n0 + row) * 16 + lslot * 4;
+    }
+
+    const int CC = a.Cin_phys / KC;
+    const int S = a.taps_per_split * CC;
+    const int nc16 = a.Cin_phys >> 4;
+    const float* zero = pwc_zero_page;
+
+    auto issue_stage = [&](int tap, int cc, int buf) {
+        const int ty = tap / 3, tx = tap - ty * 3;
+        const int dy = ty * a.dil, dx = tx * a.dil;
+        float* Ab = smem + buf * STAGE;
+        float* Bb = Ab + BM * KC;
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) {
+            const int b = wave + 4 * i;
+            if (NBA % 4 != 0 && b >= NBA) break;
+            const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+            const bool ok = ((unsigned)iy < (unsigned)a.H) && ((unsigned)ix < (unsigned)a.W);
+            const float* src = ok ? a_base[i] + (size_t)(iy * a.W + ix) * a.x_cs + cc * KC : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ab + b * 256), 16, 0, 0);
+        }
+        const float* wsrc = a.wp + (size_t)(tap * nc16 + cc * KG) * a.Cout_pad * 16;
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i) {
+            const int b = wave + 4 * i;
+            if (NBB % 4 != 0 && b >= NBB) break;
+            const float* src = b_ok[i] ? wsrc + b_src[i] : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bb + b * 256), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[WN][WM];
+#pragma unroll
+    for (int n = 0; n < WN; ++n)
+#pragma unroll
+        for (int m = 0; m < WM; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int f_off = fr * 16 + ((fq ^ swz4(fr)) << 2);
+
+    int tap = tap0, cc = 0;
+    issue_stage(tap0, 0, 0);
+    __syncthreads();
+
+    for (int s = 0; s < S; ++s) {
+        const int buf = s & 1;
+        int ntap = tap, ncc = cc + 1;
+        if (ncc == CC) { ncc = 0; ntap = tap + 1; }
+        if (s + 1 < S) issue_stage(ntap, ncc, buf ^ 1);
+
+        const float* Ab = smem + buf * STAGE;
+        const float* Bb = Ab + BM * KC;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            f32x4 wf[WN], xf[WM];
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+                wf[n] = *reinterpret_cast<const f32x4*>(Bb + (g * BN + (wn * WN + n) * 16) * 16 + f_off);
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+                xf[m] = *reinterpret_cast<const f32x4*>(Ab + (g * BM + (wm * WM + m) * 16) * 16 + f_off);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int n = 0; n < WN; ++n)
+#pragma unroll
+                    for (int m = 0; m < WM; ++m)
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][k], xf[m][k], acc[n][m], 0, 0, 0);
+        }
+        __syncthreads();   // drains this stage's LDS-DMA (vmcnt) and orders the buffer swap
+        tap = ntap;
+        cc = ncc;
+    }
+
+    if (a.ws) {
+        float* slab = a.ws + (size_t)blockIdx.z * a.M * a.Cout_pad;
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int co = n0 + (wn * WN + n) * 16 + fq * 4;
+            if (co >= a.Cout_pad) continue;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) {
+                const int pix = m0 + (wm * WM + m) * 16 + fr;
+                if (pix < a.m_end) *reinterpret_cast<f32x4*>(slab + (size_t)pix * a.Cout_pad + co) = acc[n][m];
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const int co = n0 + (wn * WN + n) * 16 + fq * 4;
+        if (co >= a.Cout) continue;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+            const int pix = m0 + (wm * WM + m) * 16 + fr;
+            if (pix >= a.m_end) continue;
             f32x4 v = acc[n][m] + b4;
             if (a.apply_act) {
                 v[0] = pwc_lrelu(v[0], a.slope);
@@ -236,64 +440,135 @@ __global__ void conv3x3_pack_kernel(const float* __restrict__ w, const int32_t* 
     }
 }
 
+// ---------------------------------------------------------------- split-K reduce
+// y[pix][co] = act(bias[co] + sum_z ws[z][pix][co]); z summed in a fixed order, so the
+// result is deterministic.
+__global__ __launch_bounds__(256) void conv3x3_splitk_reduce_kernel(const float* __restrict__ ws,
+                                                                    const float* __restrict__ bias, float* y,
+                                                                    int y_cs, int y_vec4, int M, int Cout,
+                                                                    int Cout_pad, int nsplit, int apply_act,
+                                                                    float slope) {
+    const int c4n = Cout >> 2;
+    const long total = (long)M * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const long pix = idx / c4n;
+        f32x4 v = *reinterpret_cast<const f32x4*>(bias + c4 * 4);
+        for (int z = 0; z < nsplit; ++z)
+            v += *reinterpret_cast<const f32x4*>(ws + ((size_t)z * M + pix) * Cout_pad + c4 * 4);
+        if (apply_act) {
+            v[0] = pwc_lrelu(v[0], slope); v[1] = pwc_lrelu(v[1], slope);
+            v[2] = pwc_lrelu(v[2], slope); v[3] = pwc_lrelu(v[3], slope);
+        }
+        float* dst = y + (size_t)pix * y_cs + c4 * 4;
+        if (y_vec4) *reinterpret_cast<f32x4*>(dst) = v;
+        else { dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
+    }
+}
+
 // ---------------------------------------------------------------- host side
 typedef void (*conv_kernel_t)(const ConvArgs);
 
 struct TileCfg {
     int BM, BN;
+    int wgs_per_cu;   // resident workgroups per CU (LDS / VGPR limited), KC = 32 build
     conv_kernel_t k16, k32;
 };
 
-#define PWC_TILE(WM, WN, WGM, WGN)                                                        \
-    { 16 * WM * WGM, 16 * WN * WGN, conv3x3_mfma_kernel<WM, WN, WGM, WGN, 16>,            \
-      conv3x3_mfma_kernel<WM, WN, WGM, WGN, 32> }
+#define PWC_TILE(WM, WN, WGM, WGN, OCC)                                                   \
+    { 16 * WM * WGM, 16 * WN * WGN, OCC, conv3x3_mfma_kernel<WM, WN, WGM, WGN, 16>,       \
+      conv3x3_mfma_glds_kernel<WM, WN, WGM, WGN, 32> }
 
+// KC = 16 (Cin_phys % 32 != 0) uses the register-staged kernel, KC = 32 the LDS-DMA one
+// (measured on MI355X: LDS-DMA +2 % at KC = 32, -8 % at KC = 16).
 static const TileCfg g_tiles[] = {
-    PWC_TILE(4, 4, 2, 2), // 0: 128 x 128
-    PWC_TILE(4, 3, 2, 2), // 1: 128 x 96
-    PWC_TILE(4, 2, 2, 2), // 2: 128 x 64
-    PWC_TILE(4, 2, 4, 1), // 3: 256 x 32
-    PWC_TILE(4, 1, 4, 1), // 4: 256 x 16
-    PWC_TILE(2, 4, 2, 2), // 5: 64 x 128
-    PWC_TILE(2, 3, 2, 2), // 6: 64 x 96
-    PWC_TILE(2, 2, 2, 2), // 7: 64 x 64
-    PWC_TILE(2, 2, 4, 1), // 8: 128 x 32
-    PWC_TILE(2, 1, 4, 1), // 9: 128 x 16
-    PWC_TILE(1, 4, 2, 2), // 10: 32 x 128
-    PWC_TILE(1, 3, 2, 2), // 11: 32 x 96
-    PWC_TILE(1, 2, 2, 2), // 12: 32 x 64
-    PWC_TILE(1, 2, 4, 1), // 13: 64 x 32
-    PWC_TILE(1, 1, 4, 1), // 14: 64 x 16
+    PWC_TILE(4, 4, 2, 2, 2), // 0: 128 x 128
+    PWC_TILE(4, 3, 2, 2, 2), // 1: 128 x 96
+    PWC_TILE(4, 2, 2, 2, 3), // 2: 128 x 64
+    PWC_TILE(4, 2, 4, 1, 2), // 3: 256 x 32
+    PWC_TILE(4, 1, 4, 1, 2), // 4: 256 x 16
+    PWC_TILE(2, 4, 2, 2, 3), // 5: 64 x 128
+    PWC_TILE(2, 3, 2, 2, 3), // 6: 64 x 96
+    PWC_TILE(2, 2, 2, 2, 4), // 7: 64 x 64
+    PWC_TILE(2, 2, 4, 1, 4), // 8: 128 x 32
+    PWC_TILE(2, 1, 4, 1, 4), // 9: 128 x 16
+    PWC_TILE(1, 4, 2, 2, 3), // 10: 32 x 128
+    PWC_TILE(1, 3, 2, 2, 4), // 11: 32 x 96
+    PWC_TILE(1, 2, 2, 2, 6), // 12: 32 x 64
+    PWC_TILE(1, 2, 4, 1, 6), // 13: 64 x 32
+    PWC_TILE(1, 1, 4, 1, 6), // 14: 64 x 16
 };
 static const int g_ntiles = (int)(sizeof(g_tiles) / sizeof(g_tiles[0]));
 
-static int pick_tile(int M, int Cout_pad) {
-    // widest BN that divides Cout_pad, then the largest BM that still yields >= 512
-    // workgroups (2 per CU on 256 CUs); smallest BM if none does.
-    static const int by_bn[5][3] = {
-        /* BN=128 */ {0, 5, 10}, /* 96 */ {1, 6, 11}, /* 64 */ {2, 7, 12},
-        /* 32 */ {3, 8, 13},     /* 16 */ {4, 9, 14}};
-    int row;
-    if (Cout_pad % 128 == 0) row = 0;
-    else if (Cout_pad % 96 == 0) row = 1;
-    else if (Cout_pad % 64 == 0) row = 2;
-    else if (Cout_pad % 32 == 0) row = 3;
-    else row = 4;
-    for (int c = 0; c < 3; ++c) {
-        const TileCfg& tc = g_tiles[by_bn[row][c]];
-        const long wgs = (long)((M + tc.BM - 1) / tc.BM) * (Cout_pad / tc.BN);
-        if (wgs >= 512 || c == 2) return by_bn[row][c];
+// Launch plan of one convolution: tile configuration + optional split of the 9 taps over
+// blockIdx.z (small M: too few tiles to fill 256 CUs).  tail_tile/m_main describe an
+// optional second launch with a smaller tile for the last pixels (measured: no gain on
+// MI355X -- a lone workgroup per CU gets the whole MFMA pipe -- so the planner never
+// emits it; the kernel-side pixel range stays for explicit use).
+struct ConvPlan {
+    int tile, tail_tile, m_main, nsplit;
+};
+
+// Measured on MI355X (scripts/tune_conv.py, all layer shapes of the 8x448x1024 forward):
+// the fastest configuration is the LARGEST tile that still yields >= ~384 workgroups,
+// scanning BN downwards before resorting to the tap split.  Preferred tiles per BN, large
+// BM first (128x96 and 256x32 are never the best: lower occupancy).
+static ConvPlan plan_conv(int M, int Cout_pad, int Cin_phys, bool allow_split) {
+    static const int kBN[5] = {128, 96, 64, 32, 16};
+    static const int pref[5][3] = {{0, 5, 10}, {6, 11, -1}, {2, 7, 12}, {8, 13, -1}, {4, 9, 14}};
+    const long target = 384;
+    ConvPlan p;
+    p.tail_tile = -1;
+    p.m_main = M;
+    p.nsplit = 1;
+    p.tile = -1;
+    const int max_split = (allow_split && Cin_phys >= 64) ? 9 : 1;
+    int last_valid = -1;
+    for (int split = 1; split <= max_split; split *= 3) {
+        for (int r = 0; r < 5; ++r) {
+            if (Cout_pad % kBN[r]) continue;
+            for (int c = 0; c < 3; ++c) {
+                const int t = pref[r][c];
+                if (t < 0) continue;
+                const TileCfg& tc = g_tiles[t];
+                const long wgs = (long)((M + tc.BM - 1) / tc.BM) * (Cout_pad / tc.BN) * split;
+                last_valid = t;
+                if (wgs >= target) { p.tile = t; p.nsplit = split; return p; }
+            }
+        }
     }
-    return by_bn[row][2];
+    // nothing reaches the target: smallest tile of the widest usable BN, deepest split
+    for (int r = 0; r < 5 && p.tile < 0; ++r) {
+        if (Cout_pad % kBN[r]) continue;
+        if (Cout_pad / kBN[r] * ((M + 31) / 32) * max_split >= 64 || r == 4) {
+            for (int c = 2; c >= 0; --c)
+                if (pref[r][c] >= 0) { p.tile = pref[r][c]; break; }
+        }
+    }
+    if (p.tile < 0) p.tile = last_valid;
+    p.nsplit = max_split;
+    return p;
 }
 
-extern "C" int pwc_conv3x3_select_tile(int M, int Cout, int Cin_phys, int* bm, int* bn, int* kc) {
-    if (M <= 0 || Cout <= 0 || Cin_phys <= 0) return PWC_EINVAL;
-    const int tile = pick_tile(M, (Cout + 15) & ~15);
+extern "C" int pwc_conv3x3_plan(int M, int Cout, int Cin_phys, int* plan4) {
+    if (M <= 0 || Cout <= 0 || Cin_phys <= 0 || !plan4) return PWC_EINVAL;
+    const ConvPlan p = plan_conv(M, (Cout + 15) & ~15, Cin_phys, true);
+    plan4[0] = p.tile; plan4[1] = p.tail_tile; plan4[2] = p.m_main; plan4[3] = p.nsplit;
+    return PWC_OK;
+}
+
+extern "C" int pwc_conv3x3_tile_shape(int tile, int* bm, int* bn) {
+    if (tile < 0 || tile >= g_ntiles) return PWC_EINVAL;
     if (bm) *bm = g_tiles[tile].BM;
     if (bn) *bn = g_tiles[tile].BN;
-    if (kc) *kc = (Cin_phys % 32 == 0) ? 32 : 16;
-    return tile;
+    return PWC_OK;
+}
+
+extern "C" size_t pwc_conv3x3_workspace_floats(int M, int Cout) {
+    // worst case: 9-way tap split of the whole output
+    if (M <= 0 || Cout <= 0) return 0;
+    return (size_t)9 * M * ((Cout + 15) & ~15);
 }
 
 extern "C" size_t pwc_conv3x3_packed_floats(int Cin_phys, int Cout) {
@@ -315,15 +590,32 @@ extern "C" int pwc_conv3x3_pack_f32(const float* w_hwio, const int32_t* cin_map,
     return pwc_launch_status();
 }
 
+static int launch_tile(const ConvArgs& base, int tile, int m_begin, int m_end, int nsplit, hipStream_t s) {
+    const TileCfg& tc = g_tiles[tile];
+    ConvArgs a = base;
+    a.m_begin = m_begin;
+    a.m_end = m_end;
+    a.taps_per_split = 9 / nsplit;
+    if (nsplit == 1) a.ws = nullptr;
+    const int KC = (a.Cin_phys % 32 == 0) ? 32 : 16;
+    conv_kernel_t k = KC == 32 ? tc.k32 : tc.k16;
+    const size_t lds = (size_t)2 * (tc.BM + tc.BN) * KC * sizeof(float);
+    dim3 grid((unsigned)((m_end - m_begin + tc.BM - 1) / tc.BM), (unsigned)(a.Cout_pad / tc.BN), (unsigned)nsplit);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+    return pwc_launch_status();
+}
+
 extern "C" int pwc_conv3x3_f32(const float* x, int x_cs, const float* packed, const float* bias, float* y,
                                int y_cs, int N, int H, int W, int Cin_phys, int Cout, int stride,
-                               int dilation, int apply_act, float slope, int tile, pwc_stream_t stream) {
+                               int dilation, int apply_act, float slope, int tile, int split,
+                               float* workspace, size_t workspace_floats, pwc_stream_t stream) {
     if (!x || !packed || !bias || !y) return PWC_EINVAL;
     if (N <= 0 || H <= 0 || W <= 0 || Cin_phys <= 0 || Cout <= 0) return PWC_EINVAL;
     if (stride < 1 || stride > 2 || dilation < 1) return PWC_EINVAL;
     if (Cin_phys % 16 || Cout % 16) return PWC_EUNSUPPORTED;
     if (x_cs < Cin_phys || y_cs < Cout) return PWC_EINVAL;
     if ((x_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(packed) || !pwc_aligned16(bias)) return PWC_EALIGN;
+    if (split != 0 && split != 1 && split != 3 && split != 9) return PWC_EINVAL;
     ConvArgs a;
     a.x = x; a.wp = packed; a.bias = bias; a.y = y;
     a.x_cs = x_cs; a.y_cs = y_cs;
@@ -338,14 +630,33 @@ extern "C" int pwc_conv3x3_f32(const float* x, int x_cs, const float* packed, co
     if (M >= (1L << 31) || (long)H * W * x_cs >= (1L << 31)) return PWC_ERANGE;
     a.M = (int)M;
     a.y_vec4 = ((y_cs & 3) == 0 && pwc_aligned16(y)) ? 1 : 0;
-    if (tile < 0) tile = pick_tile(a.M, a.Cout_pad);
-    if (tile >= g_ntiles) return PWC_EINVAL;
-    const TileCfg& tc = g_tiles[tile];
-    if (a.Cout_pad % tc.BN) return PWC_EINVAL;
-    const int KC = (Cin_phys % 32 == 0) ? 32 : 16;
-    conv_kernel_t k = KC == 32 ? tc.k32 : tc.k16;
-    const size_t lds = (size_t)2 * (tc.BM + tc.BN) * KC * sizeof(float);
-    dim3 grid((unsigned)((a.M + tc.BM - 1) / tc.BM), (unsigned)(a.Cout_pad / tc.BN));
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, (hipStream_t)stream, a);
-    return pwc_launch_status();
+    a.ws = workspace;
+    a.xcd_remap = 1;
+    hipStream_t s = (hipStream_t)stream;
+
+    const bool ws_ok = workspace && pwc_aligned16(workspace);
+    ConvPlan p;
+    if (tile < 0) {
+        p = plan_conv(a.M, a.Cout_pad, Cin_phys, ws_ok && split != 1);
+        if (split > 1) p.nsplit = split;
+    } else {
+        if (tile >= g_ntiles) return PWC_EINVAL;
+        p.tile = tile; p.tail_tile = -1; p.m_main = a.M; p.nsplit = split > 1 ? split : 1;
+    }
+    if (a.Cout_pad % g_tiles[p.tile].BN) return PWC_EINVAL;
+    if (p.nsplit > 1) {
+        if (!ws_ok || workspace_floats < (size_t)p.nsplit * a.M * a.Cout_pad) return PWC_EINVAL;
+        int rc = launch_tile(a, p.tile, 0, a.M, p.nsplit, s);
+        if (rc) return rc;
+        const long total = (long)a.M * (Cout >> 2);
+        long blocks = (total + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(conv3x3_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, bias,
+                           y, y_cs, a.y_vec4, a.M, Cout, a.Cout_pad, p.nsplit, apply_act, slope);
+        return pwc_launch_status();
+    }
+    int rc = launch_tile(a, p.tile, 0, p.m_main, 1, s);
+    if (rc) return rc;
+    if (p.tail_tile >= 0 && p.m_main < a.M) rc = launch_tile(a, p.tail_tile, p.m_main, a.M, 1, s);
+    return rc;
 }

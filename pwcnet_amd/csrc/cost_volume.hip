@@ -8,17 +8,22 @@
 //
 //   out[n,y,x,(v+R)*D+(h+R)] = lrelu( (1/C) * sum_c f0[n,y,x,c] * f1w[n,y+v,x+h,c] )
 //
-// HBM-bound op (AI = 2*81*C / ((2C+81)*4) = 8.9 flop/B at C = 32).  Work decomposition:
-//   workgroup = 4 x 64 output pixels of one image, D = 2R+1 waves; wave w owns the
-//     vertical shift v = w - R (wave-uniform), lane = a strip of 4 consecutive pixels,
-//     so one lane accumulates 4 pixels x D horizontal shifts = 36 outputs in VGPRs;
-//   channels are processed in chunks of 16.  Per chunk the f1w halo tile
-//     (4+2R) x (64+8) and the f0 tile are loaded NHWC-coalesced from HBM and TRANSPOSED
-//     into channel planes in LDS ([c][y][x], x contiguous), so the inner loop is 3
-//     ds_read_b128 (12-pixel window) + 1 ds_read_b128 (f0) per 36 FMAs, conflict-free:
-//     the lane -> strip map follows the four 16-lane groups a ds_read_b128 is serviced in;
-//   the 256 x 81 result tile goes back through LDS so that HBM stores are contiguous
-//     (324 B per pixel) instead of 4-byte scatters.
+// HBM-bound op (AI = 2*81*C / ((2C+81)*4) = 8.9 flop/B at C = 32).  Decomposition:
+//   workgroup = 4 x 64 output pixels of one image; channels in chunks of 16.
+//   LDS holds the f1w halo tile (4+2R) x 72 pixels PIXEL-major, one 80-byte row per pixel
+//     (16 channels + 16 bytes of padding): 64 lanes reading the same channel quad of 64
+//     consecutive pixels touch 16 distinct 16-byte slots per ds_read_b128 service group
+//     (row*5 mod 16 is a bijection), and every read address is lane_base + a compile-time
+//     offset -- no per-read address arithmetic.  The loader moves 16-byte channel quads
+//     global -> VGPR -> ds_write_b128 (plain form) or gathers the 4 bilinear corners and
+//     blends them in registers first (fused-warp form); pixels outside the image are 0.
+//   Wave = (row pair, group of 3 vertical shifts); lane = output column.  A thread owns 2
+//     vertically adjacent pixels x 3 shifts x D horizontal shifts = 54 accumulators; the 4
+//     f1w rows it needs are shared by its two pixels (36 ds_read_b128 per 216 FMAs); its
+//     two f0 pixels are read straight from global memory into registers.
+//   The 256 x 81 result tile goes back through LDS (stride 81 floats: odd, conflict-free)
+//     so that HBM stores are contiguous 324-byte pixel records, not 4-byte scatters.
+//   Tiles are visited in XCD-aware order (neighbouring tiles share halo rows in one L2).
 #include "pwc_common.h"
 
 struct CvArgs {
@@ -31,6 +36,7 @@ struct CvArgs {
     float flow_scale;
     float slope;
     int tiles_x, tiles_y;
+    int out_vec4;        // out pointer / stride allow 16-byte stores
 };
 
 constexpr int CV_TH = 4, CV_TW = 64, CV_CK = 16, CV_HW = CV_TW + 8;
@@ -55,24 +61,33 @@ __device__ __forceinline__ f32x4 cv_warp_gather(const float* f1n, int f1_cs, int
     return c00 * v00 + c01 * v01 + c10 * v10 + c11 * v11;
 }
 
+constexpr int CV_RS = 20;   // LDS row stride in floats (16 channels + 4 padding)
+
+template <int R>
+struct CvGeom {
+    static constexpr int D = 2 * R + 1, DD = D * D;
+    static constexpr int NG = (D + 2) / 3;                 // groups of 3 vertical shifts
+    static constexpr int NW = (CV_TH / 2) * NG;            // waves per workgroup
+    static constexpr int T = 64 * NW;
+    static constexpr int HH = CV_TH + 2 * R;               // halo rows
+    static constexpr int NR1 = HH * CV_HW;                 // f1 pixels in LDS
+    static constexpr int LDS_FLOATS = (NR1 * CV_RS > 128 * DD) ? NR1 * CV_RS : 128 * DD;
+};
+
 template <int R, bool FUSED>
-__global__ __launch_bounds__(64 * (2 * R + 1)) void cost_volume_kernel(const CvArgs a) {
-    constexpr int D = 2 * R + 1, DD = D * D;
-    constexpr int T = 64 * D;
-    constexpr int HH = CV_TH + 2 * R;                        // halo rows
-    constexpr int PS1 = ((HH * CV_HW + 24 + 31) / 32) * 32;  // f1 plane stride (floats)
-    constexpr int PS0 = ((CV_TH * CV_TW + 24 + 31) / 32) * 32;
-    constexpr int F0_BASE = CV_CK * PS1;
-    constexpr int N1 = HH * CV_HW * 4;                       // f1 load items (pixel x 4-ch quad)
-    constexpr int N0 = CV_TH * CV_TW * 4;
-    constexpr int NI = N1 + N0;
-    static_assert(CV_CK * (PS1 + PS0) >= 128 * DD, "output stage must fit in the tile LDS");
+__global__ __launch_bounds__(64 * CvGeom<R>::NW) void cost_volume_kernel(const CvArgs a) {
+    using G = CvGeom<R>;
+    constexpr int D = G::D, DD = G::DD, T = G::T;
+    constexpr int NI = G::NR1 * 4;                         // loader items: (halo pixel, channel quad)
+    constexpr int IPT = (NI + T - 1) / T;                  // items per thread per chunk
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);   // vertical shift index, v = w - R
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int yp = wave / G::NG;          // row pair: output rows 2*yp, 2*yp+1 of the tile
+    const int vg = wave % G::NG;          // vertical shift indices 3*vg .. 3*vg+2
 
     // tile decode (XCD-aware: consecutive logical tiles share an XCD's L2)
     const int nb = a.tiles_x * a.tiles_y * a.N;
@@ -86,101 +101,135 @@ __global__ __launch_bounds__(64 * (2 * R + 1)) void cost_volume_kernel(const CvA
     const float* f1n = a.f1 + (size_t)n * a.H * a.W * a.f1_cs;
     const float* fln = FUSED ? a.flow + (size_t)n * a.H * a.W * a.flow_cs : nullptr;
 
-    // lane -> (row, strip): each ds_read_b128 service group (16 lanes) reads one row's
-    // 16 consecutive 16-byte slots.
-    const int b = (lane & 31) >> 2;
-    const int row = 2 * (lane >> 5) + (__builtin_popcount(b) & 1);
-    const int x4 = (b >> 1) * 4 + (lane & 3);
+    // ---- loader bookkeeping (fixed over the channel loop): item q = t + T*i -> (pixel, quad)
+    int ld_src[IPT];     // plain: element offset of the pixel in f1 (+ quad*4), <0 = zero fill
+    int ld_dst[IPT];     // LDS float offset, <0 = no item
+    float ld_fx[FUSED ? IPT : 1], ld_fy[FUSED ? IPT : 1];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const int q = t + T * i;
+        const int cq = q & 3, row = q >> 2;
+        const int py = row / CV_HW, pxx = row - py * CV_HW;
+        const int y = y0 - R + py, x = x0 - 4 + pxx;
+        const bool inside = (q < NI) && ((unsigned)y < (unsigned)a.H) && ((unsigned)x < (unsigned)a.W);
+        ld_dst[i] = (q < NI) ? row * CV_RS + cq * 4 : -1;
+        ld_src[i] = inside ? (y * a.W + x) * a.f1_cs + cq * 4 : -1;
+        if (FUSED) {
+            // for the fused form ld_src keeps (y*W + x) and the flow is read once per tile
+            ld_src[i] = inside ? ((y * a.W + x) << 2) | cq : -1;
+            float fx = 0.f, fy = 0.f;
+            if (inside) {
+                const float* fp = fln + (size_t)(y * a.W + x) * a.flow_cs;
+                fx = fp[0] * a.flow_scale;
+                fy = fp[1] * a.flow_scale;
+            }
+            ld_fx[i] = fx;
+            ld_fy[i] = fy;
+        }
+    }
+    // the two f0 pixels of this thread (rows 2yp, 2yp+1, column lane)
+    const int oy0 = y0 + 2 * yp, ox = x0 + lane;
+    const bool f0ok0 = (oy0 < a.H) && (ox < a.W), f0ok1 = (oy0 + 1 < a.H) && (ox < a.W);
+    const float* f0p0 = f0n + (size_t)(f0ok0 ? oy0 * a.W + ox : 0) * a.f0_cs;
+    const float* f0p1 = f0n + (size_t)(f0ok1 ? (oy0 + 1) * a.W + ox : 0) * a.f0_cs;
 
-    float acc[4][D];
+    float acc[2][3][D];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int h = 0; h < D; ++h) acc[i][h] = 0.f;
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int h = 0; h < D; ++h) acc[j][v][h] = 0.f;
+
+    // lane base of the f1 reads: halo row (2yp + 3vg), column lane + 4 - R
+    const float* rd = smem + ((2 * yp + 3 * vg) * CV_HW + lane + 4 - R) * CV_RS;
 
     for (int c0 = 0; c0 < a.C; c0 += CV_CK) {
-        // ---------------- load + transpose this channel chunk into LDS planes
-        constexpr int U = 4;
-        for (int q0 = t; q0 < NI; q0 += T * U) {
-            f32x4 v[U];
-            int dst[U];
+        // ---------------- f0 channel chunk of the two own pixels -> registers
+        f32x4 a0[4], a1[4];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int q = q0 + u * T;
-                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dst[u] = -1;
-                if (q < N1) {
-                    const int cq = q & 3, px = q >> 2;
-                    const int py = px / CV_HW, pxx = px - py * CV_HW;
-                    const int y = y0 - R + py, x = x0 - 4 + pxx;
-                    dst[u] = cq * 4 * PS1 + 8 * cq + py * CV_HW + pxx;
-                    const int c = c0 + cq * 4;
-                    if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W && c < a.C) {
+        for (int cq = 0; cq < 4; ++cq) {
+            a0[cq] = f32x4{0.f, 0.f, 0.f, 0.f};
+            a1[cq] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c0 + cq * 4 < a.C) {
+                if (f0ok0) a0[cq] = *reinterpret_cast<const f32x4*>(f0p0 + c0 + cq * 4);
+                if (f0ok1) a1[cq] = *reinterpret_cast<const f32x4*>(f0p1 + c0 + cq * 4);
+            }
+        }
+        // ---------------- f1w halo chunk -> LDS (batches of LB items keep the loads in flight
+        // within the register budget: the fused form holds 4 corner quads per item)
+        {
+            constexpr int LB = FUSED ? 1 : IPT;
+#pragma unroll
+            for (int i0 = 0; i0 < IPT; i0 += LB) {
+                f32x4 v[LB];
+#pragma unroll
+                for (int u = 0; u < LB; ++u) {
+                    const int i = i0 + u;
+                    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (i < IPT && ld_src[i < IPT ? i : 0] >= 0) {
                         if (FUSED) {
-                            const float* fp = fln + ((size_t)y * a.W + x) * a.flow_cs;
-                            v[u] = cv_warp_gather(f1n, a.f1_cs, c, a.H, a.W, y, x, fp[0] * a.flow_scale,
-                                                  fp[1] * a.flow_scale);
+                            const int cq = ld_src[i] & 3, pix = ld_src[i] >> 2;
+                            const int y = pix / a.W, x = pix - y * a.W;
+                            if (c0 + cq * 4 < a.C)
+                                v[u] = cv_warp_gather(f1n, a.f1_cs, c0 + cq * 4, a.H, a.W, y, x, ld_fx[i], ld_fy[i]);
                         } else {
-                            v[u] = *reinterpret_cast<const f32x4*>(f1n + ((size_t)y * a.W + x) * a.f1_cs + c);
+                            v[u] = *reinterpret_cast<const f32x4*>(f1n + ld_src[i] + c0);
                         }
                     }
-                } else if (q < NI) {
-                    const int qq = q - N1;
-                    const int cq = qq & 3, px = qq >> 2;
-                    const int py = px >> 6, pxx = px & 63;
-                    const int y = y0 + py, x = x0 + pxx;
-                    dst[u] = F0_BASE + cq * 4 * PS0 + 8 * cq + py * CV_TW + pxx;
-                    const int c = c0 + cq * 4;
-                    if (y < a.H && x < a.W && c < a.C)
-                        v[u] = *reinterpret_cast<const f32x4*>(f0n + ((size_t)y * a.W + x) * a.f0_cs + c);
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (dst[u] >= 0) {
-                    const int ps = dst[u] >= F0_BASE ? PS0 : PS1;
-                    smem[dst[u]] = v[u][0];
-                    smem[dst[u] + ps] = v[u][1];
-                    smem[dst[u] + 2 * ps] = v[u][2];
-                    smem[dst[u] + 3 * ps] = v[u][3];
+                for (int u = 0; u < LB; ++u) {
+                    const int i = i0 + u;
+                    if (i < IPT && ld_dst[i < IPT ? i : 0] >= 0) *reinterpret_cast<f32x4*>(smem + ld_dst[i]) = v[u];
                 }
+                if (FUSED) __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
 
-        // ---------------- correlate: 16 channels x (4 pixels x D shifts) per lane
-        const float* p1 = smem + (row + w) * CV_HW + 4 * x4;
-        const float* p0 = smem + F0_BASE + row * CV_TW + 4 * x4;
+        // ---------------- correlate: 4 channel quads x (4 f1w rows x D columns)
 #pragma unroll
-        for (int c = 0; c < CV_CK; ++c) {
-            const int sk = 8 * (c >> 2);
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(p0 + c * PS0 + sk);
-            float win[12];
-            *reinterpret_cast<f32x4*>(&win[0]) = *reinterpret_cast<const f32x4*>(p1 + c * PS1 + sk);
-            *reinterpret_cast<f32x4*>(&win[4]) = *reinterpret_cast<const f32x4*>(p1 + c * PS1 + sk + 4);
-            *reinterpret_cast<f32x4*>(&win[8]) = *reinterpret_cast<const f32x4*>(p1 + c * PS1 + sk + 8);
+        for (int cq = 0; cq < 4; ++cq) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                for (int h = 0; h < D; ++h) acc[i][h] = fmaf(a0[i], win[i + h + 4 - R], acc[i][h]);
+                for (int h = 0; h < D; ++h) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(rd + (r * CV_HW + h) * CV_RS + cq * 4);
+                    if (r < 3) {
+                        float s = acc[0][r][h];
+                        s = fmaf(a0[cq][0], w[0], s); s = fmaf(a0[cq][1], w[1], s);
+                        s = fmaf(a0[cq][2], w[2], s); s = fmaf(a0[cq][3], w[3], s);
+                        acc[0][r][h] = s;
+                    }
+                    if (r >= 1) {
+                        float s = acc[1][r - 1][h];
+                        s = fmaf(a1[cq][0], w[0], s); s = fmaf(a1[cq][1], w[1], s);
+                        s = fmaf(a1[cq][2], w[2], s); s = fmaf(a1[cq][3], w[3], s);
+                        acc[1][r - 1][h] = s;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);         // keep one f1w row of reads in flight
+            }
         }
         __syncthreads();
     }
 
     // ---------------- mean over C, leaky-relu, stage through LDS, contiguous stores
-    const float fC = (float)a.C;
+    const float inv_c = 1.0f / (float)a.C;   // reduce_mean: x * (1/C), within 1 ulp of x / C
+    for (int hf = 0; hf < CV_TH / 2; ++hf) {
+        if (yp == hf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int h = 0; h < D; ++h) acc[i][h] = pwc_lrelu(acc[i][h] / fC, a.slope);
-
-    for (int hf = 0; hf < 2; ++hf) {
-        if ((row >> 1) == hf) {
-            float* st = smem + (((row & 1) * CV_TW + 4 * x4) * DD) + w * D;
+                for (int v = 0; v < 3; ++v) {
+                    const int vi = 3 * vg + v;
+                    if (vi < D) {
+                        float* st = smem + (j * CV_TW + lane) * DD + vi * D;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int h = 0; h < D; ++h) st[i * DD + h] = acc[i][h];
+                        for (int h = 0; h < D; ++h) st[h] = pwc_lrelu(acc[j][v][h] * inv_c, a.slope);
+                    }
+                }
         }
         __syncthreads();
         for (int e = t; e < 128 * DD; e += T) {
@@ -192,31 +241,298 @@ __global__ __launch_bounds__(64 * (2 * R + 1)) void cost_volume_kernel(const CvA
     }
 }
 
+// ---------------------------------------------------------------- persistent LDS-DMA form
+// The production kernel for the plain cost volume (the warp, when needed, runs first as
+// its own HBM-streaming kernel).  Differences from cost_volume_kernel above:
+//   * LDS rows are dense 64-byte pixel records, so both tiles (f1w halo, f0) are filled by
+//     global_load_lds_dwordx4: 1 KiB per wave instruction, no VGPR staging, no ds_write;
+//   * bank conflicts are avoided on the READ side by a per-lane chunk rotation: at step s
+//     lane l reads channel quad (s + (l>>2)) & 3 of its pixel row -- within a 16-lane
+//     ds_read_b128 service group the 4 lanes that share a quad sit on 4 different rows
+//     mod 4, and the 4 quads differ, whatever the row shift K; every address is
+//     lane_base[s] + K*64 bytes (an immediate);
+//   * two LDS stages: the DMA of the next stage (next 16-channel chunk, or the first chunk
+//     of the workgroup's NEXT tile) is issued before the current stage is computed;
+//   * one workgroup per CU walks its tiles persistently, so the HBM stream never stops
+//     at tile boundaries; the result tile is staged through the stage just consumed.
+__device__ float cv_zero_page[4];
+
+template <int R>
+struct CvPGeom {
+    static constexpr int D = 2 * R + 1, DD = D * D;
+    static constexpr int NG = (D + 2) / 3;                 // groups of 3 vertical shifts
+    static constexpr int NHS = (D >= 5) ? 2 : 1;           // horizontal shifts split over NHS waves
+    static constexpr int DH = (D + NHS - 1) / NHS;         // horizontal shifts per wave
+    static constexpr int NW = (CV_TH / 2) * NG * NHS;      // waves per workgroup (12 for R = 4)
+    static constexpr int T = 64 * NW;
+    static constexpr int HH = CV_TH + 2 * R;
+    static constexpr int NR1 = HH * CV_HW;
+    static constexpr int NR0 = CV_TH * CV_TW;
+    static constexpr int NB1 = NR1 / 16, NB0 = NR0 / 16, NBT = NB1 + NB0;
+    static constexpr int F0_BASE = NR1 * 16;
+    static constexpr int BUF = (NR1 + NR0) * 16;          // floats per stage
+    static_assert(NR1 % 16 == 0, "halo tile must be whole 16-row DMA blocks");
+    static_assert(BUF >= 128 * ((DD + 3) & ~3), "output stage must fit in one LDS stage");
+};
+
+// ABL: ablation switch for scripts/exp_cv.hip only (0 in the library): 1 = no FMAs,
+// 2 = no DMA, 4 = no result stores.
+template <int R, int ABL = 0>
+__global__ __launch_bounds__(64 * CvPGeom<R>::NW) void cost_volume_dma_kernel(const CvArgs a) {
+    using G = CvPGeom<R>;
+    constexpr int D = G::D, DD = G::DD, NW = G::NW, T = G::T, DH = G::DH;
+    constexpr int BPW = (G::NBT + NW - 1) / NW;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int hs = wave % G::NHS;                          // which half of the horizontal shifts
+    const int yp = (wave / G::NHS) / G::NG, vg = (wave / G::NHS) % G::NG;
+    const int h0 = hs * DH;
+    const float* zero = cv_zero_page;
+
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int ntiles = tiles_per_img * a.N;
+    const int nwg = gridDim.x;
+    // XCD-aware start: workgroups of one XCD own neighbouring tiles
+    const int first = pwc_xcd_remap(blockIdx.x, nwg);
+    const int spt = (a.C + CV_CK - 1) / CV_CK;             // stages per tile
+    const int cl = (lane & 3) * 4;                         // this lane's channel quad within a chunk
+
+    // ---- DMA bookkeeping.  Block b = wave + NW*i covers LDS rows 16b..16b+15; this lane
+    // fills row 16b + (lane>>2), chunk lane&3.  The (row -> tile pixel) map is tile
+    // independent: packed as (py << 8) | px with bit 31 = f0 block.
+    int blk_px[BPW];
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+        const int b = wave + NW * i;
+        const int row = b * 16 + (lane >> 2);
+        int v = -1;
+        if (b < G::NB1) {
+            const int py = row / CV_HW;
+            v = (py << 8) | (row - py * CV_HW);
+        } else if (b < G::NBT) {
+            const int r0 = row - G::NR1;
+            v = (int)0x40000000 | ((r0 >> 6) << 8) | (r0 & 63);
+        }
+        blk_px[i] = v;
+    }
+    // per-tile source element offsets of the tile whose stages are being ISSUED (-1: zeros)
+    int src_off[BPW];
+    const float* src_img0 = a.f0;
+    const float* src_img1 = a.f1;
+    auto tile_offsets = [&](int lt) {
+        const int n = lt / tiles_per_img;
+        const int rem = lt - n * tiles_per_img;
+        const int ty_ = rem / a.tiles_x, tx_ = rem - ty_ * a.tiles_x;
+        const int x0 = tx_ * CV_TW, y0 = ty_ * CV_TH;
+        src_img0 = a.f0 + (size_t)n * a.H * a.W * a.f0_cs;
+        src_img1 = a.f1 + (size_t)n * a.H * a.W * a.f1_cs;
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const int v = blk_px[i];
+            const bool is0 = (v & 0x40000000) != 0;
+            const int py = (v >> 8) & 0xFFFF, px = v & 0xFF;
+            const int y = is0 ? y0 + py : y0 - R + py;
+            const int x = is0 ? x0 + px : x0 - 4 + px;
+            const bool ok = (v >= 0) && ((unsigned)y < (unsigned)a.H) && ((unsigned)x < (unsigned)a.W);
+            src_off[i] = ok ? (y * a.W + x) * (is0 ? a.f0_cs : a.f1_cs) + cl : -1;
+        }
+    };
+    auto issue_stage = [&](int c0, int buf) {
+        float* dst = smem + buf * G::BUF;
+        const bool cok = (c0 + cl) < a.C;
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const int b = wave + NW * i;                   // wave-uniform
+            if (b < G::NBT) {
+                const float* base = (b < G::NB1) ? src_img1 : src_img0;
+                const float* src = (src_off[i] >= 0 && cok) ? base + src_off[i] + c0 : zero;
+                if (!(ABL & 2)) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + b * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    // per-lane read bases: chunk rotation cs(s) = (s + (lane >> 2)) & 3
+    const int r_base = 2 * yp + 3 * vg;
+    int rd1[4], rd0[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int cs = (s + (lane >> 2)) & 3;
+        rd1[s] = (r_base * CV_HW + lane + 4 - R + h0) * 16 + cs * 4;
+        rd0[s] = G::F0_BASE + ((2 * yp) * CV_TW + lane) * 16 + cs * 4;
+    }
+
+    // issue side runs one stage ahead of the compute side
+    int itile = first, ichunk = 0;
+    int cur = 0;
+    if (itile < ntiles) {
+        tile_offsets(itile);
+        issue_stage(0, 0);
+        if (++ichunk == spt) { ichunk = 0; itile += nwg; if (itile < ntiles) tile_offsets(itile); }
+    }
+    for (int lt = first; lt < ntiles; lt += nwg) {
+        const int n = lt / tiles_per_img;
+        const int rem = lt - n * tiles_per_img;
+        const int ty_ = rem / a.tiles_x, tx_ = rem - ty_ * a.tiles_x;
+        const int x0 = tx_ * CV_TW, y0 = ty_ * CV_TH;
+
+        float acc[2][3][DH];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+#pragma unroll
+                for (int h = 0; h < DH; ++h) acc[j][v][h] = 0.f;
+
+        for (int ci = 0; ci < spt; ++ci) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stage's DMA has landed
+            __syncthreads();                                  // ... for every wave; previous stage fully read
+            if (itile < ntiles) {
+                issue_stage(ichunk * CV_CK, cur ^ 1);
+                if (++ichunk == spt) { ichunk = 0; itile += nwg; if (itile < ntiles) tile_offsets(itile); }
+            }
+
+            const float* sb = smem + cur * G::BUF;
+            // 16 steps (4 channel quads x 4 f1w rows); the D reads of step k+1 are issued
+            // before the FMAs of step k (explicit register double buffer), so LDS latency
+            // is covered by 36..72 FMAs instead of being exposed once per row.
+            f32x4 wb[2][DH];
+            f32x4 fa[2][2];
+            auto load_row = [&](int k, int slot) {
+                const int s = k >> 2, r = k & 3;
+                // partial last shift group (D % 3 != 0): rows past the halo feed unused sums
+                const int rr = (D % 3 != 0 && r_base + r >= G::HH) ? G::HH - 1 - r_base : r;
+#pragma unroll
+                for (int h = 0; h < DH; ++h)   // (a column past D on the last split reads a valid halo pixel)
+                    wb[slot][h] = *reinterpret_cast<const f32x4*>(sb + rd1[s] + (rr * CV_HW + h) * 16);
+                if (r == 0) {
+                    fa[s & 1][0] = *reinterpret_cast<const f32x4*>(sb + rd0[s]);
+                    fa[s & 1][1] = *reinterpret_cast<const f32x4*>(sb + rd0[s] + CV_TW * 16);
+                }
+            };
+            load_row(0, 0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int s = k >> 2, r = k & 3;
+                if (k + 1 < 16) load_row(k + 1, (k + 1) & 1);
+                const f32x4 a0 = fa[s & 1][0], a1 = fa[s & 1][1];
+#pragma unroll
+                for (int h = 0; h < DH; ++h) {
+                    const f32x4 w = wb[k & 1][h];
+                    if (ABL & 1) {
+                        asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
+                        continue;
+                    }
+                    if (r < 3) {
+                        float q = acc[0][r][h];
+                        q = fmaf(a0[0], w[0], q); q = fmaf(a0[1], w[1], q);
+                        q = fmaf(a0[2], w[2], q); q = fmaf(a0[3], w[3], q);
+                        acc[0][r][h] = q;
+                    }
+                    if (r >= 1) {
+                        float q = acc[1][r - 1][h];
+                        q = fmaf(a1[0], w[0], q); q = fmaf(a1[1], w[1], q);
+                        q = fmaf(a1[2], w[2], q); q = fmaf(a1[3], w[3], q);
+                        acc[1][r - 1][h] = q;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cur ^= 1;
+        }
+
+        // ---- epilogue: mean over C, leaky-relu, through the stage just consumed (cur ^ 1).
+        // Stage rows are padded to SROW floats (multiple of 4) so the copy-out moves 16-byte
+        // quads: ds_read_b128 -> global_store_dwordx4 (a pixel record = DD floats, contiguous).
+        constexpr int SROW = (DD + 3) & ~3;
+        constexpr int QPP = (DD + 3) / 4;                     // quads per pixel (last may be partial)
+        float* stg = smem + (cur ^ 1) * G::BUF;
+        const float inv_c = 1.0f / (float)a.C;
+        for (int hf = 0; hf < CV_TH / 2; ++hf) {
+            __syncthreads();
+            if (yp == hf) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        const int vi = 3 * vg + v;
+                        if (vi < D) {
+                            float* st = stg + (j * CV_TW + lane) * SROW + vi * D + h0;
+#pragma unroll
+                            for (int h = 0; h < DH; ++h)
+                                if (h0 + h < D) st[h] = pwc_lrelu(acc[j][v][h] * inv_c, a.slope);
+                        }
+                    }
+            }
+            __syncthreads();
+            for (int e = t; e < 128 * QPP; e += T) {
+                const int px = e / QPP, q = e - px * QPP;
+                const int y = y0 + 2 * hf + (px >> 6), x = x0 + (px & 63);
+                if (y < a.H && x < a.W && !(ABL & 4)) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(stg + px * SROW + q * 4);
+                    float* dst = a.out + (((size_t)n * a.H + y) * a.W + x) * a.out_cs + q * 4;
+                    if (a.out_vec4 && q * 4 + 3 < DD) {
+                        *reinterpret_cast<f32x4*>(dst) = v4;
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (q * 4 + u < DD) dst[u] = v4[u];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int R>
+static int cv_launch_dma(const CvArgs& a, hipStream_t s) {
+    using G = CvPGeom<R>;
+    const size_t lds = (size_t)2 * G::BUF * sizeof(float);
+    static bool attr_set = false;   // idempotent, benign if raced
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_volume_dma_kernel<R, 0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long ntiles = (long)a.tiles_x * a.tiles_y * a.N;
+    // one persistent workgroup per CU; smaller LDS footprints (R < 4) may co-reside
+    const int per_cu = (int)((size_t)160 * 1024 / lds);
+    long nwg = 256L * (per_cu < 1 ? 1 : per_cu);
+    if (nwg > ntiles) nwg = ntiles;
+    hipLaunchKernelGGL((cost_volume_dma_kernel<R, 0>), dim3((unsigned)nwg), dim3(G::T), lds, s, a);
+    return pwc_launch_status();
+}
+
 template <int R, bool FUSED>
 static int cv_launch(const CvArgs& a, hipStream_t s) {
-    constexpr int D = 2 * R + 1;
-    constexpr int HH = CV_TH + 2 * R;
-    constexpr int PS1 = ((HH * CV_HW + 24 + 31) / 32) * 32;
-    constexpr int PS0 = ((CV_TH * CV_TW + 24 + 31) / 32) * 32;
-    const size_t lds = (size_t)CV_CK * (PS1 + PS0) * sizeof(float);
+    using G = CvGeom<R>;
+    const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
     static bool attr_set = false;   // idempotent, benign if raced
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_volume_kernel<R, FUSED>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const unsigned nb = (unsigned)(a.tiles_x * a.tiles_y * a.N);
-    hipLaunchKernelGGL((cost_volume_kernel<R, FUSED>), dim3(nb), dim3(64 * D), lds, s, a);
+    hipLaunchKernelGGL((cost_volume_kernel<R, FUSED>), dim3(nb), dim3(G::T), lds, s, a);
     return pwc_launch_status();
 }
 
 static int cv_dispatch(CvArgs& a, int R, bool fused, hipStream_t s) {
     a.tiles_x = (a.W + CV_TW - 1) / CV_TW;
     a.tiles_y = (a.H + CV_TH - 1) / CV_TH;
+    a.out_vec4 = ((a.out_cs & 3) == 0 && pwc_aligned16(a.out)) ? 1 : 0;
     if ((long)a.tiles_x * a.tiles_y * a.N >= (1L << 31)) return PWC_ERANGE;
+    // in-image element offsets are 32-bit in the kernel
+    if ((long)a.H * a.W * a.f0_cs >= (1L << 31) || (long)a.H * a.W * a.f1_cs >= (1L << 31)) return PWC_ERANGE;
 #define PWC_CV(RR)                                                   \
     case RR:                                                         \
-        return fused ? cv_launch<RR, true>(a, s) : cv_launch<RR, false>(a, s);
+        return fused ? cv_launch<RR, true>(a, s) : cv_launch_dma<RR>(a, s);
     switch (R) {
         PWC_CV(1)
         PWC_CV(2)

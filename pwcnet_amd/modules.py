@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .profiler import active as active_timer
 from .profiler import timed
 from .weights import FILTERS_FP, FILTERS_OF, CONTEXT, ChannelLayout
 
@@ -66,6 +67,52 @@ def _same_out(size, stride):
 
 def _p(ptr):
     return _lib.ctypes.c_void_p(ptr)
+
+
+# ---------------------------------------------------------------- launches / launch plans
+class LaunchPlan:
+    """A recorded forward: the exact sequence of C-ABI calls (function + prepared
+    arguments) plus every tensor they touch.  Replaying it costs one ctypes call per
+    kernel -- the Python bookkeeping of the eager path (views, layouts, caches,
+    allocations) runs once per input shape."""
+
+    def __init__(self):
+        self.calls = []      # [fn, args(list), what, kernel name, flops, bytes]
+        self.keep = []       # tensors whose memory the recorded pointers reference
+        self.patch = {}      # input name -> [(call index, arg index)]
+        self.outputs = None
+
+    def replay(self, inputs=None):
+        for name, ptr in (inputs or {}).items():
+            for ci, ai in self.patch.get(name, ()):
+                self.calls[ci][1][ai] = _p(ptr)
+        timer = active_timer()
+        for fn, args, what, kname, flops, nbytes in self.calls:
+            if timer is not None and kname is not None and timer.wants(kname):
+                with timer.launch(kname, flops, nbytes):
+                    rc = fn(*args)
+            else:
+                rc = fn(*args)
+            if rc:
+                _lib.check(rc, what)
+
+
+_RECORDER = None
+
+
+def _launch(fn, args, what, kname=None, flops=0.0, nbytes=0.0):
+    """Enqueue one library call on torch's current stream (timed when an OpTimer is
+    active, recorded when a LaunchPlan is being built)."""
+    with timed(kname, flops, nbytes):
+        rc = fn(*args)
+    _lib.check(rc, what)
+    if _RECORDER is not None:
+        _RECORDER.calls.append([fn, list(args), what, kname, flops, nbytes])
+
+
+def _keep(*tensors):
+    if _RECORDER is not None:
+        _RECORDER.keep.extend(t for t in tensors if t is not None)
 
 
 # ---------------------------------------------------------------- variables
@@ -169,7 +216,7 @@ class _ConvRunner:
         self.store = default_store()
 
     def conv(self, x, cout, y=None, stride=1, dilation=1, slope=0.1, cin_map=None,
-             cin_logical=None, residual=None, tile=-1):
+             cin_logical=None, residual=None, tile=-1, split=0):
         """x: View over the PHYSICAL input channels.  cin_map: physical->logical map (or
         None = identity).  Returns (View y, tensor or None)."""
         name = self.scope + "/conv2d" + ("" if self.k == 0 else f"_{self.k}")
@@ -206,12 +253,14 @@ class _ConvRunner:
                 cache[key] = packed
                 cache[key + ("cm",)] = cm
             flops = 2.0 * x.N * Ho * Wo * 9 * cin * cout     # algorithmic: logical Cin, no padding
-            with timed(_mfma_kernel_name(L, x.N * Ho * Wo, cout, x.C, tile), flops,
-                       4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout)):
-                rc = L.pwc_conv3x3_f32(_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()),
-                                       _p(y.ptr), y.cs, x.N, x.H, x.W, x.C, cout, stride, dilation,
-                                       act, sl, tile, s)
-            _lib.check(rc, f"conv3x3 {name}")
+            ws = _workspace(kern.value.device, L.pwc_conv3x3_workspace_floats(x.N * Ho * Wo, cout))
+            _keep(ws, packed, y_t)
+            _launch(L.pwc_conv3x3_f32,
+                    (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
+                     x.N, x.H, x.W, x.C, cout, stride, dilation, act, sl, tile, split, _p(ws.data_ptr()),
+                     ws.numel(), s),
+                    f"conv3x3 {name}", _mfma_kernel_name(L, x.N * Ho * Wo, cout, x.C, tile, split), flops,
+                    4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout))
         else:
             w = kern.value
             if cin_map is not None:
@@ -227,21 +276,45 @@ class _ConvRunner:
             elif x.C != cin:
                 raise ValueError(f"{name}: input has {x.C} channels, kernel expects {cin}")
             r_ptr, r_cs = (None, 0) if residual is None else (_p(residual.ptr), residual.cs)
-            with timed(f"conv3x3_direct_kernel<cout={cout}>", 2.0 * x.N * Ho * Wo * 9 * cin * cout,
-                       4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout)):
-                rc = L.pwc_conv3x3_direct_f32(_p(x.ptr), x.cs, _p(w.data_ptr()), _p(bias.value.data_ptr()),
-                                              _p(y.ptr), y.cs, r_ptr, r_cs, x.N, x.H, x.W, x.C, cout,
-                                              stride, dilation, act, sl, s)
-            _lib.check(rc, f"conv3x3_direct {name}")
+            _keep(w, y_t)
+            _launch(L.pwc_conv3x3_direct_f32,
+                    (_p(x.ptr), x.cs, _p(w.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs, r_ptr, r_cs,
+                     x.N, x.H, x.W, x.C, cout, stride, dilation, act, sl, s),
+                    f"conv3x3_direct {name}", f"conv3x3_direct_kernel<cout={cout}>",
+                    2.0 * x.N * Ho * Wo * 9 * cin * cout, 4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout))
         return y, y_t
 
 
-def _mfma_kernel_name(L, M, cout, cin_phys, tile):
+_WS = {}
+# tap-split scratch is only ever used for small outputs; cap what is kept around
+_WS_CAP_FLOATS = 64 << 20
+
+
+def _workspace(device, want_floats):
+    """Caller-owned scratch for the conv tap split (grown on demand, one per device)."""
+    want = int(min(want_floats, _WS_CAP_FLOATS))
+    ws = _WS.get(device)
+    if ws is None or ws.numel() < want:
+        ws = torch.empty((max(want, 1 << 20),), dtype=torch.float32, device=device)
+        _WS[device] = ws
+    return ws
+
+
+def _mfma_kernel_name(L, M, cout, cin_phys, tile, split):
+    plan = (_lib.ctypes.c_int * 4)()
     if tile >= 0:
-        return f"conv3x3_mfma_kernel<tile{tile}>"
-    bm, bn, kc = _lib.ctypes.c_int(), _lib.ctypes.c_int(), _lib.ctypes.c_int()
-    L.pwc_conv3x3_select_tile(M, cout, cin_phys, bm, bn, kc)
-    return f"conv3x3_mfma_kernel<{bm.value}x{bn.value},KC{kc.value}>"
+        plan[0], plan[1], plan[3] = tile, -1, max(split, 1)
+    else:
+        L.pwc_conv3x3_plan(M, cout, cin_phys, plan)
+    bm, bn = _lib.ctypes.c_int(), _lib.ctypes.c_int()
+    L.pwc_conv3x3_tile_shape(plan[0], bm, bn)
+    name = f"conv3x3_mfma_kernel<{bm.value}x{bn.value},KC{32 if cin_phys % 32 == 0 else 16}>"
+    if plan[1] >= 0:
+        L.pwc_conv3x3_tile_shape(plan[1], bm, bn)
+        name += f"+tail<{bm.value}x{bn.value}>"
+    if plan[3] > 1:
+        name += f"+split{plan[3]}"
+    return name
 
 
 class _Module:
@@ -254,18 +327,16 @@ def _copy_channels(src, dst, C):
     """dst[..., 0:C] = src[..., 0:C] (both Views over the same pixel grid)."""
     assert (src.N, src.H, src.W) == (dst.N, dst.H, dst.W)
     npix = src.N * src.H * src.W
-    with timed("copy_channels_kernel", 0.0, 8.0 * npix * C):
-        rc = _lib.lib().pwc_copy_channels_f32(_p(src.ptr), src.cs, _p(dst.ptr), dst.cs, npix, C,
-                                              _lib.current_stream())
-    _lib.check(rc, "copy_channels")
+    _launch(_lib.lib().pwc_copy_channels_f32,
+            (_p(src.ptr), src.cs, _p(dst.ptr), dst.cs, npix, C, _lib.current_stream()),
+            "copy_channels", "copy_channels_kernel", 0.0, 8.0 * npix * C)
 
 
 def _resize(src, dst, mul=1.0):
-    with timed("resize_kernel", 0.0, 4.0 * src.C * src.N * (src.H * src.W + dst.H * dst.W)):
-        rc = _lib.lib().pwc_resize_bilinear_f32(_p(src.ptr), src.cs, _p(dst.ptr), dst.cs, src.N, src.H,
-                                                src.W, src.C, dst.H, dst.W, float(mul),
-                                                _lib.current_stream())
-    _lib.check(rc, "resize_bilinear")
+    _launch(_lib.lib().pwc_resize_bilinear_f32,
+            (_p(src.ptr), src.cs, _p(dst.ptr), dst.cs, src.N, src.H, src.W, src.C, dst.H, dst.W, float(mul),
+             _lib.current_stream()),
+            "resize_bilinear", "resize_kernel", 0.0, 4.0 * src.C * src.N * (src.H * src.W + dst.H * dst.W))
 
 
 def resize_bilinear(x, size, mul=1.0):
@@ -303,6 +374,7 @@ class FeaturePyramidExtractor_custom(_Module):
             if l == 0:
                 Ho, Wo = _same_out(v0.H, 2), _same_out(v0.W, 2)
                 y_t = torch.empty((n_tot, Ho, Wo, f), dtype=torch.float32, device=device)
+                _keep(y_t)
                 n_off = 0
                 for iv in image_views:
                     yv = View(y_t.data_ptr() + 4 * n_off * Ho * Wo * f, f, iv.N, Ho, Wo, f)
@@ -336,10 +408,9 @@ class WarpingLayer(_Module):
         assert self.warp in ["nearest", "bilinear"]
         L = _lib.lib()
         fn = L.pwc_warp_bilinear_f32 if self.warp == "bilinear" else L.pwc_warp_nearest_f32
-        with timed(f"warp_kernel<{self.warp}>", 0.0, 4.0 * x.N * x.H * x.W * (2 * x.C + 2)):
-            rc = fn(_p(x.ptr), x.cs, _p(flow.ptr), flow.cs, float(flow_scale), _p(out.ptr), out.cs,
-                    x.N, x.H, x.W, x.C, _lib.current_stream())
-        _lib.check(rc, f"warp_{self.warp}")
+        _launch(fn, (_p(x.ptr), x.cs, _p(flow.ptr), flow.cs, float(flow_scale), _p(out.ptr), out.cs,
+                     x.N, x.H, x.W, x.C, _lib.current_stream()),
+                f"warp_{self.warp}", f"warp_kernel<{self.warp}>", 0.0, 4.0 * x.N * x.H * x.W * (2 * x.C + 2))
 
     def __call__(self, x, flow):
         assert self.warp in ["nearest", "bilinear"]
@@ -369,16 +440,16 @@ class CostVolumeLayer(_Module):
         npix = f0.N * f0.H * f0.W
         flops = 2.0 * npix * D * f0.C
         if flow is None:
-            with timed(f"cost_volume_kernel<R{self.s_range}>", flops, 4.0 * npix * (2 * f0.C + D)):
-                rc = L.pwc_cost_volume_f32(_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(out.ptr), out.cs,
-                                           f0.N, f0.H, f0.W, f0.C, self.s_range, 0.1, s)
+            _launch(L.pwc_cost_volume_f32,
+                    (_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(out.ptr), out.cs, f0.N, f0.H, f0.W, f0.C,
+                     self.s_range, 0.1, s),
+                    "cost_volume", f"cost_volume_dma_kernel<R{self.s_range}>", flops, 4.0 * npix * (2 * f0.C + D))
         else:
-            with timed(f"cost_volume_kernel<R{self.s_range},fused_warp>", flops,
-                       4.0 * npix * (2 * f0.C + 2 + D)):
-                rc = L.pwc_warp_cost_volume_f32(_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(flow.ptr), flow.cs,
-                                                float(flow_scale), _p(out.ptr), out.cs, f0.N, f0.H, f0.W,
-                                                f0.C, self.s_range, 0.1, s)
-        _lib.check(rc, "cost_volume")
+            _launch(L.pwc_warp_cost_volume_f32,
+                    (_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(flow.ptr), flow.cs, float(flow_scale), _p(out.ptr),
+                     out.cs, f0.N, f0.H, f0.W, f0.C, self.s_range, 0.1, s),
+                    "warp_cost_volume", f"cost_volume_kernel<R{self.s_range},fused_warp>", flops,
+                    4.0 * npix * (2 * f0.C + 2 + D))
 
     def __call__(self, features_0, features_0from1):
         f0, features_0 = as_view(features_0, "features_0")

@@ -19,8 +19,14 @@ def active():
 
 
 class OpTimer:
-    def __init__(self):
+    def __init__(self, only=None):
+        """only: optional set of kernel-name prefixes to time (others run un-instrumented:
+        an event pair costs a few microseconds and a pipeline bubble per launch)."""
         self.records = []   # (kernel, flops, bytes, start event, end event)
+        self.only = None if only is None else tuple(only)
+
+    def wants(self, kernel):
+        return self.only is None or kernel.startswith(self.only)
 
     def __enter__(self):
         global _ACTIVE
@@ -60,7 +66,7 @@ class OpTimer:
 @contextlib.contextmanager
 def timed(kernel, flops=0.0, nbytes=0.0):
     t = _ACTIVE
-    if t is None:
+    if t is None or kernel is None or not t.wants(kernel):
         yield
     else:
         with t.launch(kernel, flops, nbytes):

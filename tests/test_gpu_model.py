@@ -150,7 +150,7 @@ def test_e2e_batch_and_features_vs_oracle(pa):
 
 def test_e2e_unfused_warp_and_nearest_variants(pa):
     im0, im1 = util.smooth_images(1, 64, 128, seed=12)
-    net_f, w = make_net(pa, False)
+    net_f, w = make_net(pa, False, fuse_warp=True)
     net_u, _ = make_net(pa, False, fuse_warp=False)
     a, _ = net_f(gpu(im0), gpu(im1))
     b, _ = net_u(gpu(im0), gpu(im1))
@@ -196,3 +196,24 @@ def test_e2e_batch8_matches_single_pair(pa):
     for i in (0, 5, 7):
         f1, _ = net(gpu(im0[i:i + 1]), gpu(im1[i:i + 1]))
         assert float((f8[i:i + 1] - f1).abs().max()) <= 1e-5
+
+
+def test_launch_plan_replay_matches_eager(pa):
+    """the recorded launch plan (replayed from the 2nd call on, inputs patched by pointer)
+    gives bit-identical results to the eager path, for fresh input tensors each call."""
+    net_p, _ = make_net(pa, False)
+    net_e, _ = make_net(pa, False, use_plans=False)
+    for seed in (21, 22, 23):
+        im0, im1 = util.smooth_images(2, 64, 128, seed=seed)
+        a, pyr_a = net_p(gpu(im0), gpu(im1))
+        b, pyr_b = net_e(gpu(im0), gpu(im1))
+        assert torch.equal(a, b)
+        for x, y in zip(pyr_a, pyr_b):
+            assert torch.equal(x, y)
+    assert len(net_p._plans) == 1 and len(net_e._plans) == 0
+    # new weights invalidate the plan
+    w2 = util.model_weights(False, seed=5)
+    net_p.load_weights(w2)
+    net_e.load_weights(w2)
+    im0, im1 = util.smooth_images(2, 64, 128, seed=24)
+    assert torch.equal(net_p(gpu(im0), gpu(im1))[0], net_e(gpu(im0), gpu(im1))[0])

@@ -74,7 +74,7 @@ def test_argument_errors_are_reported_not_crashes(pa):
 
 
 # ------------------------------------------------------------------ conv (MFMA implicit GEMM)
-def run_conv_mfma(x, k, b, stride, dil, slope, tile=-1, cin_map=None, cin_phys=None, y_cs=None):
+def run_conv_mfma(x, k, b, stride, dil, slope, tile=-1, cin_map=None, cin_phys=None, y_cs=None, split=0):
     from pwcnet_amd import _lib
     L = _lib.lib()
     N, H, W, cs = x.shape
@@ -88,9 +88,10 @@ def run_conv_mfma(x, k, b, stride, dil, slope, tile=-1, cin_map=None, cin_phys=N
     Ho, Wo = -(-H // stride), -(-W // stride)
     y_cs = cout if y_cs is None else y_cs
     y = torch.full((N, Ho, Wo, y_cs), -7.0, device="cuda")
+    ws = torch.empty(L.pwc_conv3x3_workspace_floats(N * Ho * Wo, cout), device="cuda")
     _lib.check(L.pwc_conv3x3_f32(_p(xg), cs, _p(packed), _p(bg), _p(y), y_cs, N, H, W, cin_phys, cout,
                                  stride, dil, 0 if slope is None else 1, 0.0 if slope is None else slope,
-                                 tile, None))
+                                 tile, split, _p(ws), ws.numel(), None))
     torch.cuda.synchronize()
     return y
 
@@ -119,6 +120,31 @@ def test_conv_mfma_every_tile_config(pa, tile):
         b = rnd((cout,), 6) * 0.1
         y = run_conv_mfma(x, k, b, 1, 1, 0.1, tile=tile)
         close(y, orc.conv3x3(x, k, b, 1, 1, 0.1))
+
+
+@pytest.mark.parametrize("split", [3, 9])
+@pytest.mark.parametrize("N,H,W,cin,cout,stride,dil", [
+    (2, 7, 16, 192, 192, 1, 1), (1, 14, 32, 256, 128, 1, 1), (1, 28, 64, 96, 64, 1, 1), (1, 9, 13, 64, 32, 2, 1),
+    (1, 20, 24, 128, 96, 1, 4)])
+def test_conv_mfma_tap_split_vs_oracle(pa, split, N, H, W, cin, cout, stride, dil):
+    x = rnd((N, H, W, cin), 51)
+    k = rnd((3, 3, cin, cout), 52) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 53) * 0.1
+    exp = orc.conv3x3(x, k, b, stride, dil, 0.1)
+    y = run_conv_mfma(x, k, b, stride, dil, 0.1, split=split)
+    close(y, exp)
+    y2 = run_conv_mfma(x, k, b, stride, dil, 0.1, split=split, y_cs=cout + 4)
+    close(y2[..., :cout], exp)
+    assert torch.equal(y, run_conv_mfma(x, k, b, stride, dil, 0.1, split=split))     # deterministic
+
+
+def test_conv_mfma_auto_plan_large_m(pa):
+    """large M, pixel count not a multiple of any tile: 76800 = 600 tiles of 128 px."""
+    N, H, W, cin, cout = 1, 240, 320, 32, 128
+    x = rnd((N, H, W, cin), 54)
+    k = rnd((3, 3, cin, cout), 55) * 0.05
+    b = rnd((cout,), 56) * 0.1
+    close(run_conv_mfma(x, k, b, 1, 1, 0.1), orc.conv3x3(x, k, b, 1, 1, 0.1))
 
 
 def test_conv_mfma_physical_layout_padding_and_strided_output(pa):

@@ -29,12 +29,19 @@ def test_library_exports_every_declared_symbol():
     assert L.pwc_error_string(-1).decode().startswith("invalid argument")
     # pure host-side helpers are callable without a GPU
     assert L.pwc_conv3x3_packed_floats(160, 128) == 9 * 160 * 128
-    bm, bn, kc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    assert L.pwc_conv3x3_select_tile(8 * 112 * 256, 128, 160, bm, bn, kc) >= 0
-    assert (bm.value, bn.value, kc.value) == (128, 128, 32)
+    plan = (ctypes.c_int * 4)()
+    assert L.pwc_conv3x3_plan(8 * 112 * 256, 128, 160, plan) == 0
+    bm, bn = ctypes.c_int(), ctypes.c_int()
+    assert L.pwc_conv3x3_tile_shape(plan[0], bm, bn) == 0 and (bm.value, bn.value) == (128, 128)
+    assert plan[1] == -1 and plan[2] == 8 * 112 * 256 and plan[3] == 1
+    # mid-size M: the largest tile that still gives >= 384 workgroups (measured rule)
+    assert L.pwc_conv3x3_plan(8 * 28 * 64, 128, 224, plan) == 0
+    assert L.pwc_conv3x3_tile_shape(plan[0], bm, bn) == 0 and (bm.value, bn.value, plan[3]) == (32, 128, 1)
+    assert L.pwc_conv3x3_plan(8 * 7 * 16, 128, 288, plan) == 0 and plan[3] in (3, 9)   # tiny M: tap split
+    assert L.pwc_conv3x3_workspace_floats(100, 20) == 9 * 100 * 32
     # argument validation happens before any launch
     assert L.pwc_cost_volume_f32(None, 4, None, 4, None, 81, 1, 4, 4, 4, 4, 0.1, None) == -1
-    assert L.pwc_conv3x3_f32(None, 16, None, None, None, 16, 1, 4, 4, 16, 16, 1, 1, 1, 0.1, -1, None) == -1
+    assert L.pwc_conv3x3_f32(None, 16, None, None, None, 16, 1, 4, 4, 16, 16, 1, 1, 1, 0.1, -1, 0, None, 0, None) == -1
 
 
 def test_product_never_imports_the_oracle():
