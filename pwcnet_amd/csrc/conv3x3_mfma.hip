@@ -247,15 +247,15 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
 __device__ float pwc_zero_page[4];
 
 template <int WM, int WN, int WGM, int WGN, int KC>
-__global__ __launch_bounds__(256) void conv3x3_mfma_glds_kernel(const ConvArgs a) {
-    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_mfma_glds_kernel(const ConvArgs a) {
+    constexpr int NWV = WGM * WGN;               // waves per workgroup (4 or 8)
     constexpr int BM = 16 * WM * WGM;
     constexpr int BN = 16 * WN * WGN;
     constexpr int KG = KC / 16;
     constexpr int NBA = (BM / 16) * KG;          // 1-KiB blocks of the activation tile
     constexpr int NBB = (BN / 16) * KG;          // ... of the weight tile
-    constexpr int A_PW = (NBA + 3) / 4;          // blocks per wave
-    constexpr int B_PW = (NBB + 3) / 4;
+    constexpr int A_PW = (NBA + NWV - 1) / NWV;  // blocks per wave
+    constexpr int B_PW = (NBB + NWV - 1) / NWV;
     constexpr int STAGE = (BM + BN) * KC;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_glds_kernel(const ConvArgs a
     const int HoWo = a.Ho * a.Wo;
 #pragma unroll
     for (int i = 0; i < A_PW; ++i) {
-        const int b = wave + 4 * i;
+        const int b = wave + NWV * i;
         const int g = b / (BM / 16), rb = b % (BM / 16);
         const int row = rb * 16 + lrow;
         const int m = m0 + row;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_glds_kernel(const ConvArgs a
     bool b_ok[B_PW];
 #pragma unroll
     for (int i = 0; i < B_PW; ++i) {
-        const int b = wave + 4 * i;
+        const int b = wave + NWV * i;
         const int g = b / (BN / 16), rb = b % (BN / 16);
         const int row = rb * 16 + lrow;
         b_ok[i] = (b < NBB) && (n0 + row < a.Cout_pad);
@@ -315,8 +315,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_glds_kernel(const ConvArgs a
         float* Bb = Ab + BM * KC;
 #pragma unroll
         for (int i = 0; i < A_PW; ++i) {
-            const int b = wave + 4 * i;
-            if (NBA % 4 != 0 && b >= NBA) break;
+            const int b = wave + NWV * i;
+            if (NBA % NWV != 0 && b >= NBA) break;
             const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
             const bool ok = ((unsigned)iy < (unsigned)a.H) && ((unsigned)ix < (unsigned)a.W);
             const float* src = ok ? a_base[i] + (size_t)(iy * a.W + ix) * a.x_cs + cc * KC : zero;
@@ -325,8 +325,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_glds_kernel(const ConvArgs a
         const float* wsrc = a.wp + (size_t)(tap * nc16 + cc * KG) * a.Cout_pad * 16;
 #pragma unroll
         for (int i = 0; i < B_PW; ++i) {
-            const int b = wave + 4 * i;
-            if (NBB % 4 != 0 && b >= NBB) break;
+            const int b = wave + NWV * i;
+            if (NBB % NWV != 0 && b >= NBB) break;
             const float* src = b_ok[i] ? wsrc + b_src[i] : zero;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bb + b * 256), 16, 0, 0);
         }

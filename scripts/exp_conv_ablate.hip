@@ -25,9 +25,11 @@ static float run_glds(const ConvArgs& a, int BM, int BN, int iters) {
     dim3 grid((a.M + BM - 1) / BM, a.Cout_pad / BN, 1);
     hipEvent_t s, e;
     hipEventCreate(&s); hipEventCreate(&e);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv3x3_mfma_glds_kernel<WM, WN, WGM, WGN, KC>), grid, dim3(256), lds, 0, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_glds_kernel<WM, WN, WGM, WGN, KC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv3x3_mfma_glds_kernel<WM, WN, WGM, WGN, KC>), grid, dim3(64 * WGM * WGN), lds, 0, a);
     hipEventRecord(s);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv3x3_mfma_glds_kernel<WM, WN, WGM, WGN, KC>), grid, dim3(256), lds, 0, a);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv3x3_mfma_glds_kernel<WM, WN, WGM, WGN, KC>), grid, dim3(64 * WGM * WGN), lds, 0, a);
     hipEventRecord(e);
     hipEventSynchronize(e);
     float ms = 0; hipEventElapsedTime(&ms, s, e);
@@ -59,17 +61,15 @@ int main() {
     a.taps_per_split = 9; a.ws = nullptr;
     const double gf = 2.0 * a.M * 9.0 * Cin * Cout / 1e9;
     auto rep = [&](const char* nm, float us) { printf("%-34s %8.1f us %7.1f TFLOP/s\n", nm, us, gf / us * 1e3); };
+    a.xcd_remap = 1;
     for (int round = 0; round < 3; ++round) {
-        for (int xr = 0; xr < 2; ++xr) {
-            a.xcd_remap = xr;
-            printf("-- round %d xcd_remap=%d\n", round, xr);
-            rep("128x128 KC32 regstage", run<4, 4, 2, 2, 32, 0>(a, 128, 128, 10));
-            rep("128x128 KC32 GLDS", run_glds<4, 4, 2, 2, 32>(a, 128, 128, 10));
-            rep("64x128 KC32 regstage", run<2, 4, 2, 2, 32, 0>(a, 64, 128, 10));
-            rep("64x128 KC32 GLDS", run_glds<2, 4, 2, 2, 32>(a, 64, 128, 10));
-            rep("128x128 KC16 GLDS", run_glds<4, 4, 2, 2, 16>(a, 128, 128, 10));
-            rep("128x128 mfma+ds_read only", run<4, 4, 2, 2, 32, 3>(a, 128, 128, 10));
-        }
+        printf("-- round %d\n", round);
+        rep("128x128 KC32 GLDS 4 waves", run_glds<4, 4, 2, 2, 32>(a, 128, 128, 10));
+        rep("256x128 KC32 GLDS 8 waves (4x2)", run_glds<4, 4, 4, 2, 32>(a, 256, 128, 10));
+        rep("256x128 KC32 GLDS 8 waves (2x4)", run_glds<8, 2, 2, 4, 32>(a, 256, 128, 10));
+        rep("128x128 KC32 GLDS 8 waves (4x2)", run_glds<2, 4, 4, 2, 32>(a, 128, 128, 10));
+        rep("128x128 KC32 GLDS 8 waves (2x4)", run_glds<4, 2, 2, 4, 32>(a, 128, 128, 10));
+        rep("256x128 KC16 GLDS 8 waves (4x2)", run_glds<4, 4, 4, 2, 16>(a, 256, 128, 10));
     }
     return 0;
 }
