@@ -291,12 +291,14 @@ _WS_CAP_FLOATS = 64 << 20
 
 
 def _workspace(device, want_floats):
-    """Caller-owned scratch for the conv tap split (grown on demand, one per device)."""
+    """Caller-owned scratch for the conv tap split (grown on demand, one per device AND
+    stream: micro-batches running on different streams must not share it)."""
     want = int(min(want_floats, _WS_CAP_FLOATS))
-    ws = _WS.get(device)
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _WS.get(key)
     if ws is None or ws.numel() < want:
         ws = torch.empty((max(want, 1 << 20),), dtype=torch.float32, device=device)
-        _WS[device] = ws
+        _WS[key] = ws
     return ws
 
 
