@@ -115,6 +115,9 @@ size_t pwc_conv3x3_workspace_floats(int M, int Cout);
  * plan4 = {main tile id, tail tile id or -1, pixels covered by the main launch, tap split};
  * pwc_conv3x3_tile_shape gives a tile id's workgroup tile BM x BN. */
 int pwc_conv3x3_plan(int M, int Cout, int Cin_phys, int* plan4);
+/* 1 when pwc_conv3x3_f32(tile = -1, split = 0) routes this shape to the resident-weights /
+ * halo-patch kernel (stride 1, dilation 1, Cin_phys == Cout in {16, 32}, M >= 65536). */
+int pwc_conv3x3_uses_halo_kernel(int M, int Cin_phys, int Cout, int stride, int dilation);
 int pwc_conv3x3_tile_shape(int tile, int* bm, int* bn);
 
 /* Same convolution straight from the HWIO variable, any Cin/Cout, plus the optional

@@ -32,6 +32,7 @@ SIGNATURES = {
     "pwc_conv3x3_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     "pwc_conv3x3_workspace_floats": (_sz, [_i, _i]),
     "pwc_conv3x3_plan": (_i, [_i, _i, _i, ctypes.POINTER(_i)]),
+    "pwc_conv3x3_uses_halo_kernel": (_i, [_i, _i, _i, _i, _i]),
     "pwc_conv3x3_tile_shape": (_i, [_i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "pwc_conv3x3_direct_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_resize_bilinear_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),

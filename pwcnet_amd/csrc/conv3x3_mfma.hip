@@ -415,6 +415,203 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_mfma_glds_kernel(const
     }
 }
 
+// ---------------------------------------------------------------- small-Cin "halo" variant
+// Stride-1, dilation-1 convolutions with few channels (16 -> 16, 32 -> 32: the first
+// full-resolution extractor layers, modules.py:64-67 at l = 0, 1) are HBM-bound: K = 9*Cin is
+// so short that the generic kernel spends its time re-loading the same pixels once per tap
+// and synchronising 9 tiny stages.  Here
+//   * the packed weights of ALL 9 taps stay resident in LDS for the life of the workgroup;
+//   * a workgroup owns a TH x 32 pixel tile and DMA-loads its (TH+2) x 34 input patch ONCE
+//     (global_load_lds, zero page outside the image); the 9 taps are row/column shifts of
+//     the LDS read address;
+//   * workgroups are persistent (the resident weights are loaded once per workgroup); NB = 2
+//     keeps the next tile's patch in flight during the MFMAs, NB = 1 relies on 4 co-resident
+//     workgroups per CU instead -- measured faster (TH = 4, NB = 1: 98-106 TFLOP/s).
+// MFMA/LDS conventions are those of conv3x3_mfma_kernel (same packed weight image, same
+// XOR swizzle of the 16-byte chunks, recomputed per tap for the shifted patch rows).
+struct HaloArgs {
+    const float* x;
+    const float* wp;
+    const float* bias;
+    float* y;
+    int x_cs, y_cs;
+    int N, H, W;
+    int apply_act;
+    float slope;
+    int tiles_x, tiles_y;
+    int y_vec4;
+};
+
+template <int CIN, int COUT, int TH, int NB>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
+    constexpr int KG = CIN / 16;                  // 16-channel groups
+    constexpr int NT = COUT / 16;                 // cout MFMA tiles
+    constexpr int TW = 32;
+    constexpr int PW = TW + 2, PH = TH + 2;
+    constexpr int PR = PH * PW;                   // patch pixels
+    constexpr int PRP = (PR + 15) & ~15;          // padded to whole 16-row DMA blocks
+    constexpr int NBP = (PRP / 16) * KG;          // DMA blocks per patch
+    constexpr int BPW = (NBP + 3) / 4;            // per wave
+    constexpr int WFL = 9 * CIN * COUT;           // resident weight floats
+    constexpr int PFL = KG * PRP * 16;            // floats per patch buffer
+    constexpr int MT = TH * TW / 16 / 4;          // pixel MFMA tiles per wave (16 px each)
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wl = smem;
+    float* pbuf = smem + WFL;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const float* zero = pwc_zero_page;
+
+    // resident weights: linear copy of the packed image [tap][kg][cout][16]
+    for (int i = t * 4; i < WFL; i += 256 * 4)
+        *reinterpret_cast<f32x4*>(wl + i) = *reinterpret_cast<const f32x4*>(a.wp + i);
+
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int ntiles = tiles_per_img * a.N;
+    const int nwg = gridDim.x;
+    const int first = pwc_xcd_remap(blockIdx.x, nwg);
+
+    // tile-independent DMA map: block b = wave + 4*i -> kgroup g, patch rows 16*rb .. +15
+    int blk[BPW];
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+        const int b = wave + 4 * i;
+        int v = -1;
+        if (b < NBP) {
+            const int g = b / (PRP / 16), rb = b - g * (PRP / 16);
+            const int pr = rb * 16 + (lane >> 2);
+            if (pr < PR) {
+                const int py = pr / PW, px = pr - py * PW;
+                const int j = (lane & 3) ^ swz4(pr);          // source chunk for this LDS slot
+                v = (py << 16) | (px << 8) | (g * 16 + j * 4);
+            }
+        }
+        blk[i] = v;
+    }
+    auto issue_patch = [&](int lt, int buf) {
+        const int n = lt / tiles_per_img;
+        const int rem = lt - n * tiles_per_img;
+        const int ty_ = rem / a.tiles_x, tx_ = rem - ty_ * a.tiles_x;
+        const int y0 = ty_ * TH - 1, x0 = tx_ * TW - 1;      // SAME padding: one pixel of halo
+        const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs;
+        float* dst = pbuf + buf * PFL;
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const int b = wave + 4 * i;
+            if (b < NBP) {
+                const int v = blk[i];
+                const int y = y0 + (v >> 16), x = x0 + ((v >> 8) & 0xFF);
+                const bool ok = (v >= 0) && ((unsigned)y < (unsigned)a.H) && ((unsigned)x < (unsigned)a.W);
+                const float* src = ok ? xn + (size_t)(y * a.W + x) * a.x_cs + (v & 0xFF) : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + b * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 b4[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b4[n] = *reinterpret_cast<const f32x4*>(a.bias + n * 16 + fq * 4);
+
+    int cur = 0;
+    if (NB == 2 && first < ntiles) issue_patch(first, 0);
+    for (int lt = first; lt < ntiles; lt += nwg) {
+        if (NB == 1) {
+            __syncthreads();                   // previous tile fully read before the patch is overwritten
+            issue_patch(lt, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // patch `cur` landed; weights visible; previous tile read
+        if (NB == 2 && lt + nwg < ntiles) issue_patch(lt + nwg, cur ^ 1);
+
+        const float* pb = pbuf + cur * PFL;
+        f32x4 acc[NT][MT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = zero4;
+
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ty = tap / 3, tx = tap - ty * 3;
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                f32x4 wf[NT], xf[MT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    wf[n] = *reinterpret_cast<const f32x4*>(wl + ((tap * KG + g) * COUT + n * 16 + fr) * 16 +
+                                                            ((fq ^ swz4(fr)) << 2));
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int pt = wave * MT + m;               // pixel tile: row pt/2, columns 16*(pt&1)..
+                    const int pr = ((pt >> 1) + ty) * PW + (pt & 1) * 16 + fr + tx;
+                    xf[m] = *reinterpret_cast<const f32x4*>(pb + (g * PRP + pr) * 16 + ((fq ^ swz4(pr)) << 2));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][k], xf[m][k], acc[n][m], 0, 0, 0);
+            }
+        }
+
+        // epilogue: bias + leaky-relu, 16-byte NHWC stores
+        const int n_img = lt / tiles_per_img;
+        const int rem = lt - n_img * tiles_per_img;
+        const int ty_ = rem / a.tiles_x, tx_ = rem - ty_ * a.tiles_x;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int pt = wave * MT + m;
+            const int y = ty_ * TH + (pt >> 1), x = tx_ * TW + (pt & 1) * 16 + fr;
+            if (y < a.H && x < a.W) {
+                float* dst = a.y + ((size_t)(n_img * a.H + y) * a.W + x) * a.y_cs + fq * 4;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    f32x4 v = acc[n][m] + b4[n];
+                    if (a.apply_act) {
+                        v[0] = pwc_lrelu(v[0], a.slope); v[1] = pwc_lrelu(v[1], a.slope);
+                        v[2] = pwc_lrelu(v[2], a.slope); v[3] = pwc_lrelu(v[3], a.slope);
+                    }
+                    if (a.y_vec4) *reinterpret_cast<f32x4*>(dst + n * 16) = v;
+                    else { dst[n * 16] = v[0]; dst[n * 16 + 1] = v[1]; dst[n * 16 + 2] = v[2]; dst[n * 16 + 3] = v[3]; }
+                }
+            }
+        }
+        if (NB == 2) cur ^= 1;
+    }
+}
+
+template <int CIN, int COUT, int TH, int NB>
+static int launch_halo(const HaloArgs& a0, hipStream_t s) {
+    HaloArgs a = a0;
+    constexpr int KG = CIN / 16, PW = 34, PH = TH + 2;
+    constexpr int PRP = (PH * PW + 15) & ~15;
+    const size_t lds = ((size_t)9 * CIN * COUT + (size_t)NB * KG * PRP * 16) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<CIN, COUT, TH, NB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    a.tiles_x = (a.W + 31) / 32;
+    a.tiles_y = (a.H + TH - 1) / TH;
+    const long ntiles = (long)a.tiles_x * a.tiles_y * a.N;
+    int per_cu = (int)((size_t)160 * 1024 / lds);
+    if (per_cu > 4) per_cu = 4;
+    long nwg = 256L * (per_cu < 1 ? 1 : per_cu);
+    if (nwg > ntiles) nwg = ntiles;
+    hipLaunchKernelGGL((conv3x3_halo_kernel<CIN, COUT, TH, NB>), dim3((unsigned)nwg), dim3(256), lds, s, a);
+    return pwc_launch_status();
+}
+
 // ---------------------------------------------------------------- weight packing
 // packed[tap][c16][cout_pad][16]: element (j*4+e) of row `co` holds
 // w_hwio[tap][cin_map[c16*16 + ((j ^ swz4(co))*4 + e)]][co]   (0 for padding)
@@ -551,6 +748,10 @@ static ConvPlan plan_conv(int M, int Cout_pad, int Cin_phys, bool allow_split) {
     return p;
 }
 
+extern "C" int pwc_conv3x3_uses_halo_kernel(int M, int Cin_phys, int Cout, int stride, int dilation) {
+    return (stride == 1 && dilation == 1 && Cin_phys == Cout && (Cout == 16 || Cout == 32) && M >= (1 << 16)) ? 1 : 0;
+}
+
 extern "C" int pwc_conv3x3_plan(int M, int Cout, int Cin_phys, int* plan4) {
     if (M <= 0 || Cout <= 0 || Cin_phys <= 0 || !plan4) return PWC_EINVAL;
     const ConvPlan p = plan_conv(M, (Cout + 15) & ~15, Cin_phys, true);
@@ -634,6 +835,16 @@ extern "C" int pwc_conv3x3_f32(const float* x, int x_cs, const float* packed, co
     a.xcd_remap = 1;
     hipStream_t s = (hipStream_t)stream;
 
+    // small-Cin full-resolution layers: resident-weights / halo-patch kernel
+    if (tile < 0 && split == 0 && stride == 1 && dilation == 1 && Cin_phys == Cout && (Cout == 16 || Cout == 32) &&
+        M >= (1L << 16) && (long)N * H * W * x_cs < (1L << 31)) {
+        HaloArgs h;
+        h.x = x; h.wp = packed; h.bias = bias; h.y = y; h.x_cs = x_cs; h.y_cs = y_cs;
+        h.N = N; h.H = H; h.W = W; h.apply_act = apply_act; h.slope = slope; h.y_vec4 = a.y_vec4;
+        h.tiles_x = h.tiles_y = 0;
+        // measured (scripts/exp_halo.hip): 4-row tiles, one patch buffer, 4 workgroups per CU
+        return Cout == 16 ? launch_halo<16, 16, 4, 1>(h, s) : launch_halo<32, 32, 4, 1>(h, s);
+    }
     const bool ws_ok = workspace && pwc_aligned16(workspace);
     ConvPlan p;
     if (tile < 0) {

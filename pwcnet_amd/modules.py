@@ -259,7 +259,10 @@ class _ConvRunner:
                     (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
                      x.N, x.H, x.W, x.C, cout, stride, dilation, act, sl, tile, split, _p(ws.data_ptr()),
                      ws.numel(), s),
-                    f"conv3x3 {name}", _mfma_kernel_name(L, x.N * Ho * Wo, cout, x.C, tile, split), flops,
+                    f"conv3x3 {name}",
+                    (f"conv3x3_halo_kernel<{x.C},{cout}>"
+                     if tile < 0 and split == 0 and L.pwc_conv3x3_uses_halo_kernel(x.N * Ho * Wo, x.C, cout, stride, dilation)
+                     else _mfma_kernel_name(L, x.N * Ho * Wo, cout, x.C, tile, split)), flops,
                     4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout))
         else:
             w = kern.value

@@ -110,6 +110,23 @@ def test_conv_mfma_vs_oracle(pa, N, H, W, cin, cout, stride, dil):
     close(y, orc.conv3x3(x, k, b, stride, dil, 0.1))
 
 
+@pytest.mark.parametrize("N,H,W,c", [(1, 260, 300, 16), (2, 132, 260, 32), (1, 256, 256, 16), (3, 100, 224, 32)])
+def test_conv_halo_kernel_vs_oracle(pa, N, H, W, c):
+    """full-resolution 16->16 / 32->32 layers take the resident-weights halo-patch kernel
+    (M >= 65536); ragged sizes exercise the zero-page halo and the partial tiles."""
+    from pwcnet_amd import _lib
+    assert _lib.lib().pwc_conv3x3_uses_halo_kernel(N * H * W, c, c, 1, 1) == 1
+    x = rnd((N, H, W, c), 61)
+    k = rnd((3, 3, c, c), 62) * float(1.0 / np.sqrt(9 * c))
+    b = rnd((c,), 63) * 0.1
+    exp = orc.conv3x3(x, k, b, 1, 1, 0.1)
+    close(run_conv_mfma(x, k, b, 1, 1, 0.1), exp)
+    close(run_conv_mfma(x, k, b, 1, 1, 0.1, tile=14 if c == 16 else 13), exp)      # generic kernel agrees
+    y = run_conv_mfma(x, k, b, 1, 1, None, y_cs=c + 4)
+    close(y[..., :c], orc.conv3x3(x, k, b, 1, 1, None))
+    assert float(y[..., c:].min()) == -7.0
+
+
 @pytest.mark.parametrize("tile", list(range(15)))
 def test_conv_mfma_every_tile_config(pa, tile):
     bn = [128, 96, 64, 32, 16, 128, 96, 64, 32, 16, 128, 96, 64, 32, 16][tile]
