@@ -710,10 +710,10 @@ struct ConvPlan {
 // Measured on MI355X (scripts/tune_conv.py, all layer shapes of the 8x448x1024 forward):
 // the fastest configuration is the LARGEST tile that still yields >= ~384 workgroups,
 // scanning BN downwards before resorting to the tap split.  Preferred tiles per BN, large
-// BM first (128x96 and 256x32 are never the best: lower occupancy).
+// BM first (256x32 is never the best: lower occupancy), BN >= 64 whenever Cout allows.
 static ConvPlan plan_conv(int M, int Cout_pad, int Cin_phys, bool allow_split) {
     static const int kBN[5] = {128, 96, 64, 32, 16};
-    static const int pref[5][3] = {{0, 5, 10}, {6, 11, -1}, {2, 7, 12}, {8, 13, -1}, {4, 9, 14}};
+    static const int pref[5][3] = {{0, 5, 10}, {1, 6, 11}, {2, 7, 12}, {8, 13, -1}, {4, 9, 14}};
     const long target = 384;
     ConvPlan p;
     p.tail_tile = -1;
@@ -725,6 +725,7 @@ static ConvPlan plan_conv(int M, int Cout_pad, int Cin_phys, bool allow_split) {
     for (int split = 1; split <= max_split; split *= 3) {
         for (int r = 0; r < 5; ++r) {
             if (Cout_pad % kBN[r]) continue;
+            if (kBN[r] < 64 && Cout_pad >= 64) continue;   // narrow tiles re-read the pixels too often
             for (int c = 0; c < 3; ++c) {
                 const int t = pref[r][c];
                 if (t < 0) continue;

@@ -217,3 +217,31 @@ def test_launch_plan_replay_matches_eager(pa):
     net_e.load_weights(w2)
     im0, im1 = util.smooth_images(2, 64, 128, seed=24)
     assert torch.equal(net_p(gpu(im0), gpu(im1))[0], net_e(gpu(im0), gpu(im1))[0])
+
+
+def test_infer_cli_end_to_end(pa, tmp_path):
+    """infer.py (counterpart of reference test.py): PNG pair -> crop to x64 -> /255 -> forward
+    with weights restored from a TF-format bundle -> .flo + colour PNGs; checked against the
+    oracle on the same cropped images."""
+    import subprocess, sys
+    from PIL import Image
+    from pwcnet_amd import ckpt, flow_io
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.RandomState(5)
+    a = (rng.uniform(0, 255, size=(70, 140, 3))).astype(np.uint8)
+    b = np.roll(a, 2, axis=1)
+    Image.fromarray(a).save(tmp_path / "a.png")
+    Image.fromarray(b).save(tmp_path / "b.png")
+    w = util.model_weights(False)
+    ckpt.save_weights(str(tmp_path / "m.ckpt"), w)
+    out = subprocess.run([sys.executable, os.path.join(root, "infer.py"), "--input_images", str(tmp_path / "a.png"),
+                          str(tmp_path / "b.png"), "--resume", str(tmp_path / "m.ckpt"), "--out", str(tmp_path / "o"),
+                          "--time", "--iters", "3"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Inference time" in out.stdout and "Figure saved" in out.stdout
+    flow = flow_io.read_flo(str(tmp_path / "o" / "flow_final.flo"))
+    assert flow.shape == (64, 128, 2)
+    im = np.stack([a[:64, :128], b[:64, :128]]).astype(np.float32) / 255.0
+    e_final, _ = orc.OraclePWCDCNet(w)(im[0:1], im[1:2])
+    assert float(np.abs(flow - e_final[0]).max()) <= 1e-3
+    assert all(os.path.exists(tmp_path / "o" / f"flow_level{l}.png") for l in range(5))

@@ -192,3 +192,35 @@ def test_gather_stats_world2_gloo(tmp_path):
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "GATHER_OK 2.0 10.0" in out.stdout
+
+
+# ------------------------------------------------------------------ flow IO (f2)
+def test_flo_round_trip_and_layout(tmp_path):
+    from pwcnet_amd import flow_io
+    flow = np.random.RandomState(0).normal(size=(5, 7, 2)).astype(np.float32)
+    p = str(tmp_path / "a.flo")
+    flow_io.write_flo(p, flow)
+    raw = open(p, "rb").read()
+    assert len(raw) == 12 + 5 * 7 * 2 * 4
+    assert np.frombuffer(raw[:4], "<f4")[0] == np.float32(202021.25)
+    assert tuple(np.frombuffer(raw[4:12], "<i4")) == (7, 5)             # width first, then height
+    np.testing.assert_array_equal(flow_io.read_flo(p), flow)
+    open(p, "wb").write(b"\x00" * 20)
+    with pytest.raises(ValueError):
+        flow_io.read_flo(p)
+
+
+def test_flow_color_wheel_and_crop():
+    from pwcnet_amd import flow_io
+    wheel = flow_io.color_wheel()
+    assert wheel.shape == (55, 3)
+    assert tuple(wheel[0]) == (255, 0, 0) and tuple(wheel[15]) == (255, 255, 0) and tuple(wheel[21]) == (0, 255, 0)
+    assert tuple(wheel[54]) == (255, 0, 255 - np.floor(255 * 5 / 6))
+    img = flow_io.flow_to_color(np.zeros((4, 6, 2), np.float32))
+    assert img.dtype == np.uint8 and img.shape == (4, 6, 3) and (img == 255).all()     # zero flow is white
+    f = np.zeros((1, 2, 2), np.float32)
+    f[0, 0] = (1, 0)
+    f[0, 1] = (-1, 0)
+    c = flow_io.flow_to_color(f)
+    assert not np.array_equal(c[0, 0], c[0, 1])                                        # opposite directions differ
+    assert flow_io.factor_crop(np.zeros((130, 200, 3))).shape == (128, 192, 3)
