@@ -83,13 +83,13 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const DirectArgs a)
 // HBM-bound head of the extractor (reads 12 B, writes 64 B per output pixel).  Lane =
 // (output pixel, 4-channel quad): consecutive lanes store consecutive 16 bytes, so the
 // NHWC output is written in whole contiguous lines; the 27 x Cout weights sit in LDS.
-template <int CIN>
+template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv3x3_smallcin_kernel(const DirectArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wlds[];   // [27*CIN/3... = 9*CIN][Cout]
-    const int nw = 9 * CIN * a.Cout;
+    const int nw = 9 * CIN * COUT;
     for (int i = threadIdx.x; i < nw; i += blockDim.x) wlds[i] = a.w[i];
     __syncthreads();
-    const int qpp = a.Cout >> 2;
+    constexpr int qpp = COUT >> 2;
     const long total = a.M * qpp;
     const long HoWo = (long)a.Ho * a.Wo;
     for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
@@ -110,11 +110,20 @@ __global__ __launch_bounds__(256) void conv3x3_smallcin_kernel(const DirectArgs 
                 const int ix = ox * a.stride - a.pad_l + tx * a.dil;
                 const bool ok = yok && ((unsigned)ix < (unsigned)a.W);
                 const float* xp = xn + ((size_t)(ok ? iy : 0) * a.W + (ok ? ix : 0)) * a.x_cs;
+                float xv[CIN];
+                if (CIN == 3) {
+                    // one 12-byte load per tap (pixels are 4-byte aligned triples)
+                    struct __attribute__((packed, aligned(4))) f3 { float x, y, z; };
+                    const f3 v = *reinterpret_cast<const f3*>(xp);
+                    xv[0] = ok ? v.x : 0.f; xv[1] = ok ? v.y : 0.f; xv[2] = ok ? v.z : 0.f;
+                } else {
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) xv[ci] = ok ? xp[ci] : 0.f;
+                }
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci) {
-                    const float xv = ok ? xp[ci] : 0.f;
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wlds + ((ty * 3 + tx) * CIN + ci) * a.Cout + cq * 4);
-                    acc += xv * w4;
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wlds + ((ty * 3 + tx) * CIN + ci) * COUT + cq * 4);
+                    acc += xv[ci] * w4;
                 }
             }
         }
@@ -207,11 +216,10 @@ extern "C" int pwc_conv3x3_direct_f32(const float* x, int x_cs, const float* w_h
     const bool vec4 = (Cin % 4 == 0) && (x_cs % 4 == 0) && pwc_aligned16(x);
     const unsigned gx = (unsigned)((a.M + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
-    if (Cin == 3 && Cout % 4 == 0 && Cout <= 64 && !residual && (y_cs & 3) == 0 && pwc_aligned16(y) &&
-        pwc_aligned16(bias)) {
+    if (Cin == 3 && Cout == 16 && !residual && (y_cs & 3) == 0 && pwc_aligned16(y) && pwc_aligned16(bias)) {
         long blocks = (a.M * (Cout >> 2) + 255) / 256;
         if (blocks > 256 * 32) blocks = 256 * 32;
-        hipLaunchKernelGGL(conv3x3_smallcin_kernel<3>, dim3((unsigned)blocks), dim3(256),
+        hipLaunchKernelGGL((conv3x3_smallcin_kernel<3, 16>), dim3((unsigned)blocks), dim3(256),
                            (size_t)27 * Cout * sizeof(float), s, a);
         return pwc_launch_status();
     }
