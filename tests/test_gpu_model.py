@@ -245,3 +245,30 @@ def test_infer_cli_end_to_end(pa, tmp_path):
     e_final, _ = orc.OraclePWCDCNet(w)(im[0:1], im[1:2])
     assert float(np.abs(flow - e_final[0]).max()) <= 1e-3
     assert all(os.path.exists(tmp_path / "o" / f"flow_level{l}.png") for l in range(5))
+
+
+@pytest.mark.parametrize("kw", [dict(search_range=2), dict(output_level=3), dict(output_level=2, search_range=3)])
+def test_e2e_constructor_variants_vs_oracle(pa, kw):
+    """non-default constructor kwargs of reference model.py:75-77: search_range changes the
+    cost-volume depth (and every estimator's Cin), output_level where the context network
+    and the final x2^(6-l) upsampling happen."""
+    from pwcnet_amd import weights as W
+    specs = W.conv_specs(search_range=kw.get("search_range", 4), output_level=kw.get("output_level", 4))
+    w = W.randomize_biases(W.init_weights(specs, seed=2), seed=3)
+    net = pa.PWCDCNet(**kw)
+    net.load_weights(w)
+    im0, im1 = util.smooth_images(1, 128, 128, seed=41)
+    final, pyr = net(gpu(im0), gpu(im1))
+    e_final, e_pyr = orc.OraclePWCDCNet(w, **kw)(im0, im1)
+    assert final.shape == e_final.shape == (1, 128, 128, 2) and len(pyr) == len(e_pyr) == kw.get("output_level", 4) + 1
+    assert float(np.abs(final.cpu().numpy() - e_final).max()) <= 1e-3
+    assert len(net.vars) == 2 * len(specs)
+
+
+def test_sizes_not_multiple_of_64_are_rejected_like_the_reference(pa):
+    """reference test.py:13-17 crops inputs to multiples of 64 because the x2 upsampling of
+    one level must match the next pyramid level (tf.concat would fail otherwise)."""
+    net, _ = make_net(pa, False)
+    im0, im1 = util.images(1, 100, 136)
+    with pytest.raises(AssertionError, match="double in size"):
+        net(gpu(im0), gpu(im1))
