@@ -120,6 +120,23 @@ int pwc_conv3x3_plan(int M, int Cout, int Cin_phys, int* plan4);
 int pwc_conv3x3_uses_halo_kernel(int M, int Cin_phys, int Cout, int stride, int dilation);
 int pwc_conv3x3_tile_shape(int tile, int* bm, int* bn);
 
+/* Winograd F(2x2,3x3) form of the same convolution for stride 1 and Cout % 32 == 0:
+ * 2.25x fewer multiplies (16 per 2x2 outputs instead of 36), fp32 result within ~1e-6
+ * relative of the direct sum.  A dilation-d convolution is run as d*d ordinary ones on the
+ * pixel sub-lattices (y mod d, x mod d).  pwc_conv3x3_wino_workgroups gives the number of
+ * 16x16-pixel x 32-channel workgroups a launch would have (the caller's profitability test:
+ * small or sparsely filled launches are faster on pwc_conv3x3_f32).  `packed_u` holds the transformed weights
+ * U = G g G^T produced by pwc_conv3x3_wino_pack_f32 (same cin_map semantics as
+ * pwc_conv3x3_pack_f32; pwc_conv3x3_wino_packed_floats floats).  Other requirements as
+ * pwc_conv3x3_f32. */
+size_t pwc_conv3x3_wino_packed_floats(int Cin_phys, int Cout);
+int pwc_conv3x3_wino_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin, int Cin_phys,
+                              int Cout, float* packed_u, pwc_stream_t stream);
+int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packed_u, const float* bias,
+                         float* y, int y_cs, int N, int H, int W, int Cin_phys, int Cout,
+                         int dilation, int apply_act, float slope, pwc_stream_t stream);
+long pwc_conv3x3_wino_workgroups(int N, int H, int W, int Cout, int dilation);
+
 /* Same convolution straight from the HWIO variable, any Cin/Cout, plus the optional
  * residual add of modules.py:275-277 (`flows += flows_up_prev`) and modules.py:326
  * (`flows + x`): y = act(conv) + residual.  Used for Cin = 3 (first extractor layer),

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (loads libamdhip64 before libpwc_hip.so)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libpwc_hip.so")
-SOURCES = ["conv3x3_mfma.hip", "conv3x3_direct.hip", "cost_volume.hip", "pwc_ops.hip"]
+SOURCES = ["conv3x3_mfma.hip", "conv3x3_wino.hip", "conv3x3_direct.hip", "cost_volume.hip", "pwc_ops.hip"]
 HEADERS = ["pwc_common.h", os.path.join("..", "..", "include", "pwc_hip.h")]
 
 _vp, _i, _f, _l, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long, ctypes.c_size_t
@@ -34,6 +34,10 @@ SIGNATURES = {
     "pwc_conv3x3_plan": (_i, [_i, _i, _i, ctypes.POINTER(_i)]),
     "pwc_conv3x3_uses_halo_kernel": (_i, [_i, _i, _i, _i, _i]),
     "pwc_conv3x3_tile_shape": (_i, [_i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "pwc_conv3x3_wino_packed_floats": (_sz, [_i, _i]),
+    "pwc_conv3x3_wino_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "pwc_conv3x3_wino_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "pwc_conv3x3_wino_workgroups": (_l, [_i, _i, _i, _i, _i]),
     "pwc_conv3x3_direct_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_resize_bilinear_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_copy_channels_f32": (_i, [_vp, _i, _vp, _i, _l, _i, _vp]),

@@ -1,0 +1,301 @@
+// conv3x3_wino.hip -- 3x3 stride-1 dilation-1 'SAME' convolution by Winograd F(2x2, 3x3)
+// on the fp32 MFMA units of gfx950.
+//
+// Replaces the same tf.layers.Conv2D(...,(3,3),(1,1),'same') + tf.nn.leaky_relu calls as
+// conv3x3_mfma.hip (reference modules.py:64-67, 267-268, 306-307, 322-323) wherever
+// stride = dilation = 1 and Cout % 32 == 0: 16 multiplies per 2x2 outputs instead of 36,
+// i.e. 2.25x fewer MFMA instructions for the same result (fp32 error ~1e-7 relative).
+//
+//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A      per 4x4 input tile d, 2x2 output Y
+//
+// GEMM view: 16 independent products  M_xi[cout][tile] = sum_c U_xi[cout][c] * V_xi[c][tile],
+// xi = (a,b) the position in the 4x4 transformed tile.
+//
+// Work decomposition (256 threads = 4 waves):
+//   workgroup = 8 x 8 Winograd tiles (16 x 16 output pixels) x 32 output channels;
+//   wave w    = tile rows 2w, 2w+1 (16 tiles = one MFMA column block), ALL 16 positions xi
+//               and both 16-cout MFMA tiles: 16 x 2 accumulator tiles = 128 registers;
+//   lane      = (tile j = lane & 15, k-slot q = lane >> 4): it reads the 4x4 input pixels of
+//               its tile for channels 4q..4q+3 (16 ds_read_b128 from the raw patch), does the
+//               input transform B^T d B IN REGISTERS -- the result is exactly the MFMA
+//               B-operand fragment V_xi[k = 4q+s][tile j] -- and, at the end, holds all 16
+//               M_xi of its (4 couts x 1 tile) outputs, so the output transform A^T M A is
+//               register-local too.  No transformed data ever goes through LDS.
+//   LDS per 16-channel stage: the raw 18 x 18 pixel patch (64-byte rows, XOR-swizzled) and
+//   the transformed weights U[xi][32 cout][16 ch] (pre-swizzled by the packer), both filled
+//   by global_load_lds_dwordx4; out-of-image pixels read a zero page (SAME padding).
+#include "pwc_common.h"
+
+struct WinoArgs {
+    const float* x;
+    const float* up;     // packed transformed weights [xi 16][c16][Cout_pad][16], chunk-swizzled
+    const float* bias;
+    float* y;
+    int x_cs, y_cs;
+    int N, H, W;
+    int Cin_phys, Cout;
+    int apply_act;
+    float slope;
+    int tiles_x, tiles_y, ncb;   // 16x16-pixel blocks per (sub-)image, cout blocks of 32
+    int y_vec4;
+    int dil;                     // dilation d: the conv splits into d*d ordinary convs on the pixel sub-lattices
+};
+
+__device__ float wino_zero_page[4];
+
+__device__ __forceinline__ int wswz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+
+constexpr int WN_BN = 32;                 // output channels per workgroup
+constexpr int WN_PW = 18;                 // patch width/height (8 tiles * 2 + 2)
+constexpr int WN_PR = WN_PW * WN_PW;      // 324 patch pixels
+constexpr int WN_PRP = 336;               // padded to 21 DMA blocks of 16 rows
+constexpr int WN_UROWS = 16 * WN_BN;      // 512 weight rows (xi, cout) per stage
+constexpr int WN_NBP = WN_PRP / 16;       // 21
+constexpr int WN_NBU = WN_UROWS / 16;     // 32
+constexpr int WN_STAGE = (WN_PRP + WN_UROWS) * 16;   // floats per LDS stage (54 272 B)
+
+template <int NSTG>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const float* zero = wino_zero_page;
+
+    // block decode: cout block fastest, XCD-aware (the cout blocks of one pixel block share
+    // their input patch in one XCD's L2)
+    const int nblk = gridDim.x;
+    const int lb = pwc_xcd_remap(blockIdx.x, nblk);
+    const int cb = lb % a.ncb;
+    int rest = lb / a.ncb;
+    const int bx = rest % a.tiles_x;
+    rest /= a.tiles_x;
+    const int by = rest % a.tiles_y;
+    rest /= a.tiles_y;
+    const int d = a.dil;
+    const int sub = rest % (d * d);                // sub-lattice (y mod d, x mod d) of a dilated conv
+    const int n = rest / (d * d);
+    const int ry = sub / d, rx = sub - ry * d;
+    const int y0 = by * 16, x0 = bx * 16;          // output origin of the block, in sub-lattice coordinates
+    const int n0 = cb * WN_BN;
+    const int Cout_pad = (a.Cout + 15) & ~15;
+    const int nc16 = a.Cin_phys >> 4;
+    const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs;
+
+    // ---- DMA bookkeeping (fixed over the channel loop): block b = wave + 4*i
+    constexpr int NB = WN_NBP + WN_NBU;            // 53 blocks per stage
+    constexpr int BPW = (NB + 3) / 4;              // 14 per wave
+    int d_off[BPW];                                // patch: element offset in the image (-1: zeros); U: row offset
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+        const int b = wave + 4 * i;
+        int v = -1;
+        if (b < WN_NBP) {
+            const int pr = b * 16 + (lane >> 2);
+            if (pr < WN_PR) {
+                const int py = pr / WN_PW, px = pr - py * WN_PW;
+                const int y = ry + d * (y0 - 1 + py), x = rx + d * (x0 - 1 + px);
+                const int j = (lane & 3) ^ wswz(pr);               // source chunk for this LDS slot
+                if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) v = (y * a.W + x) * a.x_cs + j * 4;
+            }
+        } else if (b < NB) {
+            const int ur = (b - WN_NBP) * 16 + (lane >> 2);        // (xi, cout) row of the stage
+            const int xi = ur / WN_BN, co = ur - xi * WN_BN;
+            v = (n0 + co < Cout_pad) ? ((xi * nc16) * Cout_pad + n0 + co) * 16 + (lane & 3) * 4 : -1;
+        }
+        d_off[i] = v;
+    }
+    auto issue_stage = [&](int c16, int buf) {
+        float* dst = smem + buf * WN_STAGE;
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const int b = wave + 4 * i;
+            if (b < NB) {
+                const float* src = zero;
+                if (d_off[i] >= 0)
+                    src = (b < WN_NBP) ? xn + d_off[i] + c16 * 16 : a.up + d_off[i] + (size_t)c16 * Cout_pad * 16;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + b * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- this lane's tile and its 16 patch read offsets (floats, swizzled for k-slot fq)
+    const int tr = 2 * wave + (fr >> 3), tc = fr & 7;
+    int poff[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (2 * tr + i) * WN_PW + 2 * tc + j;
+            poff[i][j] = row * 16 + ((fq ^ wswz(row)) << 2);
+        }
+    const int u_off = WN_PRP * 16 + fr * 16 + ((fq ^ wswz(fr)) << 2);   // A-fragment row fr of a 16-row tile
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+        acc[xi][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[xi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    int cur = 0;
+    if (NSTG == 2) issue_stage(0, 0);
+    for (int c16 = 0; c16 < nc16; ++c16) {
+        if (NSTG == 1) {
+            __syncthreads();                         // previous stage fully read
+            issue_stage(c16, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (NSTG == 2 && c16 + 1 < nc16) issue_stage(c16 + 1, cur ^ 1);
+        const float* sb = smem + cur * WN_STAGE;
+
+        // ---- input transform  V = B^T d B  (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]), in place
+        f32x4 v[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = *reinterpret_cast<const f32x4*>(sb + poff[i][j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                // rows
+            const f32x4 d0 = v[0][j], d1 = v[1][j], d2 = v[2][j], d3 = v[3][j];
+            v[0][j] = d0 - d2; v[1][j] = d1 + d2; v[2][j] = d2 - d1; v[3][j] = d1 - d3;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                // columns
+            const f32x4 e0 = v[i][0], e1 = v[i][1], e2 = v[i][2], e3 = v[i][3];
+            v[i][0] = e0 - e2; v[i][1] = e1 + e2; v[i][2] = e2 - e1; v[i][3] = e1 - e3;
+        }
+        // ---- 16 positions x 2 cout tiles x 4 k-steps of MFMA
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(sb + u_off + (xi * WN_BN) * 16);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(sb + u_off + (xi * WN_BN + 16) * 16);
+            const f32x4 b = v[xi >> 2][xi & 3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[k], b[k], acc[xi][0], 0, 0, 0);
+                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[k], b[k], acc[xi][1], 0, 0, 0);
+            }
+        }
+        if (NSTG == 2) cur ^= 1;
+    }
+
+    // ---- output transform  Y = A^T M A  (A^T = [1 1 1 0; 0 1 -1 -1]), bias, leaky-relu, stores
+    const int oy = y0 + 2 * tr, ox = x0 + 2 * tc;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int co = n0 + nt * 16 + fq * 4;
+        if (co >= a.Cout) continue;
+        f32x4 s[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[0][j] = acc[0 * 4 + j][nt] + acc[1 * 4 + j][nt] + acc[2 * 4 + j][nt];
+            s[1][j] = acc[1 * 4 + j][nt] - acc[2 * 4 + j][nt] - acc[3 * 4 + j][nt];
+        }
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 yv = (j == 0) ? s[i][0] + s[i][1] + s[i][2] : s[i][1] - s[i][2] - s[i][3];
+                yv += b4;
+                if (a.apply_act) {
+                    yv[0] = pwc_lrelu(yv[0], a.slope); yv[1] = pwc_lrelu(yv[1], a.slope);
+                    yv[2] = pwc_lrelu(yv[2], a.slope); yv[3] = pwc_lrelu(yv[3], a.slope);
+                }
+                const int py = ry + d * (oy + i), px = rx + d * (ox + j);
+                if (py < a.H && px < a.W) {
+                    float* dst = a.y + ((size_t)(n * a.H + py) * a.W + px) * a.y_cs + co;
+                    if (a.y_vec4) *reinterpret_cast<f32x4*>(dst) = yv;
+                    else { dst[0] = yv[0]; dst[1] = yv[1]; dst[2] = yv[2]; dst[3] = yv[3]; }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- weight transform + packing
+// packed[xi][c16][cout_pad][16]: U_xi = (G g G^T)[a][b], xi = 4a + b, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],
+// chunk-swizzled like the direct kernel's image; cin_map as in pwc_conv3x3_pack_f32.
+__global__ void conv3x3_wino_pack_kernel(const float* __restrict__ w, const int32_t* __restrict__ cin_map, int Cin,
+                                         int Cin_phys, int Cout, int Cout_pad, float* __restrict__ packed) {
+    const size_t total = (size_t)16 * Cin_phys * Cout_pad;
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int e16 = (int)(idx & 15);
+        size_t r = idx >> 4;
+        const int co = (int)(r % Cout_pad);
+        r /= Cout_pad;
+        const int c16 = (int)(r % (Cin_phys >> 4));
+        const int xi = (int)(r / (Cin_phys >> 4));
+        const int jpos = e16 >> 2, e = e16 & 3;
+        const int j = jpos ^ wswz(co);
+        const int cphys = c16 * 16 + j * 4 + e;
+        const int clog = cin_map ? cin_map[cphys] : (cphys < Cin ? cphys : -1);
+        float u = 0.f;
+        if (clog >= 0 && clog < Cin && co < Cout) {
+            const int ua = xi >> 2, ub = xi & 3;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    u += G[ua][p] * G[ub][q] * w[((size_t)(p * 3 + q) * Cin + clog) * Cout + co];
+        }
+        packed[idx] = u;
+    }
+}
+
+extern "C" size_t pwc_conv3x3_wino_packed_floats(int Cin_phys, int Cout) {
+    if (Cin_phys <= 0 || Cout <= 0) return 0;
+    return (size_t)16 * Cin_phys * ((Cout + 15) & ~15);
+}
+
+extern "C" int pwc_conv3x3_wino_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin, int Cin_phys,
+                                         int Cout, float* packed, pwc_stream_t stream) {
+    if (!w_hwio || !packed || Cin <= 0 || Cout <= 0 || Cin_phys < Cin) return PWC_EINVAL;
+    if (Cin_phys % 16) return PWC_EALIGN;
+    const int Cout_pad = (Cout + 15) & ~15;
+    const size_t total = (size_t)16 * Cin_phys * Cout_pad;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv3x3_wino_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, cin_map,
+                       Cin, Cin_phys, Cout, Cout_pad, packed);
+    return pwc_launch_status();
+}
+
+extern "C" long pwc_conv3x3_wino_workgroups(int N, int H, int W, int Cout, int dilation) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || dilation < 1 || Cout % WN_BN) return 0;
+    const long tx = ((W + dilation - 1) / dilation + 15) / 16, ty = ((H + dilation - 1) / dilation + 15) / 16;
+    return (long)N * dilation * dilation * tx * ty * (Cout / WN_BN);
+}
+
+extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packed_u, const float* bias, float* y,
+                                    int y_cs, int N, int H, int W, int Cin_phys, int Cout, int dilation,
+                                    int apply_act, float slope, pwc_stream_t stream) {
+    if (!x || !packed_u || !bias || !y) return PWC_EINVAL;
+    if (N <= 0 || H <= 0 || W <= 0 || Cin_phys <= 0 || Cout <= 0 || dilation < 1) return PWC_EINVAL;
+    if (Cin_phys % 16 || Cout % 32) return PWC_EUNSUPPORTED;
+    if (x_cs < Cin_phys || y_cs < Cout) return PWC_EINVAL;
+    if ((x_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(packed_u) || !pwc_aligned16(bias)) return PWC_EALIGN;
+    if ((long)H * W * x_cs >= (1L << 31)) return PWC_ERANGE;
+    WinoArgs a;
+    a.x = x; a.up = packed_u; a.bias = bias; a.y = y; a.x_cs = x_cs; a.y_cs = y_cs;
+    a.N = N; a.H = H; a.W = W; a.Cin_phys = Cin_phys; a.Cout = Cout;
+    a.apply_act = apply_act; a.slope = slope;
+    a.dil = dilation;
+    a.tiles_x = ((W + dilation - 1) / dilation + 15) / 16;
+    a.tiles_y = ((H + dilation - 1) / dilation + 15) / 16;
+    a.ncb = Cout / WN_BN;
+    a.y_vec4 = ((y_cs & 3) == 0 && pwc_aligned16(y)) ? 1 : 0;
+    const long nblk = (long)N * dilation * dilation * a.tiles_x * a.tiles_y * a.ncb;
+    if (nblk >= (1L << 31)) return PWC_ERANGE;
+    const size_t lds = (size_t)WN_STAGE * sizeof(float);
+    hipLaunchKernelGGL(conv3x3_wino_kernel<1>, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
+    return pwc_launch_status();
+}

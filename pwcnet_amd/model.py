@@ -26,7 +26,7 @@ from .weights import ChannelLayout, SCALES
 
 class PWCDCNet(object):
     def __init__(self, num_levels=6, search_range=4, warp_type="bilinear", use_dc=False,
-                 output_level=4, name="pwcdcnet", seed=0, fuse_warp=False, use_plans=True):
+                 output_level=4, name="pwcdcnet", seed=0, fuse_warp=False, use_plans=True, winograd=True):
         self.num_levels = num_levels
         self.s_range = search_range
         self.warp_type = warp_type
@@ -45,6 +45,8 @@ class PWCDCNet(object):
         # Upscale factors from deep -> shallow level (reference model.py:93)
         self.scales = list(SCALES)
 
+        for mod in [self.fp_extractor, self.context] + self.of_estimators:
+            mod.winograd = bool(winograd)
         _lib.lib()  # fail now, loudly, if the HIP library is missing
         self.store = VariableStore(seed=seed)
         self._buffers = {}

@@ -237,7 +237,29 @@ class _ConvRunner:
         use_mfma = (cout % 16 == 0 and x.C % 16 == 0 and x.cs % 4 == 0 and x.ptr % 16 == 0
                     and residual is None)
         cache = self.owner._cache
-        if use_mfma:
+        use_wino = (use_mfma and getattr(self.owner, "winograd", False) and stride == 1 and cout % 32 == 0
+                    and tile < 0 and split == 0 and _wino_pays(L, x.N, x.H, x.W, cout, dilation))
+        if use_wino:
+            key = (name, "wino", x.C, None if cin_map is None else cin_map.tobytes(), self.store.version)
+            packed = cache.get(key)
+            if packed is None:
+                nfl = L.pwc_conv3x3_wino_packed_floats(x.C, cout)
+                packed = torch.empty((nfl,), dtype=torch.float32, device=kern.value.device)
+                cm = None
+                if cin_map is not None:
+                    assert len(cin_map) == x.C
+                    cm = torch.from_numpy(np.ascontiguousarray(cin_map, np.int32)).to(kern.value.device)
+                _lib.check(L.pwc_conv3x3_wino_pack_f32(_p(kern.value.data_ptr()),
+                                                       _p(cm.data_ptr()) if cm is not None else None,
+                                                       cin, x.C, cout, _p(packed.data_ptr()), s), "conv3x3 wino pack")
+                cache[key] = packed
+            _keep(packed, y_t)
+            _launch(L.pwc_conv3x3_wino_f32,
+                    (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
+                     x.N, x.H, x.W, x.C, cout, dilation, act, sl, s),
+                    f"conv3x3_wino {name}", "conv3x3_wino_kernel",
+                    2.0 * x.N * Ho * Wo * 9 * cin * cout, 4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout))
+        elif use_mfma:
             key = (name, "mfma", x.C, None if cin_map is None else cin_map.tobytes(), self.store.version)
             packed = cache.get(key)
             if packed is None:
@@ -305,6 +327,15 @@ def _workspace(device, want_floats):
     return ws
 
 
+def _wino_pays(L, N, H, W, cout, dilation):
+    """Measured on MI355X (scripts/tune_conv.py --wino): the Winograd kernel wins (1.4-1.8x)
+    once a launch has >= ~128 workgroups of 16x16 pixels x 32 channels and its 16x16 blocks
+    are reasonably filled; a dilation-d launch works on (H/d) x (W/d) sub-lattices."""
+    hs, wsub = -(-H // dilation), -(-W // dilation)
+    fill = (hs * wsub) / float((-(-hs // 16) * 16) * (-(-wsub // 16) * 16))
+    return L.pwc_conv3x3_wino_workgroups(N, H, W, cout, dilation) >= 128 and fill >= 0.6
+
+
 def _mfma_kernel_name(L, M, cout, cin_phys, tile, split):
     plan = (_lib.ctypes.c_int * 4)()
     if tile >= 0:
@@ -323,6 +354,8 @@ def _mfma_kernel_name(L, M, cout, cin_phys, tile, split):
 
 
 class _Module:
+    winograd = False     # route eligible convs (stride 1, dilation 1, Cout % 32 == 0) to the Winograd kernel
+
     def __init__(self, name):
         self.name = name
         self._cache = {}

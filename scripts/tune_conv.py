@@ -66,7 +66,45 @@ def time_conv(x, packed, bias, y, ws, N, H, W, cin_phys, cout, stride, dil, tile
     return s.elapsed_time(e) / iters * 1e3   # us
 
 
+def time_wino(x, packed_u, bias, y, N, H, W, cin_phys, cout, dil=1, iters=5):
+    def run():
+        return L.pwc_conv3x3_wino_f32(p(x), cin_phys, p(packed_u), p(bias), p(y), cout, N, H, W, cin_phys, cout, dil, 1, 0.1, None)
+    if run() != 0:
+        return None
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        run()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+def wino_main():
+    tot_a = tot_w = tot_best = 0.0
+    ws = torch.empty(64 << 20, device="cuda")
+    print(f"{'layer':9s} {'M':>8s} {'cin':>4s} {'cout':>4s} {'GF':>6s} | {'auto us':>8s} {'TF':>6s} | {'wino us':>8s} {'eff TF':>7s} speedup")
+    for tag, N, H, W, cp, cl, co, st, dl in layers():
+        if st != 1 or co % 32:
+            continue
+        M = N * H * W
+        x = torch.rand((N, H, W, cp), device="cuda") - 0.5
+        packed = torch.rand((L.pwc_conv3x3_packed_floats(cp, co),), device="cuda") - 0.5
+        pu = torch.rand((L.pwc_conv3x3_wino_packed_floats(cp, co),), device="cuda") - 0.5
+        bias = torch.zeros(co, device="cuda")
+        y = torch.empty((N, H, W, co), device="cuda")
+        gf = 2.0 * M * 9 * cl * co / 1e9
+        ta = min(time_conv(x, packed, bias, y, ws, N, H, W, cp, co, 1, dl, -1, 0) for _ in range(2))
+        tw = min(time_wino(x, pu, bias, y, N, H, W, cp, co, dl) for _ in range(2))
+        tot_a += ta; tot_w += tw; tot_best += min(ta, tw)
+        print(f"{tag:9s} {M:8d} {cp:4d} {co:4d} {gf:6.2f} | {ta:8.1f} {gf / ta * 1e3:6.1f} | {tw:8.1f} {gf / tw * 1e3:7.1f} {ta / tw:5.2f}x")
+    print(f"TOTAL eligible layers: auto {tot_a:.0f} us, winograd {tot_w:.0f} us, per-layer best {tot_best:.0f} us")
+
+
 def main():
+    if "--wino" in sys.argv:
+        return wino_main()
     quick = "--quick" in sys.argv
     torch.manual_seed(0)
     ws = torch.empty(64 << 20, device="cuda")

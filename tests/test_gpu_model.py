@@ -272,3 +272,16 @@ def test_sizes_not_multiple_of_64_are_rejected_like_the_reference(pa):
     im0, im1 = util.images(1, 100, 136)
     with pytest.raises(AssertionError, match="double in size"):
         net(gpu(im0), gpu(im1))
+
+
+def test_winograd_and_direct_convs_agree_end_to_end(pa):
+    """PWCDCNet routes its stride-1 convs to the Winograd kernel by default; the direct
+    implicit-GEMM path (winograd=False) must give the same flow within fp32 noise."""
+    net_w, w = make_net(pa, False)
+    net_d, _ = make_net(pa, False, winograd=False)
+    im0, im1 = util.smooth_images(2, 192, 256, seed=51, shift=(3, 1))
+    a, pyr_a = net_w(gpu(im0), gpu(im1))
+    b, pyr_b = net_d(gpu(im0), gpu(im1))
+    assert float((a - b).abs().max()) <= 2e-4
+    e, _ = orc.OraclePWCDCNet(w)(im0, im1)
+    assert float(np.abs(a.cpu().numpy() - e).max()) <= 1e-3 and float(np.abs(b.cpu().numpy() - e).max()) <= 1e-3

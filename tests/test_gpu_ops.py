@@ -127,6 +127,58 @@ def test_conv_halo_kernel_vs_oracle(pa, N, H, W, c):
     assert float(y[..., c:].min()) == -7.0
 
 
+def run_conv_wino(x, k, b, slope, cin_map=None, y_cs=None, dil=1):
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    N, H, W, cs = x.shape
+    cin, cout = k.shape[2], k.shape[3]
+    xg, kg, bg = gpu(x), gpu(k), gpu(b)
+    packed = torch.empty(L.pwc_conv3x3_wino_packed_floats(cs, cout), device="cuda")
+    cm = None if cin_map is None else torch.from_numpy(np.asarray(cin_map, np.int32)).cuda()
+    _lib.check(L.pwc_conv3x3_wino_pack_f32(_p(kg), _p(cm) if cm is not None else None, cin, cs, cout, _p(packed), None))
+    y_cs = cout if y_cs is None else y_cs
+    y = torch.full((N, H, W, y_cs), -7.0, device="cuda")
+    _lib.check(L.pwc_conv3x3_wino_f32(_p(xg), cs, _p(packed), _p(bg), _p(y), y_cs, N, H, W, cs, cout, dil,
+                                      0 if slope is None else 1, 0.0 if slope is None else slope, None))
+    torch.cuda.synchronize()
+    return y
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout", [
+    (2, 16, 16, 16, 32), (1, 32, 48, 32, 64), (2, 7, 16, 192, 192), (1, 14, 32, 128, 96), (1, 28, 64, 96, 64),
+    (1, 33, 21, 64, 32), (1, 5, 3, 16, 32), (2, 56, 128, 160, 128)])
+def test_conv_winograd_vs_oracle(pa, N, H, W, cin, cout):
+    x = rnd((N, H, W, cin), 71)
+    k = rnd((3, 3, cin, cout), 72) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 73) * 0.1
+    close(run_conv_wino(x, k, b, 0.1), orc.conv3x3(x, k, b, 1, 1, 0.1), rel=2e-5)
+    y = run_conv_wino(x, k, b, None, y_cs=cout + 8)
+    close(y[..., :cout], orc.conv3x3(x, k, b, 1, 1, None), rel=2e-5)
+    assert float(y[..., cout:].min()) == -7.0
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,dil", [
+    (1, 40, 48, 128, 128, 2), (1, 40, 48, 128, 96, 4), (1, 56, 64, 64, 32, 8), (2, 19, 23, 32, 64, 3),
+    (1, 33, 47, 16, 32, 16)])
+def test_conv_winograd_dilated_vs_oracle(pa, N, H, W, cin, cout, dil):
+    x = rnd((N, H, W, cin), 77)
+    k = rnd((3, 3, cin, cout), 78) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 79) * 0.1
+    close(run_conv_wino(x, k, b, 0.1, dil=dil), orc.conv3x3(x, k, b, 1, dil, 0.1), rel=2e-5)
+
+
+def test_conv_winograd_physical_layout(pa):
+    from pwcnet_amd.weights import estimator_layout
+    lay = estimator_layout(4, False)
+    xl = rnd((1, 20, 24, lay.n_logical), 74)
+    p2l = np.asarray(lay.phys2log)
+    xp = np.zeros((1, 20, 24, lay.n_phys), np.float32)
+    xp[..., p2l >= 0] = xl[..., p2l[p2l >= 0]]
+    k = rnd((3, 3, 147, 128), 75) * 0.03
+    b = rnd((128,), 76) * 0.1
+    close(run_conv_wino(xp, k, b, 0.1, cin_map=lay.cin_map()), orc.conv3x3(xl, k, b, 1, 1, 0.1), rel=2e-5)
+
+
 @pytest.mark.parametrize("tile", list(range(15)))
 def test_conv_mfma_every_tile_config(pa, tile):
     bn = [128, 96, 64, 32, 16, 128, 96, 64, 32, 16, 128, 96, 64, 32, 16][tile]
