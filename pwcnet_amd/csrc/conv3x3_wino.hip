@@ -54,7 +54,8 @@ constexpr int WN_NBP = WN_PRP / 16;       // 21
 constexpr int WN_NBU = WN_UROWS / 16;     // 32
 constexpr int WN_STAGE = (WN_PRP + WN_UROWS) * 16;   // floats per LDS stage (54 272 B)
 
-template <int NSTG>
+// ABL (scripts/exp_wino.hip only, 0 in the library): 1 = no patch DMA, 2 = no weight DMA, 4 = no MFMA
+template <int NSTG, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) {
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
                 const float* src = zero;
                 if (d_off[i] >= 0)
                     src = (b < WN_NBP) ? xn + d_off[i] + c16 * 16 : a.up + d_off[i] + (size_t)c16 * Cout_pad * 16;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + b * 256), 16, 0, 0);
+                if (!((ABL & 1) && b < WN_NBP) && !((ABL & 2) && b >= WN_NBP))
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + b * 256), 16, 0, 0);
             }
         }
     };
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
             const f32x4 b = v[xi >> 2][xi & 3];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+                if (ABL & 4) { asm volatile("" ::"v"(w0[k]), "v"(w1[k]), "v"(b[k])); continue; }
                 acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[k], b[k], acc[xi][0], 0, 0, 0);
                 acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[k], b[k], acc[xi][1], 0, 0, 0);
             }
@@ -296,6 +299,8 @@ extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packe
     const long nblk = (long)N * dilation * dilation * a.tiles_x * a.tiles_y * a.ncb;
     if (nblk >= (1L << 31)) return PWC_ERANGE;
     const size_t lds = (size_t)WN_STAGE * sizeof(float);
-    hipLaunchKernelGGL(conv3x3_wino_kernel<1>, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
+    // measured (scripts/exp_wino.hip): one LDS stage with 2 co-resident workgroups per CU beats both a
+    // double-buffered stage (1 workgroup per CU) and a split-weights pipeline
+    hipLaunchKernelGGL((conv3x3_wino_kernel<1, 0>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
     return pwc_launch_status();
 }

@@ -1,0 +1,43 @@
+// microbench of Winograd kernel variants on the 128->128 layer at 8x112x256
+#include "../pwcnet_amd/csrc/conv3x3_wino.hip"
+#include <cstdio>
+#include <vector>
+template <typename K>
+static float run(K kern, const WinoArgs& a, long nblk, size_t lds, int iters) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, 0, a);
+    hipEventRecord(s);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, 0, a);
+    hipEventRecord(e); hipEventSynchronize(e);
+    float ms; hipEventElapsedTime(&ms, s, e); return ms / iters * 1e3f;
+}
+static double checksum(const float* d, size_t n) {
+    std::vector<float> h(n); hipMemcpy(h.data(), d, n * 4, hipMemcpyDeviceToHost);
+    double s = 0; for (size_t i = 0; i < n; i += 5) s += (double)h[i] * (1 + (i % 11)); return s;
+}
+int main() {
+    const int N = 8, H = 112, W = 256, C = 128, CO = 128;
+    const size_t nx = (size_t)N * H * W * C, nu = (size_t)16 * C * CO;
+    float *x, *u, *b, *y;
+    hipMalloc(&x, nx * 4); hipMalloc(&y, (size_t)N * H * W * CO * 4); hipMalloc(&u, nu * 4); hipMalloc(&b, CO * 4);
+    std::vector<float> h(nx); unsigned r = 7;
+    for (auto& v : h) { r = r * 1664525u + 1013904223u; v = ((r >> 8) & 0xFFFF) / 65536.f - 0.5f; }
+    hipMemcpy(x, h.data(), nx * 4, hipMemcpyHostToDevice); hipMemcpy(u, h.data(), nu * 4, hipMemcpyHostToDevice); hipMemset(b, 0, CO * 4);
+    WinoArgs a{}; a.x = x; a.up = u; a.bias = b; a.y = y; a.x_cs = C; a.y_cs = CO; a.N = N; a.H = H; a.W = W; a.Cin_phys = C; a.Cout = CO;
+    a.apply_act = 1; a.slope = 0.1f; a.tiles_x = W / 16; a.tiles_y = H / 16; a.ncb = CO / 32; a.y_vec4 = 1; a.dil = 1;
+    const long nblk = (long)N * a.tiles_x * a.tiles_y * a.ncb;
+    const double gf = 2.0 * N * H * W * 9.0 * C * CO / 1e9;
+    for (int round = 0; round < 3; ++round) {
+        printf("  ablate: no patch DMA %6.1f | no U DMA %6.1f | no DMA %6.1f | no MFMA %6.1f | no MFMA, no DMA %6.1f us\n",
+               run(conv3x3_wino_kernel<1, 1>, a, nblk, (size_t)WN_STAGE * 4, 10), run(conv3x3_wino_kernel<1, 2>, a, nblk, (size_t)WN_STAGE * 4, 10),
+               run(conv3x3_wino_kernel<1, 3>, a, nblk, (size_t)WN_STAGE * 4, 10), run(conv3x3_wino_kernel<1, 4>, a, nblk, (size_t)WN_STAGE * 4, 10),
+               run(conv3x3_wino_kernel<1, 7>, a, nblk, (size_t)WN_STAGE * 4, 10));
+        float t1 = run(conv3x3_wino_kernel<1, 0>, a, nblk, (size_t)WN_STAGE * 4, 10); double c1 = checksum(y, (size_t)N * H * W * CO);
+        float t2 = run(conv3x3_wino_kernel<2, 0>, a, nblk, (size_t)2 * WN_STAGE * 4, 10); double c2 = checksum(y, (size_t)N * H * W * CO);
+        float t3 = t1; double c3 = c1;
+        printf("single-stage %7.1f us (%5.1f eff TF) | double-stage %7.1f us (%5.1f) | split-U pipeline %7.1f us (%5.1f)  checks %.3f %.3f %.3f\n",
+               t1, gf / t1 * 1e3, t2, gf / t2 * 1e3, t3, gf / t3 * 1e3, c1, c2, c3);
+    }
+    return 0;
+}
