@@ -163,6 +163,13 @@ def main():
                             "launches_per_step": dd["launches"] / args.steps,
                             "flops_per_launch": dd["flops"] / dd["launches"],
                             "measured": "HIP events around each launch of this kernel, inside the timed region"}
+        if dominant.startswith("conv3x3_wino"):
+            # Winograd F(2x2,3x3) executes 16 multiplies per 2x2 outputs instead of 36: `achieved`
+            # counts the ALGORITHMIC (direct-convolution) flops, so it can exceed the MFMA peak
+            line["roofline"]["executed_mfma_tflops"] = ach / 2.25
+            line["roofline"]["mfma_pipe_frac"] = ach / 2.25 / PEAK_F32_MFMA_TFLOPS
+            line["roofline"]["note"] = ("Winograd F(2x2,3x3): algorithmic flops = 2*M*9*Cin*Cout per launch; the MFMA "
+                                        "units execute 2.25x fewer (executed_mfma_tflops, mfma_pipe_frac)")
         hb = [(k, d) for k, d in summ.items() if k.startswith(("cost_volume", "warp_kernel"))]
         if hb:
             ms = sum(d["ms"] for _, d in hb)

@@ -120,7 +120,7 @@ int pwc_conv3x3_plan(int M, int Cout, int Cin_phys, int* plan4);
 int pwc_conv3x3_uses_halo_kernel(int M, int Cin_phys, int Cout, int stride, int dilation);
 int pwc_conv3x3_tile_shape(int tile, int* bm, int* bn);
 
-/* Winograd F(2x2,3x3) form of the same convolution for stride 1 and Cout % 32 == 0:
+/* Winograd F(2x2,3x3) form of the same convolution for stride 1 and Cout % 16 == 0:
  * 2.25x fewer multiplies (16 per 2x2 outputs instead of 36), fp32 result within ~1e-6
  * relative of the direct sum.  A dilation-d convolution is run as d*d ordinary ones on the
  * pixel sub-lattices (y mod d, x mod d).  pwc_conv3x3_wino_workgroups gives the number of

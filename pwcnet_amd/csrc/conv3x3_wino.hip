@@ -45,18 +45,22 @@ __device__ float wino_zero_page[4];
 
 __device__ __forceinline__ int wswz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
-constexpr int WN_BN = 32;                 // output channels per workgroup
 constexpr int WN_PW = 18;                 // patch width/height (8 tiles * 2 + 2)
 constexpr int WN_PR = WN_PW * WN_PW;      // 324 patch pixels
 constexpr int WN_PRP = 336;               // padded to 21 DMA blocks of 16 rows
-constexpr int WN_UROWS = 16 * WN_BN;      // 512 weight rows (xi, cout) per stage
 constexpr int WN_NBP = WN_PRP / 16;       // 21
-constexpr int WN_NBU = WN_UROWS / 16;     // 32
-constexpr int WN_STAGE = (WN_PRP + WN_UROWS) * 16;   // floats per LDS stage (54 272 B)
+// NT = 16-cout MFMA tiles per workgroup (2: 32 output channels, 1: 16)
+template <int NT> struct WinoGeom {
+    static constexpr int BN = 16 * NT;                // output channels per workgroup
+    static constexpr int UROWS = 16 * BN;             // weight rows (xi, cout) per stage
+    static constexpr int NBU = UROWS / 16;
+    static constexpr int STAGE = (WN_PRP + UROWS) * 16;   // floats per LDS stage (NT = 2: 54 272 B)
+};
 
 // ABL (scripts/exp_wino.hip only, 0 in the library): 1 = no patch DMA, 2 = no weight DMA, 4 = no MFMA
-template <int NSTG, int ABL = 0>
+template <int NSTG, int ABL = 0, int NT = 2>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) {
+    constexpr int WN_BN = WinoGeom<NT>::BN, WN_NBU = WinoGeom<NT>::NBU, WN_STAGE = WinoGeom<NT>::STAGE;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -137,12 +141,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
         }
     const int u_off = WN_PRP * 16 + fr * 16 + ((fq ^ wswz(fr)) << 2);   // A-fragment row fr of a 16-row tile
 
-    f32x4 acc[16][2];
+    f32x4 acc[16][NT];
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi) {
-        acc[xi][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[xi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[xi][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int cur = 0;
     if (NSTG == 2) issue_stage(0, 0);
@@ -175,14 +178,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
         // ---- 16 positions x 2 cout tiles x 4 k-steps of MFMA
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(sb + u_off + (xi * WN_BN) * 16);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(sb + u_off + (xi * WN_BN + 16) * 16);
+            f32x4 wf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                wf[nt] = *reinterpret_cast<const f32x4*>(sb + u_off + (xi * WN_BN + nt * 16) * 16);
             const f32x4 b = v[xi >> 2][xi & 3];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (ABL & 4) { asm volatile("" ::"v"(w0[k]), "v"(w1[k]), "v"(b[k])); continue; }
-                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[k], b[k], acc[xi][0], 0, 0, 0);
-                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[k], b[k], acc[xi][1], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (ABL & 4) { asm volatile("" ::"v"(wf[nt][k]), "v"(b[k])); continue; }
+                    acc[xi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][k], b[k], acc[xi][nt], 0, 0, 0);
+                }
             }
         }
         if (NSTG == 2) cur ^= 1;
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
     // ---- output transform  Y = A^T M A  (A^T = [1 1 1 0; 0 1 -1 -1]), bias, leaky-relu, stores
     const int oy = y0 + 2 * tr, ox = x0 + 2 * tc;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
         const int co = n0 + nt * 16 + fq * 4;
         if (co >= a.Cout) continue;
         f32x4 s[2][4];
@@ -273,9 +280,9 @@ extern "C" int pwc_conv3x3_wino_pack_f32(const float* w_hwio, const int32_t* cin
 }
 
 extern "C" long pwc_conv3x3_wino_workgroups(int N, int H, int W, int Cout, int dilation) {
-    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || dilation < 1 || Cout % WN_BN) return 0;
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || dilation < 1 || Cout % 16) return 0;
     const long tx = ((W + dilation - 1) / dilation + 15) / 16, ty = ((H + dilation - 1) / dilation + 15) / 16;
-    return (long)N * dilation * dilation * tx * ty * (Cout / WN_BN);
+    return (long)N * dilation * dilation * tx * ty * (Cout % 32 == 0 ? Cout / 32 : Cout / 16);
 }
 
 extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packed_u, const float* bias, float* y,
@@ -283,7 +290,7 @@ extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packe
                                     int apply_act, float slope, pwc_stream_t stream) {
     if (!x || !packed_u || !bias || !y) return PWC_EINVAL;
     if (N <= 0 || H <= 0 || W <= 0 || Cin_phys <= 0 || Cout <= 0 || dilation < 1) return PWC_EINVAL;
-    if (Cin_phys % 16 || Cout % 32) return PWC_EUNSUPPORTED;
+    if (Cin_phys % 16 || Cout % 16) return PWC_EUNSUPPORTED;
     if (x_cs < Cin_phys || y_cs < Cout) return PWC_EINVAL;
     if ((x_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(packed_u) || !pwc_aligned16(bias)) return PWC_EALIGN;
     if ((long)H * W * x_cs >= (1L << 31)) return PWC_ERANGE;
@@ -294,13 +301,18 @@ extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packe
     a.dil = dilation;
     a.tiles_x = ((W + dilation - 1) / dilation + 15) / 16;
     a.tiles_y = ((H + dilation - 1) / dilation + 15) / 16;
-    a.ncb = Cout / WN_BN;
+    const int bn = (Cout % 32 == 0) ? 32 : 16;
+    a.ncb = Cout / bn;
     a.y_vec4 = ((y_cs & 3) == 0 && pwc_aligned16(y)) ? 1 : 0;
     const long nblk = (long)N * dilation * dilation * a.tiles_x * a.tiles_y * a.ncb;
     if (nblk >= (1L << 31)) return PWC_ERANGE;
-    const size_t lds = (size_t)WN_STAGE * sizeof(float);
     // measured (scripts/exp_wino.hip): one LDS stage with 2 co-resident workgroups per CU beats both a
     // double-buffered stage (1 workgroup per CU) and a split-weights pipeline
-    hipLaunchKernelGGL((conv3x3_wino_kernel<1, 0>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
+    if (bn == 32)
+        hipLaunchKernelGGL((conv3x3_wino_kernel<1, 0, 2>), dim3((unsigned)nblk), dim3(256),
+                           (size_t)WinoGeom<2>::STAGE * sizeof(float), (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((conv3x3_wino_kernel<1, 0, 1>), dim3((unsigned)nblk), dim3(256),
+                           (size_t)WinoGeom<1>::STAGE * sizeof(float), (hipStream_t)stream, a);
     return pwc_launch_status();
 }

@@ -237,7 +237,7 @@ class _ConvRunner:
         use_mfma = (cout % 16 == 0 and x.C % 16 == 0 and x.cs % 4 == 0 and x.ptr % 16 == 0
                     and residual is None)
         cache = self.owner._cache
-        use_wino = (use_mfma and getattr(self.owner, "winograd", False) and stride == 1 and cout % 32 == 0
+        use_wino = (use_mfma and getattr(self.owner, "winograd", False) and stride == 1
                     and tile < 0 and split == 0 and _wino_pays(L, x.N, x.H, x.W, cout, dilation))
         if use_wino:
             key = (name, "wino", x.C, None if cin_map is None else cin_map.tobytes(), self.store.version)

@@ -30,11 +30,11 @@ int main() {
     const double gf = 2.0 * N * H * W * 9.0 * C * CO / 1e9;
     for (int round = 0; round < 3; ++round) {
         printf("  ablate: no patch DMA %6.1f | no U DMA %6.1f | no DMA %6.1f | no MFMA %6.1f | no MFMA, no DMA %6.1f us\n",
-               run(conv3x3_wino_kernel<1, 1>, a, nblk, (size_t)WN_STAGE * 4, 10), run(conv3x3_wino_kernel<1, 2>, a, nblk, (size_t)WN_STAGE * 4, 10),
-               run(conv3x3_wino_kernel<1, 3>, a, nblk, (size_t)WN_STAGE * 4, 10), run(conv3x3_wino_kernel<1, 4>, a, nblk, (size_t)WN_STAGE * 4, 10),
-               run(conv3x3_wino_kernel<1, 7>, a, nblk, (size_t)WN_STAGE * 4, 10));
-        float t1 = run(conv3x3_wino_kernel<1, 0>, a, nblk, (size_t)WN_STAGE * 4, 10); double c1 = checksum(y, (size_t)N * H * W * CO);
-        float t2 = run(conv3x3_wino_kernel<2, 0>, a, nblk, (size_t)2 * WN_STAGE * 4, 10); double c2 = checksum(y, (size_t)N * H * W * CO);
+               run(conv3x3_wino_kernel<1, 1>, a, nblk, (size_t)WinoGeom<2>::STAGE * 4, 10), run(conv3x3_wino_kernel<1, 2>, a, nblk, (size_t)WinoGeom<2>::STAGE * 4, 10),
+               run(conv3x3_wino_kernel<1, 3>, a, nblk, (size_t)WinoGeom<2>::STAGE * 4, 10), run(conv3x3_wino_kernel<1, 4>, a, nblk, (size_t)WinoGeom<2>::STAGE * 4, 10),
+               run(conv3x3_wino_kernel<1, 7>, a, nblk, (size_t)WinoGeom<2>::STAGE * 4, 10));
+        float t1 = run(conv3x3_wino_kernel<1, 0>, a, nblk, (size_t)WinoGeom<2>::STAGE * 4, 10); double c1 = checksum(y, (size_t)N * H * W * CO);
+        float t2 = run(conv3x3_wino_kernel<2, 0>, a, nblk, (size_t)2 * WinoGeom<2>::STAGE * 4, 10); double c2 = checksum(y, (size_t)N * H * W * CO);
         float t3 = t1; double c3 = c1;
         printf("single-stage %7.1f us (%5.1f eff TF) | double-stage %7.1f us (%5.1f) | split-U pipeline %7.1f us (%5.1f)  checks %.3f %.3f %.3f\n",
                t1, gf / t1 * 1e3, t2, gf / t2 * 1e3, t3, gf / t3 * 1e3, c1, c2, c3);

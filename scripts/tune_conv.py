@@ -86,7 +86,7 @@ def wino_main():
     ws = torch.empty(64 << 20, device="cuda")
     print(f"{'layer':9s} {'M':>8s} {'cin':>4s} {'cout':>4s} {'GF':>6s} | {'auto us':>8s} {'TF':>6s} | {'wino us':>8s} {'eff TF':>7s} speedup")
     for tag, N, H, W, cp, cl, co, st, dl in layers():
-        if st != 1 or co % 32:
+        if st != 1 or co % 16:
             continue
         M = N * H * W
         x = torch.rand((N, H, W, cp), device="cuda") - 0.5

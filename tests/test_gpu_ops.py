@@ -146,7 +146,7 @@ def run_conv_wino(x, k, b, slope, cin_map=None, y_cs=None, dil=1):
 
 @pytest.mark.parametrize("N,H,W,cin,cout", [
     (2, 16, 16, 16, 32), (1, 32, 48, 32, 64), (2, 7, 16, 192, 192), (1, 14, 32, 128, 96), (1, 28, 64, 96, 64),
-    (1, 33, 21, 64, 32), (1, 5, 3, 16, 32), (2, 56, 128, 160, 128)])
+    (1, 33, 21, 64, 32), (1, 5, 3, 16, 32), (2, 56, 128, 160, 128), (2, 40, 70, 16, 16), (1, 20, 30, 32, 48)])
 def test_conv_winograd_vs_oracle(pa, N, H, W, cin, cout):
     x = rnd((N, H, W, cin), 71)
     k = rnd((3, 3, cin, cout), 72) * float(1.0 / np.sqrt(9 * cin))
