@@ -91,41 +91,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
     const int nc16 = a.Cin_phys >> 4;
     const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs;
 
-    // ---- DMA bookkeeping (fixed over the channel loop): block b = wave + 4*i
-    constexpr int NB = WN_NBP + WN_NBU;            // 53 blocks per stage
-    constexpr int BPW = (NB + 3) / 4;              // 14 per wave
-    int d_off[BPW];                                // patch: element offset in the image (-1: zeros); U: row offset
+    // ---- DMA bookkeeping (fixed over the channel loop).  Patch blocks (21) and weight blocks
+    // (16*NT) are dealt to the 4 waves separately, so each unrolled issue knows its base at
+    // compile time: per stage a lane does "offset + stage advance -> 64-bit add -> DMA".
+    constexpr int PPW = (WN_NBP + 3) / 4;          // patch blocks per wave (6, the last partly unused)
+    constexpr int UPW = WN_NBU / 4;                // weight blocks per wave (8 for NT = 2)
+    static_assert(WN_NBU % 4 == 0, "weight blocks must split evenly over the waves");
+    int p_off[PPW];                                // element offset of the lane's 16-byte chunk in the image, -1: zeros
+    int u_src[UPW];                                // element offset in the packed weights (stage 0), -1: zeros
 #pragma unroll
-    for (int i = 0; i < BPW; ++i) {
+    for (int i = 0; i < PPW; ++i) {
         const int b = wave + 4 * i;
+        const int pr = b * 16 + (lane >> 2);
         int v = -1;
-        if (b < WN_NBP) {
-            const int pr = b * 16 + (lane >> 2);
-            if (pr < WN_PR) {
-                const int py = pr / WN_PW, px = pr - py * WN_PW;
-                const int y = ry + d * (y0 - 1 + py), x = rx + d * (x0 - 1 + px);
-                const int j = (lane & 3) ^ wswz(pr);               // source chunk for this LDS slot
-                if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) v = (y * a.W + x) * a.x_cs + j * 4;
-            }
-        } else if (b < NB) {
-            const int ur = (b - WN_NBP) * 16 + (lane >> 2);        // (xi, cout) row of the stage
-            const int xi = ur / WN_BN, co = ur - xi * WN_BN;
-            v = (n0 + co < Cout_pad) ? ((xi * nc16) * Cout_pad + n0 + co) * 16 + (lane & 3) * 4 : -1;
+        if (b < WN_NBP && pr < WN_PR) {
+            const int py = pr / WN_PW, px = pr - py * WN_PW;
+            const int y = ry + d * (y0 - 1 + py), x = rx + d * (x0 - 1 + px);
+            const int j = (lane & 3) ^ wswz(pr);                   // source chunk for this LDS slot
+            if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) v = (y * a.W + x) * a.x_cs + j * 4;
         }
-        d_off[i] = v;
+        p_off[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+        const int ur = (wave + 4 * i) * 16 + (lane >> 2);          // (xi, cout) row of the stage
+        const int xi = ur / WN_BN, co = ur - xi * WN_BN;
+        u_src[i] = (n0 + co < Cout_pad) ? ((xi * nc16) * Cout_pad + n0 + co) * 16 + (lane & 3) * 4 : -1;
     }
     auto issue_stage = [&](int c16, int buf) {
         float* dst = smem + buf * WN_STAGE;
+        const float* xs = xn + c16 * 16;
+        const float* us = a.up + (size_t)c16 * Cout_pad * 16;
 #pragma unroll
-        for (int i = 0; i < BPW; ++i) {
+        for (int i = 0; i < PPW; ++i) {
             const int b = wave + 4 * i;
-            if (b < NB) {
-                const float* src = zero;
-                if (d_off[i] >= 0)
-                    src = (b < WN_NBP) ? xn + d_off[i] + c16 * 16 : a.up + d_off[i] + (size_t)c16 * Cout_pad * 16;
-                if (!((ABL & 1) && b < WN_NBP) && !((ABL & 2) && b >= WN_NBP))
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + b * 256), 16, 0, 0);
+            if (b < WN_NBP) {
+                const float* src = p_off[i] >= 0 ? xs + p_off[i] : zero;
+                if (!(ABL & 1)) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + b * 256), 16, 0, 0);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const float* src = u_src[i] >= 0 ? us + u_src[i] : zero;
+            if (!(ABL & 2))
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + (WN_NBP + wave + 4 * i) * 256), 16, 0, 0);
         }
     };
 
@@ -175,28 +184,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
             const f32x4 e0 = v[i][0], e1 = v[i][1], e2 = v[i][2], e3 = v[i][3];
             v[i][0] = e0 - e2; v[i][1] = e1 + e2; v[i][2] = e2 - e1; v[i][3] = e1 - e3;
         }
-        // ---- 16 positions x 2 cout tiles x 4 k-steps of MFMA
+        // ---- 16 positions x NT cout tiles x 4 k-steps of MFMA, two positions interleaved so
+        // that 2*NT independent accumulators rotate (no dependent back-to-back issue)
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
-            f32x4 wf[NT];
+        for (int xp = 0; xp < 16; xp += 2) {
+            f32x4 wf[2][NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                wf[nt] = *reinterpret_cast<const f32x4*>(sb + u_off + (xi * WN_BN + nt * 16) * 16);
-            const f32x4 b = v[xi >> 2][xi & 3];
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+                for (int nt = 0; nt < NT; ++nt)
+                    wf[q][nt] = *reinterpret_cast<const f32x4*>(sb + u_off + ((xp + q) * WN_BN + nt * 16) * 16);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    if (ABL & 4) { asm volatile("" ::"v"(wf[nt][k]), "v"(b[k])); continue; }
-                    acc[xi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][k], b[k], acc[xi][nt], 0, 0, 0);
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int xi = xp + q;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if (ABL & 4) { asm volatile("" ::"v"(wf[q][nt][k]), "v"(v[xi >> 2][xi & 3][k])); continue; }
+                        acc[xi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[q][nt][k], v[xi >> 2][xi & 3][k],
+                                                                           acc[xi][nt], 0, 0, 0);
+                    }
                 }
-            }
         }
         if (NSTG == 2) cur ^= 1;
     }
 
     // ---- output transform  Y = A^T M A  (A^T = [1 1 1 0; 0 1 -1 -1]), bias, leaky-relu, stores
     const int oy = y0 + 2 * tr, ox = x0 + 2 * tc;
+    const int py0 = ry + d * oy, px0 = rx + d * ox;                   // real coordinates of output (0,0)
+    const bool okr[2] = {py0 < a.H, py0 + d < a.H};
+    const bool okc[2] = {px0 < a.W, px0 + d < a.W};
+    float* out00 = a.y + ((size_t)(n * a.H + py0) * a.W + px0) * a.y_cs;
+    const size_t dcol = (size_t)d * a.y_cs, drow = (size_t)d * a.W * a.y_cs;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0 + nt * 16 + fq * 4;
@@ -218,9 +238,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
                     yv[0] = pwc_lrelu(yv[0], a.slope); yv[1] = pwc_lrelu(yv[1], a.slope);
                     yv[2] = pwc_lrelu(yv[2], a.slope); yv[3] = pwc_lrelu(yv[3], a.slope);
                 }
-                const int py = ry + d * (oy + i), px = rx + d * (ox + j);
-                if (py < a.H && px < a.W) {
-                    float* dst = a.y + ((size_t)(n * a.H + py) * a.W + px) * a.y_cs + co;
+                if (okr[i] && okc[j]) {
+                    float* dst = out00 + i * drow + j * dcol + co;
                     if (a.y_vec4) *reinterpret_cast<f32x4*>(dst) = yv;
                     else { dst[0] = yv[0]; dst[1] = yv[1]; dst[2] = yv[2]; dst[3] = yv[3]; }
                 }
