@@ -163,6 +163,16 @@ def main():
                             "launches_per_step": dd["launches"] / args.steps,
                             "flops_per_launch": dd["flops"] / dd["launches"],
                             "measured": "HIP events around each launch of this kernel, inside the timed region"}
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc) and (B, H, Wd, args.use_dc) == (8, 448, 1024, False):
+            # HBM bytes per launch from the committed PMC passes of this same workload
+            # (scripts/gpu_pmc_traffic.sh; counters cannot be collected from inside the process)
+            t = json.load(open(pmc))
+            fam = t["kernels"].get(dominant.split("<")[0])
+            if fam:
+                line["roofline"]["traffic"] = fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"]
+                line["roofline"]["traffic_unit"] = "bytes per launch (mean over the kernel's launches)"
+                line["roofline"]["traffic_source"] = "profiles/pmc_traffic.json: " + t["source"]
         if dominant.startswith("conv3x3_wino"):
             # Winograd F(2x2,3x3) executes 16 multiplies per 2x2 outputs instead of 36: `achieved`
             # counts the ALGORITHMIC (direct-convolution) flops, so it can exceed the MFMA peak

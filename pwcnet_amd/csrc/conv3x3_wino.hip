@@ -71,6 +71,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
     const int fr = lane & 15, fq = lane >> 4;
     const float* zero = wino_zero_page;
 
+    if (ABL & 24) {
+        // experiments: break the lockstep of the two co-resident workgroups of a CU
+        const unsigned hw = __builtin_amdgcn_s_getreg((3 << 11) | 4);   // HW_REG_HW_ID[3:0] = wave slot
+        if (__builtin_amdgcn_readfirstlane(hw) & 1) {
+            if (ABL & 8) __builtin_amdgcn_s_setprio(1);
+            if (ABL & 16) { __builtin_amdgcn_s_sleep(32); __builtin_amdgcn_s_sleep(32); }
+        }
+    }
+
     // block decode: cout block fastest, XCD-aware (the cout blocks of one pixel block share
     // their input patch in one XCD's L2)
     const int nblk = gridDim.x;
@@ -98,7 +107,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
     constexpr int UPW = WN_NBU / 4;                // weight blocks per wave (8 for NT = 2)
     static_assert(WN_NBU % 4 == 0, "weight blocks must split evenly over the waves");
     int p_off[PPW];                                // element offset of the lane's 16-byte chunk in the image, -1: zeros
-    int u_src[UPW];                                // element offset in the packed weights (stage 0), -1: zeros
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int b = wave + 4 * i;
@@ -112,12 +120,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
         }
         p_off[i] = v;
     }
-#pragma unroll
-    for (int i = 0; i < UPW; ++i) {
-        const int ur = (wave + 4 * i) * 16 + (lane >> 2);          // (xi, cout) row of the stage
+    // weight blocks: block wave + 4*i holds rows (xi, cout) = ((wave + 4*i) * 16 + lane/4); 4 blocks
+    // = 64 rows = 64 / WN_BN positions, so one per-lane offset plus a uniform stride covers all i
+    static_assert(64 % WN_BN == 0, "weight block stride must be a whole number of positions");
+    int u_src0;
+    {
+        const int ur = wave * 16 + (lane >> 2);
         const int xi = ur / WN_BN, co = ur - xi * WN_BN;
-        u_src[i] = (n0 + co < Cout_pad) ? ((xi * nc16) * Cout_pad + n0 + co) * 16 + (lane & 3) * 4 : -1;
+        u_src0 = (n0 + co < Cout_pad) ? ((xi * nc16) * Cout_pad + n0 + co) * 16 + (lane & 3) * 4 : -1;
     }
+    const int u_step = (64 / WN_BN) * nc16 * Cout_pad * 16;
     auto issue_stage = [&](int c16, int buf) {
         float* dst = smem + buf * WN_STAGE;
         const float* xs = xn + c16 * 16;
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
         }
 #pragma unroll
         for (int i = 0; i < UPW; ++i) {
-            const float* src = u_src[i] >= 0 ? us + u_src[i] : zero;
+            const float* src = u_src0 >= 0 ? us + u_src0 + i * u_step : zero;
             if (!(ABL & 2))
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + (WN_NBP + wave + 4 * i) * 256), 16, 0, 0);
         }
@@ -186,25 +198,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
         }
         // ---- 16 positions x NT cout tiles x 4 k-steps of MFMA, two positions interleaved so
         // that 2*NT independent accumulators rotate (no dependent back-to-back issue)
+        f32x4 wf[2][NT];                         // [ring slot][cout tile]
+        auto load_w = [&](int slot, int xi) {
 #pragma unroll
-        for (int xp = 0; xp < 16; xp += 2) {
-            f32x4 wf[2][NT];
+            for (int nt = 0; nt < NT; ++nt)
+                wf[slot][nt] = *reinterpret_cast<const f32x4*>(sb + u_off + (xi * WN_BN + nt * 16) * 16);
+        };
+        load_w(0, 0);
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    wf[q][nt] = *reinterpret_cast<const f32x4*>(sb + u_off + ((xp + q) * WN_BN + nt * 16) * 16);
+        for (int xi = 0; xi < 16; ++xi) {
+            const int slot = xi & 1;
+            if (ABL & 32) {
+                // (experiment; spills at 256 VGPRs and measured slower) the NEXT position's weights are requested before this position's 4*NT MFMAs
+                // (~250 cycles of cover for the LDS latency); the scheduling barrier keeps them here
+                if (xi + 1 < 16) load_w(slot ^ 1, xi + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (xi > 0) load_w(slot, xi);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int xi = xp + q;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        if (ABL & 4) { asm volatile("" ::"v"(wf[q][nt][k]), "v"(v[xi >> 2][xi & 3][k])); continue; }
-                        acc[xi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[q][nt][k], v[xi >> 2][xi & 3][k],
-                                                                           acc[xi][nt], 0, 0, 0);
-                    }
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (ABL & 4) { asm volatile("" ::"v"(wf[slot][nt][k]), "v"(v[xi >> 2][xi & 3][k])); continue; }
+                    acc[xi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][nt][k], v[xi >> 2][xi & 3][k],
+                                                                       acc[xi][nt], 0, 0, 0);
                 }
         }
         if (NSTG == 2) cur ^= 1;
