@@ -21,9 +21,10 @@
 //               B-operand fragment V_xi[k = 4q+s][tile j] -- and, at the end, holds all 16
 //               M_xi of its (4 couts x 1 tile) outputs, so the output transform A^T M A is
 //               register-local too.  No transformed data ever goes through LDS.
-//   LDS per 16-channel stage: the raw 18 x 18 pixel patch (64-byte rows, XOR-swizzled) and
-//   the transformed weights U[xi][32 cout][16 ch] (pre-swizzled by the packer), both filled
-//   by global_load_lds_dwordx4; out-of-image pixels read a zero page (SAME padding).
+//   LDS per 16-channel stage: the raw 18 x 18 pixel patch (64-byte rows, see wpswz) and the
+//   transformed weights U[xi][32 cout][16 ch] (pre-swizzled by the packer), both filled by
+//   buffer_load_dwordx4 ... lds; out-of-image pixels are out-of-range buffer offsets and
+//   read as zeros (SAME padding).
 #include "pwc_common.h"
 
 struct WinoArgs {
@@ -41,44 +42,62 @@ struct WinoArgs {
     int dil;                     // dilation d: the conv splits into d*d ordinary convs on the pixel sub-lattices
 };
 
-__device__ float wino_zero_page[4];
+__device__ __forceinline__ int wswz(int row) { return (4 - ((row >> 2) & 3)) & 3; }   // weight rows
+// Patch image in LDS: pixel (py, px) of the 18 x 18 patch sits in 64-byte row
+//   py * 20 + (px & 1) * 10 + (px >> 1)
+// (even pixel columns first, then the odd ones; rows 9 and 19 of every 20 are unused), its
+// 16-byte chunk c at slot c ^ wpswz(row).  The 16 tiles a wave reads at one (i, j) of the 4x4
+// window then lie in two runs of 8 CONSECUTIVE rows, and with this chunk swizzle every
+// ds_read_b128 lane group ({0-3,12-15,20-27}, ... MI355X_MICROARCH.md) covers the 16 slots of the
+// 256-byte bank row exactly once.  (The first layout, rows py*18+px, had 2-way conflicts on all
+// 16 patch reads of a stage: SQ_LDS_BANK_CONFLICT = 40 % of SQ_LDS_IDX_ACTIVE.)
+__device__ __forceinline__ int wpswz(int row) { return (row >> 1) & 2; }
 
-__device__ __forceinline__ int wswz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
-
-constexpr int WN_PW = 18;                 // patch width/height (8 tiles * 2 + 2)
-constexpr int WN_PR = WN_PW * WN_PW;      // 324 patch pixels
-constexpr int WN_PRP = 336;               // padded to 21 DMA blocks of 16 rows
-constexpr int WN_NBP = WN_PRP / 16;       // 21
+constexpr int WN_PW = 18;                 // patch width/height in pixels (8 tiles * 2 + 2)
+constexpr int WN_PS = 20;                 // LDS rows per patch row
+constexpr int WN_PRP = 368;               // 18 * 20 = 360 rows, padded to 23 DMA blocks of 16 rows
+constexpr int WN_NBP = WN_PRP / 16;       // 23
+constexpr unsigned WN_OOB = 0x7FFF0000u;  // byte offset beyond every buffer: loads return 0, stores are dropped
 // NT = 16-cout MFMA tiles per workgroup (2: 32 output channels, 1: 16)
 template <int NT> struct WinoGeom {
     static constexpr int BN = 16 * NT;                // output channels per workgroup
     static constexpr int UROWS = 16 * BN;             // weight rows (xi, cout) per stage
     static constexpr int NBU = UROWS / 16;
-    static constexpr int STAGE = (WN_PRP + UROWS) * 16;   // floats per LDS stage (NT = 2: 54 272 B)
+    static constexpr int STAGE = (WN_PRP + UROWS) * 16;   // floats per LDS stage (NT = 2: 56 320 B)
 };
 
-// ABL (scripts/exp_wino.hip only, 0 in the library): 1 = no patch DMA, 2 = no weight DMA, 4 = no MFMA
-template <int NSTG, int ABL = 0, int NT = 2>
+template <bool B> struct WinoBool { static constexpr bool value = B; };
+
+// -1.0f in an SGPR the optimiser cannot see through: p - q is written fma(q, -1, p) so that it
+// can become one v_pk_fma_f32 per two floats (a vector fsub is scalarised by the backend: there
+// is v_pk_add_f32 but no packed subtract).  The VALU instructions of the transforms share the
+// issue port with the MFMAs and their time ADDS to the MFMA time (measured: removing the 128
+// scalar transform instructions of a stage saved 10 % of the kernel).
+// (Inline-asm v_pk_add_f32 with neg modifiers was tried: fully packed, same speed, but every
+// VALU write an MFMA reads next needs 2 wait states that the hazard recogniser only inserts
+// for instructions it can see -- results were wrong until the s_nop moved into the asm.)
+__device__ __forceinline__ float wino_minus_one() {
+    float m;
+    asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(m));
+    return m;
+}
+
+// ABL (scripts/exp_wino.hip only, 0 in the library): 1 = no patch DMA, 2 = no weight DMA, 4 = no MFMA,
+// 64 = no input transform
+template <int ABL = 0, int NT = 2>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) {
-    constexpr int WN_BN = WinoGeom<NT>::BN, WN_NBU = WinoGeom<NT>::NBU, WN_STAGE = WinoGeom<NT>::STAGE;
-    typedef const __attribute__((address_space(1))) void* gptr_t;
+    constexpr int WN_BN = WinoGeom<NT>::BN, WN_NBU = WinoGeom<NT>::NBU;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const float* zero = wino_zero_page;
-
-    if (ABL & 24) {
-        // experiments: break the lockstep of the two co-resident workgroups of a CU
-        const unsigned hw = __builtin_amdgcn_s_getreg((3 << 11) | 4);   // HW_REG_HW_ID[3:0] = wave slot
-        if (__builtin_amdgcn_readfirstlane(hw) & 1) {
-            if (ABL & 8) __builtin_amdgcn_s_setprio(1);
-            if (ABL & 16) { __builtin_amdgcn_s_sleep(32); __builtin_amdgcn_s_sleep(32); }
-        }
-    }
+    const float m1 = wino_minus_one();
+    const f32x4 M1 = {m1, m1, m1, m1};
+#define WSUB(p, q) __builtin_elementwise_fma((q), M1, (p))    /* p - q */
 
     // block decode: cout block fastest, XCD-aware (the cout blocks of one pixel block share
     // their input patch in one XCD's L2)
@@ -98,56 +117,54 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
     const int n0 = cb * WN_BN;
     const int Cout_pad = (a.Cout + 15) & ~15;
     const int nc16 = a.Cin_phys >> 4;
-    const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs;
 
-    // ---- DMA bookkeeping (fixed over the channel loop).  Patch blocks (21) and weight blocks
-    // (16*NT) are dealt to the 4 waves separately, so each unrolled issue knows its base at
-    // compile time: per stage a lane does "offset + stage advance -> 64-bit add -> DMA".
-    constexpr int PPW = (WN_NBP + 3) / 4;          // patch blocks per wave (6, the last partly unused)
+    // ---- LDS-DMA bookkeeping.  Both operands are fetched with buffer_load_dwordx4 ... lds:
+    // a per-lane BYTE offset that is fixed over the channel loop (VGPR), the stage advance in the
+    // scalar offset (SGPR) -- no vector instruction per fetch -- and the buffer range check gives
+    // the zeros of the SAME padding: out-of-image lanes carry the offset WN_OOB.
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + (size_t)n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.up, 0, 16 * a.Cin_phys * Cout_pad * 4, 0x00020000);
+    constexpr int PPW = (WN_NBP + 3) / 4;          // patch blocks per wave (6; wave 3 has 5)
     constexpr int UPW = WN_NBU / 4;                // weight blocks per wave (8 for NT = 2)
     static_assert(WN_NBU % 4 == 0, "weight blocks must split evenly over the waves");
-    int p_off[PPW];                                // element offset of the lane's 16-byte chunk in the image, -1: zeros
+    unsigned p_voff[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int b = wave + 4 * i;
-        const int pr = b * 16 + (lane >> 2);
-        int v = -1;
-        if (b < WN_NBP && pr < WN_PR) {
-            const int py = pr / WN_PW, px = pr - py * WN_PW;
-            const int y = ry + d * (y0 - 1 + py), x = rx + d * (x0 - 1 + px);
-            const int j = (lane & 3) ^ wswz(pr);                   // source chunk for this LDS slot
-            if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) v = (y * a.W + x) * a.x_cs + j * 4;
-        }
-        p_off[i] = v;
+        const int pr = b * 16 + (lane >> 2);                       // LDS row this lane fills
+        const int py = pr / WN_PS, rem = pr - py * WN_PS;
+        const int half = rem >= WN_PS / 2 ? 1 : 0, col = rem - half * (WN_PS / 2);
+        const int px = 2 * col + half;
+        const int y = ry + d * (y0 - 1 + py), x = rx + d * (x0 - 1 + px);
+        const int ch = (lane & 3) ^ wpswz(pr);                     // source chunk for this LDS slot
+        const bool ok = py < WN_PW && col < WN_PW / 2 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        p_voff[i] = ok ? (unsigned)(((y * a.W + x) * a.x_cs + ch * 4) * 4) : WN_OOB;
     }
     // weight blocks: block wave + 4*i holds rows (xi, cout) = ((wave + 4*i) * 16 + lane/4); 4 blocks
     // = 64 rows = 64 / WN_BN positions, so one per-lane offset plus a uniform stride covers all i
     static_assert(64 % WN_BN == 0, "weight block stride must be a whole number of positions");
-    int u_src0;
+    unsigned u_voff;
     {
         const int ur = wave * 16 + (lane >> 2);
         const int xi = ur / WN_BN, co = ur - xi * WN_BN;
-        u_src0 = (n0 + co < Cout_pad) ? ((xi * nc16) * Cout_pad + n0 + co) * 16 + (lane & 3) * 4 : -1;
+        u_voff = (n0 + co < Cout_pad) ? (unsigned)((((xi * nc16) * Cout_pad + n0 + co) * 16 + (lane & 3) * 4) * 4) : WN_OOB;
     }
-    const int u_step = (64 / WN_BN) * nc16 * Cout_pad * 16;
-    auto issue_stage = [&](int c16, int buf) {
-        float* dst = smem + buf * WN_STAGE;
-        const float* xs = xn + c16 * 16;
-        const float* us = a.up + (size_t)c16 * Cout_pad * 16;
+    const int u_step = (64 / WN_BN) * nc16 * Cout_pad * 64;       // bytes between a wave's consecutive weight blocks
+    auto issue_stage = [&](int c16) {
+        const int xs = c16 * 64, us = c16 * Cout_pad * 64;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int b = wave + 4 * i;
-            if (b < WN_NBP) {
-                const float* src = p_off[i] >= 0 ? xs + p_off[i] : zero;
-                if (!(ABL & 1)) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + b * 256), 16, 0, 0);
-            }
+            if (b < WN_NBP && !(ABL & 1))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(smem + b * 256), 16, (int)p_voff[i], xs, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < UPW; ++i) {
-            const float* src = u_src0 >= 0 ? us + u_src0 + i * u_step : zero;
+        for (int i = 0; i < UPW; ++i)
             if (!(ABL & 2))
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + (WN_NBP + wave + 4 * i) * 256), 16, 0, 0);
-        }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lptr_t)(smem + (WN_NBP + wave + 4 * i) * 256), 16,
+                                                         (int)u_voff, us + i * u_step, 0, 0);
     };
 
     // ---- this lane's tile and its 16 patch read offsets (floats, swizzled for k-slot fq)
@@ -157,82 +174,87 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int row = (2 * tr + i) * WN_PW + 2 * tc + j;
-            poff[i][j] = row * 16 + ((fq ^ wswz(row)) << 2);
+            const int row = (2 * tr + i) * WN_PS + (j & 1) * (WN_PS / 2) + tc + (j >> 1);
+            poff[i][j] = row * 16 + ((fq ^ wpswz(row)) << 2);
         }
     const int u_off = WN_PRP * 16 + fr * 16 + ((fq ^ wswz(fr)) << 2);   // A-fragment row fr of a 16-row tile
 
     f32x4 acc[16][NT];
-#pragma unroll
-    for (int xi = 0; xi < 16; ++xi)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[xi][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    int cur = 0;
-    if (NSTG == 2) issue_stage(0, 0);
-    for (int c16 = 0; c16 < nc16; ++c16) {
-        if (NSTG == 1) {
-            __syncthreads();                         // previous stage fully read
-            issue_stage(c16, 0);
-        }
+    // one 16-channel stage; FIRST: the accumulators start from the MFMA's zero C operand
+    auto stage = [&](auto first, int c16) {
+        constexpr bool FIRST = decltype(first)::value;
+        __syncthreads();                             // previous stage fully read
+        issue_stage(c16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (NSTG == 2 && c16 + 1 < nc16) issue_stage(c16 + 1, cur ^ 1);
-        const float* sb = smem + cur * WN_STAGE;
 
         // ---- input transform  V = B^T d B  (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]), in place
         f32x4 v[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[i][j] = *reinterpret_cast<const f32x4*>(sb + poff[i][j]);
+            for (int j = 0; j < 4; ++j) v[i][j] = *reinterpret_cast<const f32x4*>(smem + poff[i][j]);
+        if (!(ABL & 64)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                // rows
-            const f32x4 d0 = v[0][j], d1 = v[1][j], d2 = v[2][j], d3 = v[3][j];
-            v[0][j] = d0 - d2; v[1][j] = d1 + d2; v[2][j] = d2 - d1; v[3][j] = d1 - d3;
+            for (int j = 0; j < 4; ++j) {            // rows
+                const f32x4 d0 = v[0][j], d1 = v[1][j], d2 = v[2][j], d3 = v[3][j];
+                v[0][j] = WSUB(d0, d2); v[1][j] = d1 + d2; v[2][j] = WSUB(d2, d1); v[3][j] = WSUB(d1, d3);
+            }
+            // opaque uses: the MFMAs take single floats out of these vectors and the backend would
+            // rewrite extract(vector op) as scalar ops, losing the packed instructions
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm("" : "+v"(v[i][j]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {            // columns
+                const f32x4 e0 = v[i][0], e1 = v[i][1], e2 = v[i][2], e3 = v[i][3];
+                v[i][0] = WSUB(e0, e2); v[i][1] = e1 + e2; v[i][2] = WSUB(e2, e1); v[i][3] = WSUB(e1, e3);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm("" : "+v"(v[i][j]));
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                // columns
-            const f32x4 e0 = v[i][0], e1 = v[i][1], e2 = v[i][2], e3 = v[i][3];
-            v[i][0] = e0 - e2; v[i][1] = e1 + e2; v[i][2] = e2 - e1; v[i][3] = e1 - e3;
-        }
-        // ---- 16 positions x NT cout tiles x 4 k-steps of MFMA, two positions interleaved so
-        // that 2*NT independent accumulators rotate (no dependent back-to-back issue)
-        f32x4 wf[2][NT];                         // [ring slot][cout tile]
-        auto load_w = [&](int slot, int xi) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                wf[slot][nt] = *reinterpret_cast<const f32x4*>(sb + u_off + (xi * WN_BN + nt * 16) * 16);
-        };
-        load_w(0, 0);
+        // ---- 16 positions x NT cout tiles x 4 k-steps of MFMA
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
-            const int slot = xi & 1;
-            if (ABL & 32) {
-                // (experiment; spills at 256 VGPRs and measured slower) the NEXT position's weights are requested before this position's 4*NT MFMAs
-                // (~250 cycles of cover for the LDS latency); the scheduling barrier keeps them here
-                if (xi + 1 < 16) load_w(slot ^ 1, xi + 1);
-                __builtin_amdgcn_sched_barrier(0);
-            } else if (xi > 0) load_w(slot, xi);
+            f32x4 wf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                wf[nt] = *reinterpret_cast<const f32x4*>(smem + u_off + (xi * WN_BN + nt * 16) * 16);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    if (ABL & 4) { asm volatile("" ::"v"(wf[slot][nt][k]), "v"(v[xi >> 2][xi & 3][k])); continue; }
-                    acc[xi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][nt][k], v[xi >> 2][xi & 3][k],
-                                                                       acc[xi][nt], 0, 0, 0);
+                    if (ABL & 4) {
+                        if (FIRST && k == 0) acc[xi][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        asm volatile("" ::"v"(wf[nt][k]), "v"(v[xi >> 2][xi & 3][k]));
+                        continue;
+                    }
+                    const f32x4 c = (FIRST && k == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[xi][nt];
+                    acc[xi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][k], v[xi >> 2][xi & 3][k], c, 0, 0, 0);
                 }
         }
-        if (NSTG == 2) cur ^= 1;
-    }
+    };
+    stage(WinoBool<true>{}, 0);
+    for (int c16 = 1; c16 < nc16; ++c16) stage(WinoBool<false>{}, c16);
 
-    // ---- output transform  Y = A^T M A  (A^T = [1 1 1 0; 0 1 -1 -1]), bias, leaky-relu, stores
-    const int oy = y0 + 2 * tr, ox = x0 + 2 * tc;
-    const int py0 = ry + d * oy, px0 = rx + d * ox;                   // real coordinates of output (0,0)
-    const bool okr[2] = {py0 < a.H, py0 + d < a.H};
-    const bool okc[2] = {px0 < a.W, px0 + d < a.W};
-    float* out00 = a.y + ((size_t)(n * a.H + py0) * a.W + px0) * a.y_cs;
-    const size_t dcol = (size_t)d * a.y_cs, drow = (size_t)d * a.W * a.y_cs;
+    // ---- output transform  Y = A^T M A  (A^T = [1 1 1 0; 0 1 -1 -1]), bias, leaky-relu; stores go
+    // through a buffer resource of image n so that pixels beyond the image edge are dropped by the
+    // range check (no divergent branches)
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.y + (size_t)n * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
+    const int py0 = ry + d * (y0 + 2 * tr), px0 = rx + d * (x0 + 2 * tc);   // real coordinates of output (0,0)
+    unsigned y_voff[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int py = py0 + i * d, px = px0 + j * d;
+            y_voff[i][j] = (py < a.H && px < a.W) ? (unsigned)(((py * a.W + px) * a.y_cs + n0 + fq * 4) * 4) : WN_OOB;
+        }
+    const bool slope_max = a.slope <= 1.f;           // leaky-relu(v) == max(v, slope*v) then
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0 + nt * 16 + fq * 4;
@@ -241,27 +263,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             s[0][j] = acc[0 * 4 + j][nt] + acc[1 * 4 + j][nt] + acc[2 * 4 + j][nt];
-            s[1][j] = acc[1 * 4 + j][nt] - acc[2 * 4 + j][nt] - acc[3 * 4 + j][nt];
+            s[1][j] = WSUB(WSUB(acc[1 * 4 + j][nt], acc[2 * 4 + j][nt]), acc[3 * 4 + j][nt]);
         }
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + co);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                f32x4 yv = (j == 0) ? s[i][0] + s[i][1] + s[i][2] : s[i][1] - s[i][2] - s[i][3];
+                f32x4 yv = (j == 0) ? s[i][0] + s[i][1] + s[i][2] : WSUB(WSUB(s[i][1], s[i][2]), s[i][3]);
                 yv += b4;
                 if (a.apply_act) {
-                    yv[0] = pwc_lrelu(yv[0], a.slope); yv[1] = pwc_lrelu(yv[1], a.slope);
-                    yv[2] = pwc_lrelu(yv[2], a.slope); yv[3] = pwc_lrelu(yv[3], a.slope);
+                    if (slope_max) {
+                        const f32x4 sv = yv * a.slope;
+                        yv[0] = fmaxf(yv[0], sv[0]); yv[1] = fmaxf(yv[1], sv[1]);
+                        yv[2] = fmaxf(yv[2], sv[2]); yv[3] = fmaxf(yv[3], sv[3]);
+                    } else {
+                        yv[0] = pwc_lrelu(yv[0], a.slope); yv[1] = pwc_lrelu(yv[1], a.slope);
+                        yv[2] = pwc_lrelu(yv[2], a.slope); yv[3] = pwc_lrelu(yv[3], a.slope);
+                    }
                 }
-                if (okr[i] && okc[j]) {
-                    float* dst = out00 + i * drow + j * dcol + co;
-                    if (a.y_vec4) *reinterpret_cast<f32x4*>(dst) = yv;
-                    else { dst[0] = yv[0]; dst[1] = yv[1]; dst[2] = yv[2]; dst[3] = yv[3]; }
+                if (a.y_vec4) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yv), yrsrc, (int)y_voff[i][j], nt * 64, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[e]), yrsrc,
+                                                              (int)y_voff[i][j], nt * 64 + e * 4, 0);
                 }
             }
         }
     }
+#undef WSUB
 }
 
 // ---------------------------------------------------------------- weight transform + packing
@@ -328,7 +360,9 @@ extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packe
     if (Cin_phys % 16 || Cout % 16) return PWC_EUNSUPPORTED;
     if (x_cs < Cin_phys || y_cs < Cout) return PWC_EINVAL;
     if ((x_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(packed_u) || !pwc_aligned16(bias)) return PWC_EALIGN;
-    if ((long)H * W * x_cs >= (1L << 31)) return PWC_ERANGE;
+    // per-image slabs are addressed with 32-bit byte offsets through buffer resources
+    if ((long)H * W * x_cs * 4 >= (long)WN_OOB || (long)H * W * y_cs * 4 >= (long)WN_OOB) return PWC_ERANGE;
+    if ((long)16 * Cin_phys * ((Cout + 15) & ~15) * 4 >= (long)WN_OOB) return PWC_ERANGE;
     WinoArgs a;
     a.x = x; a.up = packed_u; a.bias = bias; a.y = y; a.x_cs = x_cs; a.y_cs = y_cs;
     a.N = N; a.H = H; a.W = W; a.Cin_phys = Cin_phys; a.Cout = Cout;
@@ -344,10 +378,10 @@ extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packe
     // measured (scripts/exp_wino.hip): one LDS stage with 2 co-resident workgroups per CU beats both a
     // double-buffered stage (1 workgroup per CU) and a split-weights pipeline
     if (bn == 32)
-        hipLaunchKernelGGL((conv3x3_wino_kernel<1, 0, 2>), dim3((unsigned)nblk), dim3(256),
+        hipLaunchKernelGGL((conv3x3_wino_kernel<0, 2>), dim3((unsigned)nblk), dim3(256),
                            (size_t)WinoGeom<2>::STAGE * sizeof(float), (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL((conv3x3_wino_kernel<1, 0, 1>), dim3((unsigned)nblk), dim3(256),
+        hipLaunchKernelGGL((conv3x3_wino_kernel<0, 1>), dim3((unsigned)nblk), dim3(256),
                            (size_t)WinoGeom<1>::STAGE * sizeof(float), (hipStream_t)stream, a);
     return pwc_launch_status();
 }

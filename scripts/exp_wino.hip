@@ -6,7 +6,7 @@ template <typename K>
 static float run(K kern, const WinoArgs& a, long nblk, size_t lds, int iters) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, 0, a);
+    for (int i = 0; i < (iters > 1 ? 3 : 1); ++i) hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, 0, a);
     hipEventRecord(s);
     for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, 0, a);
     hipEventRecord(e); hipEventSynchronize(e);
@@ -16,7 +16,8 @@ static double checksum(const float* d, size_t n) {
     std::vector<float> h(n); hipMemcpy(h.data(), d, n * 4, hipMemcpyDeviceToHost);
     double s = 0; for (size_t i = 0; i < n; i += 5) s += (double)h[i] * (1 + (i % 11)); return s;
 }
-int main() {
+int main(int argc, char** argv) {
+    const bool pmc = argc > 1;   // counter-collection mode: a few launches per variant
     const int N = 8, H = 112, W = 256, C = 128, CO = 128;
     const size_t nx = (size_t)N * H * W * C, nu = (size_t)16 * C * CO;
     float *x, *u, *b, *y;
@@ -30,21 +31,23 @@ int main() {
     const double gf = 2.0 * N * H * W * 9.0 * C * CO / 1e9;
     const size_t L1 = (size_t)WinoGeom<2>::STAGE * 4;
     // interleaved A/B rounds without idle gaps (a D2H copy between runs lets the clocks drop)
-    const char* names[] = {"base(prefetch)", "no prefetch", "stagger", "setprio+stagger", "noDMA", "noMFMA", "none"};
+    const char* names[] = {"base", "no transform", "noDMA no transform", "base again", "noDMA", "noMFMA", "none"};
     float best[7]; for (auto& v : best) v = 1e9f;
-    for (int round = 0; round < 6; ++round) {
+    for (int round = 0; round < (pmc ? 1 : 5); ++round) {
         float t[7];
-        t[0] = run(conv3x3_wino_kernel<1, 0>, a, nblk, L1, 10);
-        t[1] = run(conv3x3_wino_kernel<1, 32>, a, nblk, L1, 10);
-        t[2] = run(conv3x3_wino_kernel<1, 16>, a, nblk, L1, 10);
-        t[3] = run(conv3x3_wino_kernel<1, 24>, a, nblk, L1, 10);
-        t[4] = run(conv3x3_wino_kernel<1, 3>, a, nblk, L1, 10);
-        t[5] = run(conv3x3_wino_kernel<1, 4>, a, nblk, L1, 10);
-        t[6] = run(conv3x3_wino_kernel<1, 7>, a, nblk, L1, 10);
+        t[0] = run(conv3x3_wino_kernel<0>, a, nblk, L1, pmc ? 1 : 10);
+        t[1] = run(conv3x3_wino_kernel<64>, a, nblk, L1, pmc ? 1 : 10);
+        t[2] = run(conv3x3_wino_kernel<67>, a, nblk, L1, pmc ? 1 : 10);
+        t[3] = run(conv3x3_wino_kernel<0>, a, nblk, L1, pmc ? 1 : 10);
+        t[4] = run(conv3x3_wino_kernel<3>, a, nblk, L1, pmc ? 1 : 10);
+        t[5] = run(conv3x3_wino_kernel<4>, a, nblk, L1, pmc ? 1 : 10);
+        t[6] = run(conv3x3_wino_kernel<7>, a, nblk, L1, pmc ? 1 : 10);
         printf("round %d:", round);
         for (int i = 0; i < 7; ++i) { printf(" %s %.1f |", names[i], t[i]); if (t[i] < best[i]) best[i] = t[i]; }
         printf("\n");
     }
+    run(conv3x3_wino_kernel<0>, a, nblk, L1, 1);
+    printf("checksum %.3f (reference value of this input: 71486133.074)\n", checksum(y, (size_t)N * H * W * CO));
     printf("best:");
     for (int i = 0; i < 7; ++i) printf(" %s %.1f (%.1f eff TF) |", names[i], best[i], gf / best[i] * 1e3);
     printf("\n");
