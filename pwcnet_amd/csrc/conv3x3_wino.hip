@@ -55,15 +55,15 @@ __device__ __forceinline__ int wpswz(int row) { return (row >> 1) & 2; }
 
 constexpr int WN_PW = 18;                 // patch width/height in pixels (8 tiles * 2 + 2)
 constexpr int WN_PS = 20;                 // LDS rows per patch row
-constexpr int WN_PRP = 368;               // 18 * 20 = 360 rows, padded to 23 DMA blocks of 16 rows
-constexpr int WN_NBP = WN_PRP / 16;       // 23
+constexpr int WN_PRP = 384;               // 18 * 20 = 360 rows, padded to 24 DMA blocks of 16 rows (6 per wave)
+constexpr int WN_NBP = WN_PRP / 16;       // 24
 constexpr unsigned WN_OOB = 0x7FFF0000u;  // byte offset beyond every buffer: loads return 0, stores are dropped
 // NT = 16-cout MFMA tiles per workgroup (2: 32 output channels, 1: 16)
 template <int NT> struct WinoGeom {
     static constexpr int BN = 16 * NT;                // output channels per workgroup
     static constexpr int UROWS = 16 * BN;             // weight rows (xi, cout) per stage
     static constexpr int NBU = UROWS / 16;
-    static constexpr int STAGE = (WN_PRP + UROWS) * 16;   // floats per LDS stage (NT = 2: 56 320 B)
+    static constexpr int STAGE = (WN_PRP + UROWS) * 16;   // floats per LDS stage (NT = 2: 57 344 B)
 };
 
 template <bool B> struct WinoBool { static constexpr bool value = B; };
@@ -84,7 +84,9 @@ __device__ __forceinline__ float wino_minus_one() {
 
 // ABL (scripts/exp_wino.hip only, 0 in the library): 1 = no patch DMA, 2 = no weight DMA, 4 = no MFMA,
 // 64 = no input transform
-template <int ABL = 0, int NT = 2>
+// PIPE = 1: the stage is fetched in three parts (patch, weights of positions 0-7, of 8-15), each
+// re-fetched for the next stage as soon as its LDS region is free, one barrier per part.
+template <int ABL = 0, int NT = 2, int PIPE = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) {
     constexpr int WN_BN = WinoGeom<NT>::BN, WN_NBU = WinoGeom<NT>::NBU;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -126,9 +128,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
         (void*)(a.x + (size_t)n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.up, 0, 16 * a.Cin_phys * Cout_pad * 4, 0x00020000);
-    constexpr int PPW = (WN_NBP + 3) / 4;          // patch blocks per wave (6; wave 3 has 5)
+    constexpr int PPW = WN_NBP / 4;                // patch blocks per wave (6)
     constexpr int UPW = WN_NBU / 4;                // weight blocks per wave (8 for NT = 2)
-    static_assert(WN_NBU % 4 == 0, "weight blocks must split evenly over the waves");
+    constexpr int UH = UPW / 2;                    // ... per half of the positions
+    static_assert(WN_NBU % 8 == 0 && WN_NBP % 4 == 0, "blocks must split evenly over the waves");
     unsigned p_voff[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
@@ -152,20 +155,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
         u_voff = (n0 + co < Cout_pad) ? (unsigned)((((xi * nc16) * Cout_pad + n0 + co) * 16 + (lane & 3) * 4) * 4) : WN_OOB;
     }
     const int u_step = (64 / WN_BN) * nc16 * Cout_pad * 64;       // bytes between a wave's consecutive weight blocks
-    auto issue_stage = [&](int c16) {
-        const int xs = c16 * 64, us = c16 * Cout_pad * 64;
+    auto issue_patch = [&](int c16) {
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int b = wave + 4 * i;
-            if (b < WN_NBP && !(ABL & 1))
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(smem + b * 256), 16, (int)p_voff[i], xs, 0, 0);
-        }
+        for (int i = 0; i < PPW; ++i)
+            if (!(ABL & 1))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(smem + (wave + 4 * i) * 256), 16, (int)p_voff[i],
+                                                         c16 * 64, 0, 0);
+    };
+    auto issue_u = [&](int c16, int half) {        // half 0: positions 0-7, 1: positions 8-15
+        const int us = c16 * Cout_pad * 64;
 #pragma unroll
-        for (int i = 0; i < UPW; ++i)
+        for (int i = half * UH; i < (half + 1) * UH; ++i)
             if (!(ABL & 2))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lptr_t)(smem + (WN_NBP + wave + 4 * i) * 256), 16,
                                                          (int)u_voff, us + i * u_step, 0, 0);
     };
+    // s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8])
+#define WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
 
     // ---- this lane's tile and its 16 patch read offsets (floats, swizzled for k-slot fq)
     const int tr = 2 * wave + (fr >> 3), tc = fr & 7;
@@ -183,10 +189,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
     // one 16-channel stage; FIRST: the accumulators start from the MFMA's zero C operand
     auto stage = [&](auto first, int c16) {
         constexpr bool FIRST = decltype(first)::value;
-        __syncthreads();                             // previous stage fully read
-        issue_stage(c16);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        const bool has_next = c16 + 1 < nc16;
+        if (PIPE) {
+            WAIT_VM(UH);                             // patch(c) landed (weights A(c) may be in flight)
+            __syncthreads();                         // ... for every wave; positions 8-15 of c-1 fully read
+            issue_u(c16, 1);
+        } else {
+            __syncthreads();                         // previous stage fully read
+            issue_patch(c16); issue_u(c16, 0); issue_u(c16, 1);
+            WAIT_VM(0);
+            __syncthreads();
+        }
 
         // ---- input transform  V = B^T d B  (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]), in place
         f32x4 v[4][4];
@@ -216,27 +229,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) asm("" : "+v"(v[i][j]));
         }
-        // ---- 16 positions x NT cout tiles x 4 k-steps of MFMA
+        // ---- 16 positions x NT cout tiles x 4 k-steps of MFMA, in two halves of 8 positions
+        auto mfma_half = [&](int h) {
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
-            f32x4 wf[NT];
+            for (int xi = 8 * h; xi < 8 * h + 8; ++xi) {
+                f32x4 wf[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                wf[nt] = *reinterpret_cast<const f32x4*>(smem + u_off + (xi * WN_BN + nt * 16) * 16);
+                for (int nt = 0; nt < NT; ++nt)
+                    wf[nt] = *reinterpret_cast<const f32x4*>(smem + u_off + (xi * WN_BN + nt * 16) * 16);
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    if (ABL & 4) {
-                        if (FIRST && k == 0) acc[xi][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        asm volatile("" ::"v"(wf[nt][k]), "v"(v[xi >> 2][xi & 3][k]));
-                        continue;
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if (ABL & 4) {
+                            if (FIRST && k == 0) acc[xi][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            asm volatile("" ::"v"(wf[nt][k]), "v"(v[xi >> 2][xi & 3][k]));
+                            continue;
+                        }
+                        const f32x4 c = (FIRST && k == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[xi][nt];
+                        acc[xi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][k], v[xi >> 2][xi & 3][k], c, 0, 0, 0);
                     }
-                    const f32x4 c = (FIRST && k == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[xi][nt];
-                    acc[xi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][k], v[xi >> 2][xi & 3][k], c, 0, 0, 0);
-                }
+            }
+        };
+        if (PIPE) {
+            WAIT_VM(UH);                             // weights A(c) landed (B(c) may be in flight)
+            __syncthreads();                         // ... for every wave; patch(c) fully read
+            if (has_next) issue_patch(c16 + 1);
         }
+        mfma_half(0);
+        if (PIPE) {
+            if (has_next) WAIT_VM(PPW); else WAIT_VM(0);   // weights B(c) landed (patch(c+1) may be in flight)
+            __syncthreads();                         // ... for every wave; positions 0-7 of c fully read
+            if (has_next) issue_u(c16 + 1, 0);
+        }
+        mfma_half(1);
     };
+    if (PIPE) { issue_patch(0); issue_u(0, 0); }
     stage(WinoBool<true>{}, 0);
     for (int c16 = 1; c16 < nc16; ++c16) stage(WinoBool<false>{}, c16);
 
@@ -294,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
         }
     }
 #undef WSUB
+#undef WAIT_VM
 }
 
 // ---------------------------------------------------------------- weight transform + packing
@@ -378,10 +407,10 @@ extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packe
     // measured (scripts/exp_wino.hip): one LDS stage with 2 co-resident workgroups per CU beats both a
     // double-buffered stage (1 workgroup per CU) and a split-weights pipeline
     if (bn == 32)
-        hipLaunchKernelGGL((conv3x3_wino_kernel<0, 2>), dim3((unsigned)nblk), dim3(256),
+        hipLaunchKernelGGL((conv3x3_wino_kernel<0, 2, 1>), dim3((unsigned)nblk), dim3(256),
                            (size_t)WinoGeom<2>::STAGE * sizeof(float), (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL((conv3x3_wino_kernel<0, 1>), dim3((unsigned)nblk), dim3(256),
+        hipLaunchKernelGGL((conv3x3_wino_kernel<0, 1, 1>), dim3((unsigned)nblk), dim3(256),
                            (size_t)WinoGeom<1>::STAGE * sizeof(float), (hipStream_t)stream, a);
     return pwc_launch_status();
 }
