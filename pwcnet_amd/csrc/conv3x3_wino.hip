@@ -53,17 +53,21 @@ __device__ __forceinline__ int wswz(int row) { return (4 - ((row >> 2) & 3)) & 3
 // 16 patch reads of a stage: SQ_LDS_BANK_CONFLICT = 40 % of SQ_LDS_IDX_ACTIVE.)
 __device__ __forceinline__ int wpswz(int row) { return (row >> 1) & 2; }
 
-constexpr int WN_PW = 18;                 // patch width/height in pixels (8 tiles * 2 + 2)
+constexpr int WN_PW = 18;                 // patch width in pixels (8 tiles * 2 + 2)
 constexpr int WN_PS = 20;                 // LDS rows per patch row
-constexpr int WN_PRP = 384;               // 18 * 20 = 360 rows, padded to 24 DMA blocks of 16 rows (6 per wave)
-constexpr int WN_NBP = WN_PRP / 16;       // 24
 constexpr unsigned WN_OOB = 0x7FFF0000u;  // byte offset beyond every buffer: loads return 0, stores are dropped
-// NT = 16-cout MFMA tiles per workgroup (2: 32 output channels, 1: 16)
-template <int NT> struct WinoGeom {
+// NT = 16-cout MFMA tiles per workgroup (2: 32 output channels, 1: 16).
+// SPLIT = 1: the 8 tile rows of the workgroup are 4 + 4 rows of TWO sub-lattice images (for dilated
+// convs whose sub-lattices are at most 8 pixels high, e.g. d = 16 on a 112-row level: 7 x 16-pixel
+// sub-lattices would fill 44 % of a 16 x 16 block); the patch then has 2 x (8 + 2) pixel rows.
+template <int NT, int SPLIT = 0> struct WinoGeom {
     static constexpr int BN = 16 * NT;                // output channels per workgroup
     static constexpr int UROWS = 16 * BN;             // weight rows (xi, cout) per stage
     static constexpr int NBU = UROWS / 16;
-    static constexpr int STAGE = (WN_PRP + UROWS) * 16;   // floats per LDS stage (NT = 2: 57 344 B)
+    static constexpr int PH = SPLIT ? 20 : 18;        // patch height in pixels
+    static constexpr int PRP = SPLIT ? 448 : 384;     // PH * 20 LDS rows, padded to a multiple of 64 (16-row DMA blocks x 4 waves)
+    static constexpr int NBP = PRP / 16;
+    static constexpr int STAGE = (PRP + UROWS) * 16;  // floats per LDS stage (NT = 2: 57 344 B, SPLIT: 61 440 B)
 };
 
 template <bool B> struct WinoBool { static constexpr bool value = B; };
@@ -86,9 +90,10 @@ __device__ __forceinline__ float wino_minus_one() {
 // 64 = no input transform
 // PIPE = 1: the stage is fetched in three parts (patch, weights of positions 0-7, of 8-15), each
 // re-fetched for the next stage as soon as its LDS region is free, one barrier per part.
-template <int ABL = 0, int NT = 2, int PIPE = 0>
+template <int ABL = 0, int NT = 2, int PIPE = 0, int SPLIT = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) {
-    constexpr int WN_BN = WinoGeom<NT>::BN, WN_NBU = WinoGeom<NT>::NBU;
+    typedef WinoGeom<NT, SPLIT> Geo;
+    constexpr int WN_BN = Geo::BN, WN_NBU = Geo::NBU, WN_PRP = Geo::PRP, WN_NBP = Geo::NBP, WN_PH = Geo::PH;
     typedef __attribute__((address_space(3))) void* lptr_t;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -112,9 +117,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
     const int by = rest % a.tiles_y;
     rest /= a.tiles_y;
     const int d = a.dil;
-    const int sub = rest % (d * d);                // sub-lattice (y mod d, x mod d) of a dilated conv
-    const int n = rest / (d * d);
-    const int ry = sub / d, rx = sub - ry * d;
+    const int nsub = SPLIT ? (d * d) >> 1 : d * d;   // sub-lattices (SPLIT: pairs of them) of a dilated conv
+    const int sub = rest % nsub;
+    const int n = rest / nsub;
+    // sub-lattice (y mod d, x mod d) of tile-row group g (SPLIT: g = 0 for tile rows 0-3, 1 for 4-7)
+    const int sub_g[2] = {SPLIT ? 2 * sub : sub, SPLIT ? 2 * sub + 1 : sub};
+    const int ry_g[2] = {sub_g[0] / d, sub_g[1] / d};
+    const int rx_g[2] = {sub_g[0] - ry_g[0] * d, sub_g[1] - ry_g[1] * d};
     const int y0 = by * 16, x0 = bx * 16;          // output origin of the block, in sub-lattice coordinates
     const int n0 = cb * WN_BN;
     const int Cout_pad = (a.Cout + 15) & ~15;
@@ -140,9 +149,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
         const int py = pr / WN_PS, rem = pr - py * WN_PS;
         const int half = rem >= WN_PS / 2 ? 1 : 0, col = rem - half * (WN_PS / 2);
         const int px = 2 * col + half;
-        const int y = ry + d * (y0 - 1 + py), x = rx + d * (x0 - 1 + px);
+        const int g = SPLIT ? (py >= 10 ? 1 : 0) : 0, pyl = py - 10 * g;   // SPLIT: patch rows 0-9 / 10-19
+        const int y = ry_g[g] + d * (y0 - 1 + pyl), x = rx_g[g] + d * (x0 - 1 + px);
         const int ch = (lane & 3) ^ wpswz(pr);                     // source chunk for this LDS slot
-        const bool ok = py < WN_PW && col < WN_PW / 2 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        const bool ok = py < WN_PH && col < WN_PW / 2 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
         p_voff[i] = ok ? (unsigned)(((y * a.W + x) * a.x_cs + ch * 4) * 4) : WN_OOB;
     }
     // weight blocks: block wave + 4*i holds rows (xi, cout) = ((wave + 4*i) * 16 + lane/4); 4 blocks
@@ -180,7 +190,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int row = (2 * tr + i) * WN_PS + (j & 1) * (WN_PS / 2) + tc + (j >> 1);
+            const int prow = SPLIT ? (tr >> 2) * 10 + 2 * (tr & 3) + i : 2 * tr + i;
+            const int row = prow * WN_PS + (j & 1) * (WN_PS / 2) + tc + (j >> 1);
             poff[i][j] = row * 16 + ((fq ^ wpswz(row)) << 2);
         }
     const int u_off = WN_PRP * 16 + fr * 16 + ((fq ^ wswz(fr)) << 2);   // A-fragment row fr of a 16-row tile
@@ -273,7 +284,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
     // range check (no divergent branches)
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.y + (size_t)n * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
-    const int py0 = ry + d * (y0 + 2 * tr), px0 = rx + d * (x0 + 2 * tc);   // real coordinates of output (0,0)
+    const int og = SPLIT ? tr >> 2 : 0, otr = SPLIT ? tr & 3 : tr;
+    const int py0 = ry_g[og] + d * (y0 + 2 * otr), px0 = rx_g[og] + d * (x0 + 2 * tc);   // real coordinates of output (0,0)
     unsigned y_voff[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -375,10 +387,16 @@ extern "C" int pwc_conv3x3_wino_pack_f32(const float* w_hwio, const int32_t* cin
     return pwc_launch_status();
 }
 
+// two sub-lattice images per workgroup when they are at most 8 pixels high (see WinoGeom)
+static bool wino_split(int H, int dilation) {
+    return (dilation * dilation) % 2 == 0 && (H + dilation - 1) / dilation <= 8;
+}
+
 extern "C" long pwc_conv3x3_wino_workgroups(int N, int H, int W, int Cout, int dilation) {
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || dilation < 1 || Cout % 16) return 0;
     const long tx = ((W + dilation - 1) / dilation + 15) / 16, ty = ((H + dilation - 1) / dilation + 15) / 16;
-    return (long)N * dilation * dilation * tx * ty * (Cout % 32 == 0 ? Cout / 32 : Cout / 16);
+    const long nsub = wino_split(H, dilation) ? dilation * dilation / 2 : dilation * dilation;
+    return (long)N * nsub * tx * ty * (Cout % 32 == 0 ? Cout / 32 : Cout / 16);
 }
 
 extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packed_u, const float* bias, float* y,
@@ -402,15 +420,25 @@ extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packe
     const int bn = (Cout % 32 == 0) ? 32 : 16;
     a.ncb = Cout / bn;
     a.y_vec4 = ((y_cs & 3) == 0 && pwc_aligned16(y)) ? 1 : 0;
-    const long nblk = (long)N * dilation * dilation * a.tiles_x * a.tiles_y * a.ncb;
+    const bool split = wino_split(H, dilation);
+    const long nblk = (long)N * (split ? dilation * dilation / 2 : dilation * dilation) * a.tiles_x * a.tiles_y * a.ncb;
     if (nblk >= (1L << 31)) return PWC_ERANGE;
-    // measured (scripts/exp_wino.hip): one LDS stage with 2 co-resident workgroups per CU beats both a
-    // double-buffered stage (1 workgroup per CU) and a split-weights pipeline
-    if (bn == 32)
-        hipLaunchKernelGGL((conv3x3_wino_kernel<0, 2, 1>), dim3((unsigned)nblk), dim3(256),
-                           (size_t)WinoGeom<2>::STAGE * sizeof(float), (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL((conv3x3_wino_kernel<0, 1, 1>), dim3((unsigned)nblk), dim3(256),
-                           (size_t)WinoGeom<1>::STAGE * sizeof(float), (hipStream_t)stream, a);
+    // measured (scripts/exp_wino.hip): one LDS stage fetched in three pipelined parts with 2 co-resident
+    // workgroups per CU beats a double-buffered whole stage (1 workgroup per CU)
+#define WINO_LAUNCH(NT, SPLIT)                                                                              \
+    do {                                                                                                    \
+        const size_t lds = (size_t)WinoGeom<NT, SPLIT>::STAGE * sizeof(float);                              \
+        static bool attr_done = false;                                                                      \
+        if (!attr_done) {                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<0, NT, 1, SPLIT>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+            attr_done = true;                                                                               \
+        }                                                                                                   \
+        hipLaunchKernelGGL((conv3x3_wino_kernel<0, NT, 1, SPLIT>), dim3((unsigned)nblk), dim3(256), lds,    \
+                           (hipStream_t)stream, a);                                                         \
+    } while (0)
+    if (bn == 32) { if (split) WINO_LAUNCH(2, 1); else WINO_LAUNCH(2, 0); }
+    else          { if (split) WINO_LAUNCH(1, 1); else WINO_LAUNCH(1, 0); }
+#undef WINO_LAUNCH
     return pwc_launch_status();
 }

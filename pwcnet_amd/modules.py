@@ -332,7 +332,8 @@ def _wino_pays(L, N, H, W, cout, dilation):
     once a launch has >= ~128 workgroups of 16x16 pixels x 32 channels and its 16x16 blocks
     are reasonably filled; a dilation-d launch works on (H/d) x (W/d) sub-lattices."""
     hs, wsub = -(-H // dilation), -(-W // dilation)
-    fill = (hs * wsub) / float((-(-hs // 16) * 16) * (-(-wsub // 16) * 16))
+    rows = 8 if (hs <= 8 and (dilation * dilation) % 2 == 0) else -(-hs // 16) * 16   # two short sub-lattices share a block
+    fill = (hs * wsub) / float(rows * (-(-wsub // 16) * 16))
     return L.pwc_conv3x3_wino_workgroups(N, H, W, cout, dilation) >= 128 and fill >= 0.6
 
 

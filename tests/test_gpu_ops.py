@@ -159,7 +159,9 @@ def test_conv_winograd_vs_oracle(pa, N, H, W, cin, cout):
 
 @pytest.mark.parametrize("N,H,W,cin,cout,dil", [
     (1, 40, 48, 128, 128, 2), (1, 40, 48, 128, 96, 4), (1, 56, 64, 64, 32, 8), (2, 19, 23, 32, 64, 3),
-    (1, 33, 47, 16, 32, 16)])
+    (1, 33, 47, 16, 32, 16),
+    # sub-lattices at most 8 pixels high: two of them share a workgroup (SPLIT kernels)
+    (1, 112, 256, 96, 64, 16), (2, 14, 40, 32, 16, 2), (1, 16, 16, 16, 32, 2), (1, 15, 9, 48, 48, 4)])
 def test_conv_winograd_dilated_vs_oracle(pa, N, H, W, cin, cout, dil):
     x = rnd((N, H, W, cin), 77)
     k = rnd((3, 3, cin, cout), 78) * float(1.0 / np.sqrt(9 * cin))
