@@ -27,6 +27,10 @@
 //   read as zeros (SAME padding).
 #include "pwc_common.h"
 
+#ifndef WINO_BN32_MIN_WG
+#define WINO_BN32_MIN_WG 384
+#endif
+
 struct WinoArgs {
     const float* x;
     const float* up;     // packed transformed weights [xi 16][c16][Cout_pad][16], chunk-swizzled
@@ -387,6 +391,13 @@ extern "C" int pwc_conv3x3_wino_pack_f32(const float* w_hwio, const int32_t* cin
     return pwc_launch_status();
 }
 
+// output channels per workgroup: 32, or 16 when 32 would leave most of the 512 workgroup slots
+// (256 CUs x 2) empty -- measured on the 28 x 64 level (14 336 pixels): 16 is faster below ~384 workgroups
+static int wino_bn(long pix_blocks, int Cout) {
+    if (Cout % 32) return 16;
+    return pix_blocks * (Cout / 32) >= WINO_BN32_MIN_WG ? 32 : 16;
+}
+
 // two sub-lattice images per workgroup when they are at most 8 pixels high (see WinoGeom)
 static bool wino_split(int H, int dilation) {
     return (dilation * dilation) % 2 == 0 && (H + dilation - 1) / dilation <= 8;
@@ -396,7 +407,8 @@ extern "C" long pwc_conv3x3_wino_workgroups(int N, int H, int W, int Cout, int d
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || dilation < 1 || Cout % 16) return 0;
     const long tx = ((W + dilation - 1) / dilation + 15) / 16, ty = ((H + dilation - 1) / dilation + 15) / 16;
     const long nsub = wino_split(H, dilation) ? dilation * dilation / 2 : dilation * dilation;
-    return (long)N * nsub * tx * ty * (Cout % 32 == 0 ? Cout / 32 : Cout / 16);
+    const long pix_blocks = (long)N * nsub * tx * ty;
+    return pix_blocks * (Cout / wino_bn(pix_blocks, Cout));
 }
 
 extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packed_u, const float* bias, float* y,
@@ -417,7 +429,8 @@ extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packe
     a.dil = dilation;
     a.tiles_x = ((W + dilation - 1) / dilation + 15) / 16;
     a.tiles_y = ((H + dilation - 1) / dilation + 15) / 16;
-    const int bn = (Cout % 32 == 0) ? 32 : 16;
+    const int bn = wino_bn((long)N * (wino_split(H, dilation) ? dilation * dilation / 2 : dilation * dilation) *
+                               a.tiles_x * a.tiles_y, Cout);
     a.ncb = Cout / bn;
     a.y_vec4 = ((y_cs & 3) == 0 && pwc_aligned16(y)) ? 1 : 0;
     const bool split = wino_split(H, dilation);

@@ -328,13 +328,14 @@ def _workspace(device, want_floats):
 
 
 def _wino_pays(L, N, H, W, cout, dilation):
-    """Measured on MI355X (scripts/tune_conv.py --wino): the Winograd kernel wins (1.4-1.8x)
-    once a launch has >= ~128 workgroups of 16x16 pixels x 32 channels and its 16x16 blocks
-    are reasonably filled; a dilation-d launch works on (H/d) x (W/d) sub-lattices."""
+    """Measured on MI355X (scripts/tune_conv.py --wino): the Winograd kernel wins (1.1-2.2x)
+    from the 14x32 pyramid level upwards, i.e. whenever its 16x16-pixel blocks are reasonably
+    filled (the 7x16 level fills 44 % and loses to the split-K direct kernel); a dilation-d
+    launch works on (H/d) x (W/d) sub-lattices."""
     hs, wsub = -(-H // dilation), -(-W // dilation)
     rows = 8 if (hs <= 8 and (dilation * dilation) % 2 == 0) else -(-hs // 16) * 16   # two short sub-lattices share a block
     fill = (hs * wsub) / float(rows * (-(-wsub // 16) * 16))
-    return L.pwc_conv3x3_wino_workgroups(N, H, W, cout, dilation) >= 128 and fill >= 0.6
+    return L.pwc_conv3x3_wino_workgroups(N, H, W, cout, dilation) >= 24 and fill >= 0.6
 
 
 def _mfma_kernel_name(L, M, cout, cin_phys, tile, split):
