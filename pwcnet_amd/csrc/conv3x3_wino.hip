@@ -298,7 +298,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
             const int py = py0 + i * d, px = px0 + j * d;
             y_voff[i][j] = (py < a.H && px < a.W) ? (unsigned)(((py * a.W + px) * a.y_cs + n0 + fq * 4) * 4) : WN_OOB;
         }
-    const bool slope_max = a.slope <= 1.f;           // leaky-relu(v) == max(v, slope*v) then
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0 + nt * 16 + fq * 4;
@@ -316,23 +315,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
             for (int j = 0; j < 2; ++j) {
                 f32x4 yv = (j == 0) ? s[i][0] + s[i][1] + s[i][2] : WSUB(WSUB(s[i][1], s[i][2]), s[i][3]);
                 yv += b4;
-                if (a.apply_act) {
-                    if (slope_max) {
-                        const f32x4 sv = yv * a.slope;
-                        yv[0] = fmaxf(yv[0], sv[0]); yv[1] = fmaxf(yv[1], sv[1]);
-                        yv[2] = fmaxf(yv[2], sv[2]); yv[3] = fmaxf(yv[3], sv[3]);
-                    } else {
-                        yv[0] = pwc_lrelu(yv[0], a.slope); yv[1] = pwc_lrelu(yv[1], a.slope);
-                        yv[2] = pwc_lrelu(yv[2], a.slope); yv[3] = pwc_lrelu(yv[3], a.slope);
-                    }
+                if (a.apply_act) {               // tf.nn.leaky_relu = max(v, slope * v)
+                    const f32x4 sv = yv * a.slope;
+                    yv[0] = fmaxf(yv[0], sv[0]); yv[1] = fmaxf(yv[1], sv[1]);
+                    yv[2] = fmaxf(yv[2], sv[2]); yv[3] = fmaxf(yv[3], sv[3]);
                 }
                 if (a.y_vec4) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yv), yrsrc, (int)y_voff[i][j], nt * 64, 0);
                 } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[e]), yrsrc,
-                                                              (int)y_voff[i][j], nt * 64 + e * 4, 0);
+                    const u32x4 yu = __builtin_bit_cast(u32x4, yv);
+                    __builtin_amdgcn_raw_buffer_store_b32(yu[0], yrsrc, (int)y_voff[i][j], nt * 64 + 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(yu[1], yrsrc, (int)y_voff[i][j], nt * 64 + 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(yu[2], yrsrc, (int)y_voff[i][j], nt * 64 + 8, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(yu[3], yrsrc, (int)y_voff[i][j], nt * 64 + 12, 0);
                 }
             }
         }

@@ -169,6 +169,19 @@ def test_conv_winograd_dilated_vs_oracle(pa, N, H, W, cin, cout, dil):
     close(run_conv_wino(x, k, b, 0.1, dil=dil), orc.conv3x3(x, k, b, 1, dil, 0.1), rel=2e-5)
 
 
+def test_conv_winograd_unaligned_output_stride_and_slopes(pa):
+    """channel stride not a multiple of 4 (scalar stores through the buffer resource); slopes > 1
+    and < 0 (tf.nn.leaky_relu is max(v, slope*v) whatever the slope)"""
+    x = rnd((2, 21, 37, 32), 91)
+    k = rnd((3, 3, 32, 48), 92) * float(1.0 / np.sqrt(9 * 32))
+    b = rnd((48,), 93) * 0.1
+    y = run_conv_wino(x, k, b, 0.1, y_cs=48 + 3)
+    close(y[..., :48], orc.conv3x3(x, k, b, 1, 1, 0.1), rel=2e-5)
+    assert float(y[..., 48:].min()) == -7.0 and float(y[..., 48:].max()) == -7.0
+    for slope in (1.5, -0.25):
+        close(run_conv_wino(x, k, b, slope), orc.conv3x3(x, k, b, 1, 1, slope), rel=2e-5)
+
+
 def test_conv_winograd_physical_layout(pa):
     from pwcnet_amd.weights import estimator_layout
     lay = estimator_layout(4, False)
