@@ -28,8 +28,132 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const DirectArgs a)
     const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int co0 = blockIdx.y * CT;
     if (m >= a.M) return;
-    // 32-bit index math throughout (the host routes here only when M and the per-image extent fit):
-    // the first version decomposed a 64-bit flat index with 64-bit divisions per pixel group
+    const long HoWo = (long)a.Ho * a.Wo;
+    const int n = (int)(m / HoWo);
+    const int rem = (int)(m - (long)n * HoWo);
+    const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+    float acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = (co0 + c < a.Cout) ? a.bias[co0 + c] : 0.f;
+    const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs;
+    for (int ty = 0; ty < 3; ++ty) {
+        const int iy = oy * a.stride - a.pad_t + ty * a.dil;
+        if ((unsigned)iy >= (unsigned)a.H) continue;
+        for (int tx = 0; tx < 3; ++tx) {
+            const int ix = ox * a.stride - a.pad_l + tx * a.dil;
+            if ((unsigned)ix >= (unsigned)a.W) continue;
+            const float* xp = xn + ((size_t)iy * a.W + ix) * a.x_cs;
+            const float* wt = a.w + (size_t)(ty * 3 + tx) * a.Cin * a.Cout + co0;
+            if (VEC4) {
+                for (int ci = 0; ci < a.Cin; ci += 4) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + ci);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float* wr = wt + (size_t)(ci + e) * a.Cout;
+#pragma unroll
+                        for (int c = 0; c < CT; ++c)
+                            if (co0 + c < a.Cout) acc[c] = fmaf(xv[e], wr[c], acc[c]);
+                    }
+                }
+            } else {
+                for (int ci = 0; ci < a.Cin; ++ci) {
+                    const float xv = xp[ci];
+                    const float* wr = wt + (size_t)ci * a.Cout;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        if (co0 + c < a.Cout) acc[c] = fmaf(xv, wr[c], acc[c]);
+                }
+            }
+        }
+    }
+    float* yo = a.y + (size_t)m * a.y_cs + co0;
+    const float* ro = a.res ? a.res + (size_t)m * a.res_cs + co0 : nullptr;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        if (co0 + c >= a.Cout) break;
+        float v = acc[c];
+        if (a.apply_act) v = pwc_lrelu(v, a.slope);
+        if (ro) v += ro[c];
+        yo[c] = v;
+    }
+}
+
+// ---------------------------------------------------------------- Cin = 3 (first layer)
+// modules.py:62, l = 0: 3 -> 16 channels, stride 2, on the full-resolution images: the
+// HBM-bound head of the extractor (reads 12 B, writes 64 B per output pixel).  Lane =
+// (output pixel, 4-channel quad): consecutive lanes store consecutive 16 bytes, so the
+// NHWC output is written in whole contiguous lines; the 27 x Cout weights sit in LDS.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv3x3_smallcin_kernel(const DirectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wlds[];   // [27*CIN/3... = 9*CIN][Cout]
+    const int nw = 9 * CIN * COUT;
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) wlds[i] = a.w[i];
+    __syncthreads();
+    constexpr int qpp = COUT >> 2;
+    const long total = a.M * qpp;
+    const long HoWo = (long)a.Ho * a.Wo;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
+         gid += (long)gridDim.x * blockDim.x) {
+        const int cq = (int)(gid % qpp);
+        const long m = gid / qpp;
+        const int n = (int)(m / HoWo);
+        const int rem = (int)(m - (long)n * HoWo);
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(a.bias + cq * 4);
+        const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+            const int iy = oy * a.stride - a.pad_t + ty * a.dil;
+            const bool yok = (unsigned)iy < (unsigned)a.H;
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const int ix = ox * a.stride - a.pad_l + tx * a.dil;
+                const bool ok = yok && ((unsigned)ix < (unsigned)a.W);
+                const float* xp = xn + ((size_t)(ok ? iy : 0) * a.W + (ok ? ix : 0)) * a.x_cs;
+                float xv[CIN];
+                if (CIN == 3) {
+                    // one 12-byte load per tap (pixels are 4-byte aligned triples)
+                    struct __attribute__((packed, aligned(4))) f3 { float x, y, z; };
+                    const f3 v = *reinterpret_cast<const f3*>(xp);
+                    xv[0] = ok ? v.x : 0.f; xv[1] = ok ? v.y : 0.f; xv[2] = ok ? v.z : 0.f;
+                } else {
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) xv[ci] = ok ? xp[ci] : 0.f;
+                }
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wlds + ((ty * 3 + tx) * CIN + ci) * COUT + cq * 4);
+                    acc += xv[ci] * w4;
+                }
+            }
+        }
+        if (a.apply_act) {
+            acc[0] = pwc_lrelu(acc[0], a.slope); acc[1] = pwc_lrelu(acc[1], a.slope);
+            acc[2] = pwc_lrelu(acc[2], a.slope); acc[3] = pwc_lrelu(acc[3], a.slope);
+        }
+        *reinterpret_cast<f32x4*>(a.y + (size_t)m * a.y_cs + cq * 4) = acc;
+    }
+}
+
+// ---------------------------------------------------------------- Cout = 2 flow heads
+// modules.py:274 / :324 (+ residual adds :275-277, :326) with Cin = 32: 8 lanes share one
+// output pixel, lane q holds input channels 4q..4q+3 (one coalesced 128-byte read per
+// pixel tap) and its 9 x 4 x 2 weights in VGPRs; the 8 partial sums are combined with
+// wave shuffles; persistent grid-stride loop over pixel groups.
+__global__ __launch_bounds__(256) void conv3x3_head2_c32_kernel(const DirectArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int q = lane & 7;
+    float w0[9][4], w1[9][4];
+    // HWIO (3,3,32,2): the 4 channels x 2 couts of lane q are 8 contiguous floats per tap
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.w + ((size_t)tap * 32 + q * 4) * 2);
+        const f32x4 lo = wp[0], hi = wp[1];
+        w0[tap][0] = lo[0]; w1[tap][0] = lo[1]; w0[tap][1] = lo[2]; w1[tap][1] = lo[3];
+        w0[tap][2] = hi[0]; w1[tap][2] = hi[1]; w0[tap][3] = hi[2]; w1[tap][3] = hi[3];
+    }
+    const float b0 = a.bias[0], b1 = a.bias[1];
+    // 32-bit index math (the host routes here only when M and the per-image extent fit in 31 bits)
     const unsigned HoWo = (unsigned)(a.Ho * a.Wo), M = (unsigned)a.M;
     const unsigned ngroups = (M + 7) / 8;               // 8 pixels per wave iteration
     const unsigned wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
