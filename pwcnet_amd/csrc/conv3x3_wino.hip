@@ -57,21 +57,28 @@ __device__ __forceinline__ int wswz(int row) { return (4 - ((row >> 2) & 3)) & 3
 // 16 patch reads of a stage: SQ_LDS_BANK_CONFLICT = 40 % of SQ_LDS_IDX_ACTIVE.)
 __device__ __forceinline__ int wpswz(int row) { return (row >> 1) & 2; }
 
-constexpr int WN_PW = 18;                 // patch width in pixels (8 tiles * 2 + 2)
-constexpr int WN_PS = 20;                 // LDS rows per patch row
 constexpr unsigned WN_OOB = 0x7FFF0000u;  // byte offset beyond every buffer: loads return 0, stores are dropped
 // NT = 16-cout MFMA tiles per workgroup (2: 32 output channels, 1: 16).
-// SPLIT = 1: the 8 tile rows of the workgroup are 4 + 4 rows of TWO sub-lattice images (for dilated
-// convs whose sub-lattices are at most 8 pixels high, e.g. d = 16 on a 112-row level: 7 x 16-pixel
-// sub-lattices would fill 44 % of a 16 x 16 block); the patch then has 2 x (8 + 2) pixel rows.
-template <int NT, int SPLIT = 0> struct WinoGeom {
+// GEO = shape of the workgroup's 64 Winograd tiles:
+//   0  8 x 8 tiles = 16 x 16 pixels (patch 18 x 18);
+//   1  SPLIT: 4 + 4 tile rows of TWO sub-lattice images (dilated convs whose sub-lattices are at
+//      most 8 pixels high, e.g. d = 16 on a 112-row level: 7 x 16-pixel sub-lattices would fill
+//      44 % of a 16 x 16 block); patch 2 x (8 + 2) rows x 18;
+//   2  WIDE: 2 x 32 tiles = 4 x 64 pixels (patch 6 x 66), for images whose height is a multiple
+//      of 4 but not of 16 (56- and 28-row levels and sub-lattices: 12.5 % of a 16-row grid is waste).
+template <int NT, int GEO = 0> struct WinoGeom {
     static constexpr int BN = 16 * NT;                // output channels per workgroup
     static constexpr int UROWS = 16 * BN;             // weight rows (xi, cout) per stage
     static constexpr int NBU = UROWS / 16;
-    static constexpr int PH = SPLIT ? 20 : 18;        // patch height in pixels
-    static constexpr int PRP = SPLIT ? 448 : 384;     // PH * 20 LDS rows, padded to a multiple of 64 (16-row DMA blocks x 4 waves)
+    static constexpr int BH = GEO == 2 ? 4 : 16, BW = GEO == 2 ? 64 : 16;   // output pixels per workgroup
+    static constexpr int PH = GEO == 2 ? 6 : GEO == 1 ? 20 : 18;           // patch height in pixels
+    static constexpr int PW = BW + 2;                                       // patch width in pixels
+    static constexpr int PS = GEO == 2 ? 68 : 20;     // LDS rows per patch row: even pixel columns, then odd ones
+    static_assert(PS / 2 >= PW / 2 && PS % 4 == 0, "patch row stride");
+    static constexpr int PRP = GEO == 0 ? 384 : 448;  // PH * PS LDS rows, padded to a multiple of 64 (16-row DMA blocks x 4 waves)
+    static_assert(PH * PS <= PRP, "patch does not fit");
     static constexpr int NBP = PRP / 16;
-    static constexpr int STAGE = (PRP + UROWS) * 16;  // floats per LDS stage (NT = 2: 57 344 B, SPLIT: 61 440 B)
+    static constexpr int STAGE = (PRP + UROWS) * 16;  // floats per LDS stage (NT = 2: 57 344 B, GEO 1/2: 61 440 B)
 };
 
 template <bool B> struct WinoBool { static constexpr bool value = B; };
@@ -94,10 +101,12 @@ __device__ __forceinline__ float wino_minus_one() {
 // 64 = no input transform
 // PIPE = 1: the stage is fetched in three parts (patch, weights of positions 0-7, of 8-15), each
 // re-fetched for the next stage as soon as its LDS region is free, one barrier per part.
-template <int ABL = 0, int NT = 2, int PIPE = 0, int SPLIT = 0>
+template <int ABL = 0, int NT = 2, int PIPE = 0, int GEO = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) {
-    typedef WinoGeom<NT, SPLIT> Geo;
+    typedef WinoGeom<NT, GEO> Geo;
+    constexpr int SPLIT = GEO == 1, WIDE = GEO == 2;
     constexpr int WN_BN = Geo::BN, WN_NBU = Geo::NBU, WN_PRP = Geo::PRP, WN_NBP = Geo::NBP, WN_PH = Geo::PH;
+    constexpr int WN_PW = Geo::PW, WN_PS = Geo::PS;
     typedef __attribute__((address_space(3))) void* lptr_t;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
     const int sub_g[2] = {SPLIT ? 2 * sub : sub, SPLIT ? 2 * sub + 1 : sub};
     const int ry_g[2] = {sub_g[0] / d, sub_g[1] / d};
     const int rx_g[2] = {sub_g[0] - ry_g[0] * d, sub_g[1] - ry_g[1] * d};
-    const int y0 = by * 16, x0 = bx * 16;          // output origin of the block, in sub-lattice coordinates
+    const int y0 = by * Geo::BH, x0 = bx * Geo::BW;   // output origin of the block, in sub-lattice coordinates
     const int n0 = cb * WN_BN;
     const int Cout_pad = (a.Cout + 15) & ~15;
     const int nc16 = a.Cin_phys >> 4;
@@ -188,7 +197,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
 #define WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
 
     // ---- this lane's tile and its 16 patch read offsets (floats, swizzled for k-slot fq)
-    const int tr = 2 * wave + (fr >> 3), tc = fr & 7;
+    // tile (tr, tc) of this lane: 8 x 8 tiles (wave = 2 tile rows) or, WIDE, 2 x 32 tiles (wave = half a row)
+    const int tr = WIDE ? wave >> 1 : 2 * wave + (fr >> 3), tc = WIDE ? (wave & 1) * 16 + fr : fr & 7;
     int poff[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -393,16 +403,30 @@ static int wino_bn(long pix_blocks, int Cout) {
     return pix_blocks * (Cout / 32) >= WINO_BN32_MIN_WG ? 32 : 16;
 }
 
-// two sub-lattice images per workgroup when they are at most 8 pixels high (see WinoGeom)
-static bool wino_split(int H, int dilation) {
-    return (dilation * dilation) % 2 == 0 && (H + dilation - 1) / dilation <= 8;
+// geometry of a launch (see WinoGeom): 1 = two sub-lattice images per workgroup when they are at most
+// 8 pixels high; 2 = 4 x 64-pixel blocks when they cover the (sub-)image with at least 5 % less
+// waste than 16 x 16 ones; 0 otherwise
+static int wino_geo(int H, int W, int dilation) {
+    const long hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
+    if ((dilation * dilation) % 2 == 0 && hs <= 8) return 1;
+    const double sq = (double)(((hs + 15) / 16) * 16) * (((ws + 15) / 16) * 16);
+    const double wd = (double)(((hs + 3) / 4) * 4) * (((ws + 63) / 64) * 64);
+    return wd < 0.95 * sq ? 2 : 0;
+}
+
+static void wino_grid(int N, int H, int W, int dilation, int geo, int* tiles_x, int* tiles_y, long* pix_blocks) {
+    const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
+    const int bh = geo == 2 ? 4 : 16, bw = geo == 2 ? 64 : 16;
+    *tiles_x = (ws + bw - 1) / bw;
+    *tiles_y = (hs + bh - 1) / bh;
+    *pix_blocks = (long)N * (geo == 1 ? dilation * dilation / 2 : dilation * dilation) * *tiles_x * *tiles_y;
 }
 
 extern "C" long pwc_conv3x3_wino_workgroups(int N, int H, int W, int Cout, int dilation) {
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || dilation < 1 || Cout % 16) return 0;
-    const long tx = ((W + dilation - 1) / dilation + 15) / 16, ty = ((H + dilation - 1) / dilation + 15) / 16;
-    const long nsub = wino_split(H, dilation) ? dilation * dilation / 2 : dilation * dilation;
-    const long pix_blocks = (long)N * nsub * tx * ty;
+    int tx, ty;
+    long pix_blocks;
+    wino_grid(N, H, W, dilation, wino_geo(H, W, dilation), &tx, &ty, &pix_blocks);
     return pix_blocks * (Cout / wino_bn(pix_blocks, Cout));
 }
 
@@ -422,31 +446,30 @@ extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packe
     a.N = N; a.H = H; a.W = W; a.Cin_phys = Cin_phys; a.Cout = Cout;
     a.apply_act = apply_act; a.slope = slope;
     a.dil = dilation;
-    a.tiles_x = ((W + dilation - 1) / dilation + 15) / 16;
-    a.tiles_y = ((H + dilation - 1) / dilation + 15) / 16;
-    const int bn = wino_bn((long)N * (wino_split(H, dilation) ? dilation * dilation / 2 : dilation * dilation) *
-                               a.tiles_x * a.tiles_y, Cout);
+    const int geo = wino_geo(H, W, dilation);
+    long pix_blocks;
+    wino_grid(N, H, W, dilation, geo, &a.tiles_x, &a.tiles_y, &pix_blocks);
+    const int bn = wino_bn(pix_blocks, Cout);
     a.ncb = Cout / bn;
     a.y_vec4 = ((y_cs & 3) == 0 && pwc_aligned16(y)) ? 1 : 0;
-    const bool split = wino_split(H, dilation);
-    const long nblk = (long)N * (split ? dilation * dilation / 2 : dilation * dilation) * a.tiles_x * a.tiles_y * a.ncb;
+    const long nblk = pix_blocks * a.ncb;
     if (nblk >= (1L << 31)) return PWC_ERANGE;
     // measured (scripts/exp_wino.hip): one LDS stage fetched in three pipelined parts with 2 co-resident
     // workgroups per CU beats a double-buffered whole stage (1 workgroup per CU)
-#define WINO_LAUNCH(NT, SPLIT)                                                                              \
+#define WINO_LAUNCH(NT, GEO)                                                                                \
     do {                                                                                                    \
-        const size_t lds = (size_t)WinoGeom<NT, SPLIT>::STAGE * sizeof(float);                              \
+        const size_t lds = (size_t)WinoGeom<NT, GEO>::STAGE * sizeof(float);                                \
         static bool attr_done = false;                                                                      \
         if (!attr_done) {                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<0, NT, 1, SPLIT>), \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<0, NT, 1, GEO>),   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
             attr_done = true;                                                                               \
         }                                                                                                   \
-        hipLaunchKernelGGL((conv3x3_wino_kernel<0, NT, 1, SPLIT>), dim3((unsigned)nblk), dim3(256), lds,    \
+        hipLaunchKernelGGL((conv3x3_wino_kernel<0, NT, 1, GEO>), dim3((unsigned)nblk), dim3(256), lds,      \
                            (hipStream_t)stream, a);                                                         \
     } while (0)
-    if (bn == 32) { if (split) WINO_LAUNCH(2, 1); else WINO_LAUNCH(2, 0); }
-    else          { if (split) WINO_LAUNCH(1, 1); else WINO_LAUNCH(1, 0); }
+    if (bn == 32) { if (geo == 1) WINO_LAUNCH(2, 1); else if (geo == 2) WINO_LAUNCH(2, 2); else WINO_LAUNCH(2, 0); }
+    else          { if (geo == 1) WINO_LAUNCH(1, 1); else if (geo == 2) WINO_LAUNCH(1, 2); else WINO_LAUNCH(1, 0); }
 #undef WINO_LAUNCH
     return pwc_launch_status();
 }

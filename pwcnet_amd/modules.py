@@ -333,8 +333,15 @@ def _wino_pays(L, N, H, W, cout, dilation):
     filled (the 7x16 level fills 44 % and loses to the split-K direct kernel); a dilation-d
     launch works on (H/d) x (W/d) sub-lattices."""
     hs, wsub = -(-H // dilation), -(-W // dilation)
-    rows = 8 if (hs <= 8 and (dilation * dilation) % 2 == 0) else -(-hs // 16) * 16   # two short sub-lattices share a block
-    fill = (hs * wsub) / float(rows * (-(-wsub // 16) * 16))
+    # block geometries of conv3x3_wino.hip (wino_geo): two short sub-lattices per 16x16 block,
+    # 4x64-pixel blocks, 16x16-pixel blocks
+    if hs <= 8 and (dilation * dilation) % 2 == 0:
+        area = 8 * (-(-wsub // 16) * 16)
+    else:
+        sq = (-(-hs // 16) * 16) * (-(-wsub // 16) * 16)
+        wd = (-(-hs // 4) * 4) * (-(-wsub // 64) * 64)
+        area = wd if wd < 0.95 * sq else sq
+    fill = (hs * wsub) / float(area)
     return L.pwc_conv3x3_wino_workgroups(N, H, W, cout, dilation) >= 24 and fill >= 0.6
 
 

@@ -146,7 +146,9 @@ def run_conv_wino(x, k, b, slope, cin_map=None, y_cs=None, dil=1):
 
 @pytest.mark.parametrize("N,H,W,cin,cout", [
     (2, 16, 16, 16, 32), (1, 32, 48, 32, 64), (2, 7, 16, 192, 192), (1, 14, 32, 128, 96), (1, 28, 64, 96, 64),
-    (1, 33, 21, 64, 32), (1, 5, 3, 16, 32), (2, 56, 128, 160, 128), (2, 40, 70, 16, 16), (1, 20, 30, 32, 48)])
+    (1, 33, 21, 64, 32), (1, 5, 3, 16, 32), (2, 56, 128, 160, 128), (2, 40, 70, 16, 16), (1, 20, 30, 32, 48),
+    # 4x64-pixel block geometry (height a multiple of 4, not of 16), incl. ragged right edges
+    (1, 28, 64, 96, 64), (2, 56, 128, 32, 16), (1, 20, 130, 16, 32), (1, 36, 200, 48, 48)])
 def test_conv_winograd_vs_oracle(pa, N, H, W, cin, cout):
     x = rnd((N, H, W, cin), 71)
     k = rnd((3, 3, cin, cout), 72) * float(1.0 / np.sqrt(9 * cin))
@@ -161,7 +163,9 @@ def test_conv_winograd_vs_oracle(pa, N, H, W, cin, cout):
     (1, 40, 48, 128, 128, 2), (1, 40, 48, 128, 96, 4), (1, 56, 64, 64, 32, 8), (2, 19, 23, 32, 64, 3),
     (1, 33, 47, 16, 32, 16),
     # sub-lattices at most 8 pixels high: two of them share a workgroup (SPLIT kernels)
-    (1, 112, 256, 96, 64, 16), (2, 14, 40, 32, 16, 2), (1, 16, 16, 16, 32, 2), (1, 15, 9, 48, 48, 4)])
+    (1, 112, 256, 96, 64, 16), (2, 14, 40, 32, 16, 2), (1, 16, 16, 16, 32, 2), (1, 15, 9, 48, 48, 4),
+    # dilated + 4x64-pixel blocks (sub-lattices 56x128, 28x64)
+    (1, 112, 256, 32, 32, 2), (1, 112, 256, 16, 32, 4)])
 def test_conv_winograd_dilated_vs_oracle(pa, N, H, W, cin, cout, dil):
     x = rnd((N, H, W, cin), 77)
     k = rnd((3, 3, cin, cout), 78) * float(1.0 / np.sqrt(9 * cin))
