@@ -281,13 +281,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
             __syncthreads();                         // ... for every wave; patch(c) fully read
             if (has_next) issue_patch(c16 + 1);
         }
+        if (ABL & 8) __builtin_amdgcn_s_setprio(1);
         mfma_half(0);
+        if (ABL & 8) __builtin_amdgcn_s_setprio(0);
         if (PIPE) {
             if (has_next) WAIT_VM(PPW); else WAIT_VM(0);   // weights B(c) landed (patch(c+1) may be in flight)
             __syncthreads();                         // ... for every wave; positions 0-7 of c fully read
             if (has_next) issue_u(c16 + 1, 0);
         }
+        if (ABL & 8) __builtin_amdgcn_s_setprio(1);
         mfma_half(1);
+        if (ABL & 8) __builtin_amdgcn_s_setprio(0);
     };
     if (PIPE) { issue_patch(0); issue_u(0, 0); }
     stage(WinoBool<true>{}, 0);

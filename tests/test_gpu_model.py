@@ -247,6 +247,44 @@ def test_infer_cli_end_to_end(pa, tmp_path):
     assert all(os.path.exists(tmp_path / "o" / f"flow_level{l}.png") for l in range(5))
 
 
+def test_evaluate_cli_end_to_end(pa, tmp_path):
+    """evaluate.py: list of PNG pairs + ground-truth .flo -> sharded forward ->
+    EPE; with the oracle's own flows as ground truth the EPE must vanish, and the saved flows
+    must equal the oracle's."""
+    import json, subprocess, sys
+    from PIL import Image
+    from pwcnet_amd import ckpt, flow_io
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.RandomState(11)
+    w = util.model_weights(False)
+    ckpt.save_weights(str(tmp_path / "m.ckpt"), w)
+    net = orc.OraclePWCDCNet(w)
+    lines, gts = [], []
+    for i in range(3):
+        a = rng.uniform(0, 255, size=(64, 128, 3)).astype(np.uint8)
+        b = np.roll(a, i + 1, axis=1)
+        Image.fromarray(a).save(tmp_path / f"a{i}.png")
+        Image.fromarray(b).save(tmp_path / f"b{i}.png")
+        im = np.stack([a, b]).astype(np.float32) / 255.0
+        gt = net(im[0:1], im[1:2])[0][0]
+        if i == 2:
+            gt = gt + np.float32(0.5)                      # a known error on the last pair: |(.5,.5)| = 0.7071
+        flow_io.write_flo(str(tmp_path / f"gt{i}.flo"), gt)
+        gts.append(gt)
+        lines.append(f"{tmp_path / f'a{i}.png'} {tmp_path / f'b{i}.png'} {tmp_path / f'gt{i}.flo'}")
+    (tmp_path / "pairs.txt").write_text("\n".join(lines) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(root, "evaluate.py"), "--list", str(tmp_path / "pairs.txt"),
+                          "--resume", str(tmp_path / "m.ckpt"), "--batch", "2", "--save_dir", str(tmp_path / "o")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["pairs"] == 3 and res["n_gpus"] == 1
+    assert max(res["per_pair_epe"][:2]) <= 1e-3 and abs(res["per_pair_epe"][2] - 0.5 * np.sqrt(2)) <= 1e-3
+    assert abs(res["epe"] - 0.5 * np.sqrt(2) / 3) <= 1e-3
+    pred = flow_io.read_flo(str(tmp_path / "o" / "000001.flo"))
+    assert float(np.abs(pred - gts[1]).max()) <= 1e-3
+
+
 @pytest.mark.parametrize("kw", [dict(search_range=2), dict(output_level=3), dict(output_level=2, search_range=3)])
 def test_e2e_constructor_variants_vs_oracle(pa, kw):
     """non-default constructor kwargs of reference model.py:75-77: search_range changes the

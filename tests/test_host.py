@@ -194,6 +194,46 @@ def test_gather_stats_world2_gloo(tmp_path):
     assert "GATHER_OK 2.0 10.0" in out.stdout
 
 
+_EVAL_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from pwcnet_amd import sharding
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+N, h, wd = 7, 6, 10                        # 7 pairs over 2 ranks: 4 + 3
+rs = np.random.RandomState(3)
+im = rs.rand(N, 2, h, wd, 3).astype(np.float32)
+gt = rs.normal(size=(N, h, wd, 2)).astype(np.float32)
+def load_pair(i):
+    return torch.from_numpy(im[i, 0]), torch.from_numpy(im[i, 1]), torch.from_numpy(gt[i])
+def forward(a, b):                         # a stand-in "network": flow = channel differences
+    return torch.stack([(a - b)[..., 0], (a + b)[..., 1]], dim=3)
+res = sharding.evaluate_pairs(forward, load_pair, N, batch=3, dist=dist, device="cpu", gather=True)
+pred = np.stack([im[:, 0, ..., 0] - im[:, 1, ..., 0], im[:, 0, ..., 1] + im[:, 1, ..., 1]], axis=3)
+norms = np.sqrt(((gt - pred) ** 2).sum(axis=3))
+assert abs(res["epe"] - norms.mean()) < 1e-6 and res["pairs"] == N
+assert np.allclose(res["per_pair_epe"], norms.mean(axis=(1, 2)), atol=1e-6)
+assert tuple(res["flows"].shape) == (N, h, wd, 2) and np.allclose(res["flows"].numpy(), pred, atol=1e-6)
+assert abs(float(sharding.epe(torch.from_numpy(gt), torch.from_numpy(pred))) - norms.mean()) < 1e-6
+if r == 0:
+    print("EVAL_OK", w)
+dist.destroy_process_group()
+"""
+
+
+def test_sharded_evaluation_world2_gloo(tmp_path):
+    """pairs sharded 4 + 3 over two ranks, flows and EPE statistics gathered."""
+    script = tmp_path / "eval_worker.py"
+    script.write_text(_EVAL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29618", str(script), ROOT],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "EVAL_OK 2" in out.stdout
+
+
 # ------------------------------------------------------------------ flow IO (f2)
 def test_flo_round_trip_and_layout(tmp_path):
     from pwcnet_amd import flow_io
