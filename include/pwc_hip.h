@@ -70,6 +70,18 @@ int pwc_warp_nearest_f32(const float* x, int x_cs, const float* flow, int flow_c
                          float flow_scale, float* out, int out_cs,
                          int N, int H, int W, int C, pwc_stream_t stream);
 
+/* ---- a2+a1 (+ the f0 part of tf.concat, modules.py:264) for the COARSE pyramid levels ----
+ * One launch for model.py:105-112 on small feature maps (7x16 ... 28x64 pixels per image), where
+ * separate warp / cost-volume / copy launches are latency-bound: out as pwc_cost_volume_f32 of
+ * (f0, warp(f1, flow_scale*flow)); flow == NULL: no warp (pyramid level 0, model.py:105-106);
+ * f0_copy != NULL: f0's C channels are also copied to f0_copy (channel stride f0_copy_cs).
+ * search_range must be 4 (PWC_EUNSUPPORTED otherwise); alignment rules of pwc_cost_volume_f32. */
+int pwc_cost_volume_coarse_f32(const float* f0, int f0_cs, const float* f1, int f1_cs,
+                               const float* flow, int flow_cs, float flow_scale,
+                               float* out, int out_cs, float* f0_copy, int f0_copy_cs,
+                               int N, int H, int W, int C, int search_range, float slope,
+                               pwc_stream_t stream);
+
 /* ---- a2+a1 fused: model.py:109-112 (warp then cost volume) without materialising
  * the warped feature map.  f1 is the UN-warped second feature map.  Same result as
  * pwc_warp_bilinear_f32 followed by pwc_cost_volume_f32. */

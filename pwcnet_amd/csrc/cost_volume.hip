@@ -543,6 +543,197 @@ static int cv_dispatch(CvArgs& a, int R, bool fused, hipStream_t s) {
 #undef PWC_CV
 }
 
+// ---------------------------------------------------------------- coarse levels, fused
+// cost_volume_coarse_kernel: warp (optional) + cost volume + the tf.concat copy of f0, for the
+// coarse pyramid levels (7x16 ... 28x64 pixels per image).  There the persistent 4x64-tile kernel
+// above is a latency-bound chain (a 7x16 image occupies 16 workgroups that each walk 12 channel
+// stages: 40 us for 896 pixels), and the warp and copy launches cost ~6 us apiece for kilobytes.
+//
+//   workgroup  = (image n, 8x8-pixel tile, vertical shift v): 9x more workgroups than tiles, each
+//                produces the 9 horizontal shifts of its v -- 36 contiguous bytes per pixel record;
+//   loader     = per 32-channel stage every thread fetches one of the 8 x 16 patch pixels
+//                (rows y0+v .. y0+v+7, columns x0-4 .. x0+11) for 4 channel quads -- through the
+//                bilinear warp of modules.py:99-137 when a flow is given -- and one f0 tile pixel
+//                for 2 quads, into registers; the values go to LDS after the previous stage is
+//                computed (register-staged double buffer: the loads of stage s+1 fly during stage s);
+//   compute    = wave w owns channel quads 2w, 2w+1 of the stage, lane = tile pixel: 1 + 9
+//                ds_read_b128 per quad (patch row stride 24 pixels: the 64 lanes of one shift hit 64
+//                distinct 16-byte slots in every ds_read_b128 lane group);
+//   epilogue   = the 4 waves' partial sums are added through LDS, mean, leaky-relu, store.
+struct CvCoarseArgs {
+    const float* f0;
+    const float* f1;
+    const float* flow;      // null: f1 is used as is (pyramid level 0, model.py:105-106)
+    float* out;
+    float* f0_copy;         // null or the `features_0` slice of the estimator input (modules.py:264)
+    int f0_cs, f1_cs, flow_cs, out_cs, f0_copy_cs;
+    int N, H, W, C;
+    float flow_scale, slope;
+    int tiles_x, tiles_y;
+};
+
+constexpr int CC_PSTR = 24;                          // patch row stride in pixels (16 used)
+constexpr int CC_QS = 8;                             // channel quads per stage
+constexpr int CC_F1 = CC_QS * 8 * CC_PSTR * 4;       // floats of the f1 patch image of a stage
+constexpr int CC_STAGE = CC_F1 + CC_QS * 64 * 4;     // + f0 tile: 8192 floats = 32 KB
+
+template <bool WARP>
+__global__ __launch_bounds__(256) void cost_volume_coarse_kernel(const CvCoarseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 stages
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    int blk = blockIdx.x;
+    const int dyi = blk % 9;                         // vertical shift v = dyi - 4
+    blk /= 9;
+    const int bx = blk % a.tiles_x;
+    blk /= a.tiles_x;
+    const int by = blk % a.tiles_y;
+    const int n = blk / a.tiles_y;
+    const int y0 = by * 8, x0 = bx * 8;
+    const float* f0n = a.f0 + (size_t)n * a.H * a.W * a.f0_cs;
+    const float* f1n = a.f1 + (size_t)n * a.H * a.W * a.f1_cs;
+
+    // ---- loader role
+    const int pp = t >> 1, qb = (t & 1) * 4;         // patch pixel, first of its 4 quads
+    const int prow = pp >> 4, pcol = pp & 15;
+    const int yy = y0 + prow + dyi - 4, xx = x0 + pcol - 4;
+    const bool pin = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;   // outside: zeros (pad2d)
+    int o00 = 0, o01 = 0, o10 = 0, o11 = 0;
+    float c00 = 1.f, c01 = 0.f, c10 = 0.f, c11 = 0.f;
+    if (pin) {
+        if (WARP) {
+            // bilinear_warp, modules.py:107-137: un-clipped floors give the weights, the four corner
+            // indices are clipped independently
+            const float* fl = a.flow + (((size_t)n * a.H + yy) * a.W + xx) * a.flow_cs;
+            const float fx = fl[0] * a.flow_scale, fy = fl[1] * a.flow_scale;
+            const float fx0 = floorf(fx), fy0 = floorf(fy);
+            const float fx1 = fx0 + 1.f, fy1 = fy0 + 1.f;
+            const float hl = (float)(a.H - 1), wl = (float)(a.W - 1);
+            const int iy0 = (int)fminf(fmaxf((float)yy + fy0, 0.f), hl), iy1 = (int)fminf(fmaxf((float)yy + fy1, 0.f), hl);
+            const int ix0 = (int)fminf(fmaxf((float)xx + fx0, 0.f), wl), ix1 = (int)fminf(fmaxf((float)xx + fx1, 0.f), wl);
+            c00 = (fy1 - fy) * (fx1 - fx); c01 = (fy1 - fy) * (fx - fx0);
+            c10 = (fy - fy0) * (fx1 - fx); c11 = (fy - fy0) * (fx - fx0);
+            o00 = (iy0 * a.W + ix0) * a.f1_cs; o01 = (iy0 * a.W + ix1) * a.f1_cs;
+            o10 = (iy1 * a.W + ix0) * a.f1_cs; o11 = (iy1 * a.W + ix1) * a.f1_cs;
+        } else {
+            o00 = (yy * a.W + xx) * a.f1_cs;
+        }
+    }
+    const int fp = t >> 2, fqb = (t & 3) * 2;        // f0 tile pixel, first of its 2 quads
+    const int fy_ = y0 + (fp >> 3), fx_ = x0 + (fp & 7);
+    const bool fin = fy_ < a.H && fx_ < a.W;
+    const int f0off = fin ? (fy_ * a.W + fx_) * a.f0_cs : 0;
+    float* cpy = (a.f0_copy && dyi == 4 && fin) ? a.f0_copy + (((size_t)n * a.H + fy_) * a.W + fx_) * a.f0_copy_cs : nullptr;
+
+    f32x4 g1[4], g0[2];
+    auto gload = [&](int st) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = st * 32 + (qb + k) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pin && c < a.C) {
+                if (WARP) {
+                    v = c00 * *reinterpret_cast<const f32x4*>(f1n + o00 + c) + c01 * *reinterpret_cast<const f32x4*>(f1n + o01 + c) +
+                        c10 * *reinterpret_cast<const f32x4*>(f1n + o10 + c) + c11 * *reinterpret_cast<const f32x4*>(f1n + o11 + c);
+                } else {
+                    v = *reinterpret_cast<const f32x4*>(f1n + o00 + c);
+                }
+            }
+            g1[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = st * 32 + (fqb + k) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (fin && c < a.C) v = *reinterpret_cast<const f32x4*>(f0n + f0off + c);
+            g0[k] = v;
+        }
+    };
+    auto lstore = [&](int st, int buf) {
+        float* b = smem + buf * CC_STAGE;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            *reinterpret_cast<f32x4*>(b + ((qb + k) * (8 * CC_PSTR) + prow * CC_PSTR + pcol) * 4) = g1[k];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            *reinterpret_cast<f32x4*>(b + CC_F1 + ((fqb + k) * 64 + fp) * 4) = g0[k];
+            const int c = st * 32 + (fqb + k) * 4;
+            if (cpy && c < a.C) *reinterpret_cast<f32x4*>(cpy + c) = g0[k];
+        }
+    };
+
+    // ---- compute role
+    const int py = lane >> 3, px = lane & 7;
+    const int rbase = (py * CC_PSTR + px) * 4;
+    float acc[9];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) acc[d] = 0.f;
+
+    const int nst = (a.C + 31) >> 5;
+    gload(0);
+    lstore(0, 0);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const bool more = st + 1 < nst;
+        if (more) gload(st + 1);
+        const float* b = smem + (st & 1) * CC_STAGE;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int q = 2 * wave + qq;
+            const f32x4 u = *reinterpret_cast<const f32x4*>(b + CC_F1 + (q * 64 + lane) * 4);
+            const float* pq = b + q * (8 * CC_PSTR * 4) + rbase;
+#pragma unroll
+            for (int d = 0; d < 9; ++d) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(pq + d * 4);
+                acc[d] = fmaf(u[0], w[0], fmaf(u[1], w[1], fmaf(u[2], w[2], fmaf(u[3], w[3], acc[d]))));
+            }
+        }
+        if (more) lstore(st + 1, (st + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- sum the 4 waves' partial sums, mean over channels, leaky-relu, store
+    float* red = smem;
+#pragma unroll
+    for (int d = 0; d < 9; ++d) red[(wave * 9 + d) * 64 + lane] = acc[d];
+    __syncthreads();
+    const float inv = 1.f / (float)a.C;
+    for (int idx = t; idx < 64 * 9; idx += 256) {
+        const int l = idx / 9, d = idx - l * 9;
+        const int y = y0 + (l >> 3), x = x0 + (l & 7);
+        if (y < a.H && x < a.W) {
+            const float v = (red[d * 64 + l] + red[(9 + d) * 64 + l] + red[(18 + d) * 64 + l] + red[(27 + d) * 64 + l]) * inv;
+            a.out[(((size_t)n * a.H + y) * a.W + x) * a.out_cs + dyi * 9 + d] = pwc_lrelu(v, a.slope);
+        }
+    }
+}
+
+extern "C" int pwc_cost_volume_coarse_f32(const float* f0, int f0_cs, const float* f1, int f1_cs, const float* flow,
+                                          int flow_cs, float flow_scale, float* out, int out_cs, float* f0_copy,
+                                          int f0_copy_cs, int N, int H, int W, int C, int search_range, float slope,
+                                          pwc_stream_t stream) {
+    if (!f0 || !f1 || !out) return PWC_EINVAL;
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return PWC_EINVAL;
+    if (search_range != 4) return PWC_EUNSUPPORTED;
+    if (f0_cs < C || f1_cs < C || out_cs < 81 || (flow && flow_cs < 2) || (f0_copy && f0_copy_cs < C)) return PWC_EINVAL;
+    if ((C & 3) || (f0_cs & 3) || (f1_cs & 3) || !pwc_aligned16(f0) || !pwc_aligned16(f1)) return PWC_EALIGN;
+    if (f0_copy && ((f0_copy_cs & 3) || !pwc_aligned16(f0_copy))) return PWC_EALIGN;
+    if ((long)H * W * f0_cs >= (1L << 31) || (long)H * W * f1_cs >= (1L << 31)) return PWC_ERANGE;
+    CvCoarseArgs a;
+    a.f0 = f0; a.f1 = f1; a.flow = flow; a.out = out; a.f0_copy = f0_copy;
+    a.f0_cs = f0_cs; a.f1_cs = f1_cs; a.flow_cs = flow_cs; a.out_cs = out_cs; a.f0_copy_cs = f0_copy_cs;
+    a.N = N; a.H = H; a.W = W; a.C = C; a.flow_scale = flow_scale; a.slope = slope;
+    a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
+    const long nblk = (long)N * a.tiles_x * a.tiles_y * 9;
+    if (nblk >= (1L << 31)) return PWC_ERANGE;
+    const size_t lds = (size_t)2 * CC_STAGE * sizeof(float);
+    if (flow)
+        hipLaunchKernelGGL(cost_volume_coarse_kernel<true>, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(cost_volume_coarse_kernel<false>, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
+    return pwc_launch_status();
+}
+
 static int cv_check(const float* f0, int f0_cs, const float* f1, int f1_cs, float* out, int out_cs, int N,
                     int H, int W, int C, int R) {
     if (!f0 || !f1 || !out) return PWC_EINVAL;

@@ -26,7 +26,8 @@ from .weights import ChannelLayout, SCALES
 
 class PWCDCNet(object):
     def __init__(self, num_levels=6, search_range=4, warp_type="bilinear", use_dc=False,
-                 output_level=4, name="pwcdcnet", seed=0, fuse_warp=False, use_plans=True, winograd=True):
+                 output_level=4, name="pwcdcnet", seed=0, fuse_warp=False, use_plans=True, winograd=True,
+                 coarse_cv=True):
         self.num_levels = num_levels
         self.s_range = search_range
         self.warp_type = warp_type
@@ -35,6 +36,7 @@ class PWCDCNet(object):
         self.output_level = output_level
         self.name = name
         self.fuse_warp = fuse_warp
+        self.coarse_cv = coarse_cv
 
         self.fp_extractor = FeaturePyramidExtractor_custom(self.num_levels)
         self.warp_layer = WarpingLayer(self.warp_type)
@@ -129,11 +131,16 @@ class PWCDCNet(object):
 
                 # Warping + cost volume (model.py:105-112)
                 cv_out = sub_view(E, lay.offset("cv"), (2 * self.s_range + 1) ** 2)
-                if l == 0:
-                    self.cv_layer._run(f0, f1, cv_out)
+                f0_dst = sub_view(E, lay.offset("f0"), C)
+                flow_v = sub_view(E, lay.offset("flow"), 2) if l > 0 else None
+                if self.coarse_cv and self.cv_layer.coarse_ok(f0) and (l == 0 or self.warp_type == "bilinear"):
+                    # coarse levels: warp + cost volume + the f0 part of the concat in ONE launch
+                    self.cv_layer._run(f0, f1, cv_out, flow=flow_v, flow_scale=self.scales[l] if l > 0 else 1.0,
+                                       f0_copy=f0_dst, coarse=True)
                 else:
-                    flow_v = sub_view(E, lay.offset("flow"), 2)
-                    if self.warp_type == "bilinear" and self.fuse_warp:
+                    if l == 0:
+                        self.cv_layer._run(f0, f1, cv_out)
+                    elif self.warp_type == "bilinear" and self.fuse_warp:
                         self.cv_layer._run(f0, f1, cv_out, flow=flow_v, flow_scale=self.scales[l])
                     else:
                         f1w_t = torch.empty((N, h, w, C), dtype=torch.float32, device=dev)
@@ -141,7 +148,7 @@ class PWCDCNet(object):
                         f1w = View(f1w_t.data_ptr(), C, N, h, w, C)
                         self.warp_layer._run(f1, flow_v, f1w, flow_scale=self.scales[l])
                         self.cv_layer._run(f0, f1w, cv_out)
-                _copy_channels(f0, sub_view(E, lay.offset("f0"), C), C)
+                    _copy_channels(f0, f0_dst, C)
 
                 flows_t = torch.empty((N, h, w, 2), dtype=torch.float32, device=dev)
                 _keep(flows_t)

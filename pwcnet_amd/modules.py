@@ -479,13 +479,34 @@ class CostVolumeLayer(_Module):
         super().__init__(name)
         self.s_range = search_range
 
-    def _run(self, f0, f1, out, flow=None, flow_scale=1.0):
-        """flow given: f1 is the UN-warped map and the bilinear warp is fused in."""
+    # pixels per batch up to which the coarse-level kernel (warp + cost volume + f0 copy in one
+    # launch) is used.  Measured at batch 8: 7x16 level 11.5 us vs 48 us for the three separate
+    # launches, 14x32 level 25 vs 44 us, 28x64 level 48 vs 41 us (the streaming kernels win)
+    COARSE_MAX_PIXELS = 4096
+
+    def coarse_ok(self, f0):
+        return self.s_range == 4 and f0.N * f0.H * f0.W <= self.COARSE_MAX_PIXELS
+
+    def _run(self, f0, f1, out, flow=None, flow_scale=1.0, f0_copy=None, coarse=False):
+        """flow given: f1 is the UN-warped map and the bilinear warp is fused in.
+        coarse: one launch of pwc_cost_volume_coarse_f32 (optionally also copying f0 into
+        the `f0_copy` view, the features_0 slice of the estimator input)."""
         L = _lib.lib()
         s = _lib.current_stream()
         D = (2 * self.s_range + 1) ** 2
         npix = f0.N * f0.H * f0.W
         flops = 2.0 * npix * D * f0.C
+        if coarse:
+            assert self.coarse_ok(f0)
+            _launch(L.pwc_cost_volume_coarse_f32,
+                    (_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(flow.ptr) if flow is not None else None,
+                     flow.cs if flow is not None else 0, float(flow_scale), _p(out.ptr), out.cs,
+                     _p(f0_copy.ptr) if f0_copy is not None else None, f0_copy.cs if f0_copy is not None else 0,
+                     f0.N, f0.H, f0.W, f0.C, self.s_range, 0.1, s),
+                    "cost_volume_coarse", "cost_volume_coarse_kernel", flops,
+                    4.0 * npix * (2 * f0.C + D + (2 if flow is not None else 0) + (f0.C if f0_copy is not None else 0)))
+            return
+        assert f0_copy is None
         if flow is None:
             _launch(L.pwc_cost_volume_f32,
                     (_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(out.ptr), out.cs, f0.N, f0.H, f0.W, f0.C,

@@ -417,6 +417,41 @@ def test_fused_warp_cost_volume_vs_oracle(pa, N, H, W, C):
     close(out, exp, rel=4e-6, floor=4e-7)
 
 
+@pytest.mark.parametrize("N,H,W,C,with_flow", [
+    (2, 7, 16, 192, False), (2, 14, 32, 128, True), (1, 28, 64, 96, True), (3, 9, 21, 32, True),
+    (1, 5, 3, 8, True), (1, 17, 10, 48, False), (2, 8, 8, 20, True)])
+def test_coarse_cost_volume_kernel_vs_oracle(pa, N, H, W, C, with_flow):
+    """pwc_cost_volume_coarse_f32: warp + cost volume + f0 copy in one launch (coarse levels),
+    written into channel slices of wider buffers; ragged tiles, C not a multiple of 32."""
+    from pwcnet_amd.modules import View
+    f0, f1 = rnd((N, H, W, C), 41), rnd((N, H, W, C), 42)
+    flow = util.flow_field(N, H, W, seed=43) / 5.0
+    f1w = orc.warp(f1, flow, "bilinear", flow_scale=5.0) if with_flow else f1
+    exp = orc.cost_volume(f0, f1w, 4)
+    g0, g1 = gpu(f0), gpu(f1)
+    fl = torch.full((N, H, W, 4), 9.0, device="cuda")
+    fl[..., :2] = gpu(flow)
+    E = torch.full((N, H, W, 84 + C + 4), -3.0, device="cuda")            # [cv 81 | pad 3 | f0 C | pad 4]
+    Ev = View(E.data_ptr(), 84 + C + 4, N, H, W, 84 + C + 4)
+    from pwcnet_amd.modules import sub_view
+    pa.CostVolumeLayer(4)._run(View(g0.data_ptr(), C, N, H, W, C), View(g1.data_ptr(), C, N, H, W, C),
+                               sub_view(Ev, 0, 81), flow=View(fl.data_ptr(), 4, N, H, W, 2) if with_flow else None,
+                               flow_scale=5.0, f0_copy=sub_view(Ev, 84, C), coarse=True)
+    torch.cuda.synchronize()
+    close(E[..., :81], exp, rel=4e-6, floor=4e-7)
+    assert torch.equal(E[..., 84:84 + C], g0)
+    assert float(E[..., 81:84].min()) == -3.0 and float(E[..., 84 + C:].max()) == -3.0
+
+
+def test_coarse_cost_volume_rejects_other_search_ranges(pa):
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    x = torch.zeros((1, 8, 8, 32), device="cuda")
+    out = torch.zeros((1, 8, 8, 81), device="cuda")
+    rc = L.pwc_cost_volume_coarse_f32(_p(x), 32, _p(x), 32, None, 0, 1.0, _p(out), 81, None, 0, 1, 8, 8, 32, 3, 0.1, None)
+    assert rc == -4
+
+
 # ------------------------------------------------------------------ resize / copy
 @pytest.mark.parametrize("N,H,W,C,OH,OW,mul", [
     (2, 7, 16, 2, 14, 32, 1.0), (2, 7, 16, 32, 14, 32, 1.0), (1, 112, 256, 2, 448, 1024, 20.0),
