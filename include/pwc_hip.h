@@ -164,6 +164,13 @@ int pwc_resize_bilinear_f32(const float* x, int x_cs, float* y, int y_cs,
                             int N, int H, int W, int C, int OH, int OW, float mul,
                             pwc_stream_t stream);
 
+/* Two resizes of one geometry in one launch (modules.py:283-284: flows_up and features_up of the
+ * same level): xa/ya carry 2 channels (8-byte aligned, even channel strides), xb/yb CB channels
+ * (CB % 4 == 0, 16-byte aligned).  Same arithmetic as pwc_resize_bilinear_f32 with mul = 1. */
+int pwc_resize_bilinear_pair_f32(const float* xa, int xa_cs, float* ya, int ya_cs,
+                                 const float* xb, int xb_cs, float* yb, int yb_cs,
+                                 int N, int H, int W, int CB, int OH, int OW, pwc_stream_t stream);
+
 /* ---- tf.concat helper (modules.py:264,305): dst[p, 0:C] = src[p, 0:C] for npix pixels. */
 int pwc_copy_channels_f32(const float* src, int src_cs, float* dst, int dst_cs,
                           long npix, int C, pwc_stream_t stream);

@@ -164,6 +164,77 @@ extern "C" int pwc_resize_bilinear_f32(const float* x, int x_cs, float* y, int y
     return pwc_launch_status();
 }
 
+// Two resizes of the same geometry in one launch: the 2-channel flows and the feature map that
+// the estimator hands to the next pyramid level (modules.py:283-284) -- at the coarse levels each
+// separate launch costs its ~6 us floor for kilobytes of data.
+struct ResizePairArgs {
+    const float* xa;    // 2 channels (float2 units)
+    float* ya;
+    const float* xb;    // CB channels, CB % 4 == 0 (float4 units)
+    float* yb;
+    int xa_cs, ya_cs, xb_cs, yb_cs;
+    int H, W, CB, OH, OW;
+    float sy, sx;
+    int rows;
+};
+
+__global__ __launch_bounds__(256) void resize_pair_kernel(const ResizePairArgs a) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const unsigned upp = 1u + (unsigned)a.CB / 4;            // units per output pixel: 1 float2 + CB/4 float4
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= (unsigned)a.OW * upp) return;
+    const unsigned ox = e / upp, un = e - ox * upp;
+    const float fx = (float)ox * a.sx;
+    const int x0 = (int)floorf(fx);
+    const int x1 = min(x0 + 1, a.W - 1);
+    const float xl = fx - (float)x0;
+    for (int row = blockIdx.y; row < a.rows; row += gridDim.y) {
+        const int n = row / a.OH, oy = row - n * a.OH;
+        const float fy = (float)oy * a.sy;
+        const int y0 = (int)floorf(fy);
+        const int y1 = min(y0 + 1, a.H - 1);
+        const float yl = fy - (float)y0;
+        const size_t p00 = ((size_t)n * a.H + y0) * a.W, p10 = ((size_t)n * a.H + y1) * a.W;
+        const size_t po = (size_t)row * a.OW + ox;
+        if (un == 0) {
+            const f32x2 tl = *reinterpret_cast<const f32x2*>(a.xa + (p00 + x0) * a.xa_cs);
+            const f32x2 tr = *reinterpret_cast<const f32x2*>(a.xa + (p00 + x1) * a.xa_cs);
+            const f32x2 bl = *reinterpret_cast<const f32x2*>(a.xa + (p10 + x0) * a.xa_cs);
+            const f32x2 br = *reinterpret_cast<const f32x2*>(a.xa + (p10 + x1) * a.xa_cs);
+            const f32x2 top = tl + (tr - tl) * xl, bot = bl + (br - bl) * xl;
+            *reinterpret_cast<f32x2*>(a.ya + po * a.ya_cs) = top + (bot - top) * yl;
+        } else {
+            const int c = (int)(un - 1) * 4;
+            const f32x4 tl = *reinterpret_cast<const f32x4*>(a.xb + (p00 + x0) * a.xb_cs + c);
+            const f32x4 tr = *reinterpret_cast<const f32x4*>(a.xb + (p00 + x1) * a.xb_cs + c);
+            const f32x4 bl = *reinterpret_cast<const f32x4*>(a.xb + (p10 + x0) * a.xb_cs + c);
+            const f32x4 br = *reinterpret_cast<const f32x4*>(a.xb + (p10 + x1) * a.xb_cs + c);
+            const f32x4 top = tl + (tr - tl) * xl, bot = bl + (br - bl) * xl;
+            *reinterpret_cast<f32x4*>(a.yb + po * a.yb_cs + c) = top + (bot - top) * yl;
+        }
+    }
+}
+
+extern "C" int pwc_resize_bilinear_pair_f32(const float* xa, int xa_cs, float* ya, int ya_cs, const float* xb,
+                                            int xb_cs, float* yb, int yb_cs, int N, int H, int W, int CB, int OH,
+                                            int OW, pwc_stream_t stream) {
+    if (!xa || !ya || !xb || !yb) return PWC_EINVAL;
+    if (N <= 0 || H <= 0 || W <= 0 || CB <= 0 || OH <= 0 || OW <= 0) return PWC_EINVAL;
+    if (xa_cs < 2 || ya_cs < 2 || xb_cs < CB || yb_cs < CB) return PWC_EINVAL;
+    if ((CB & 3) || (xb_cs & 3) || (yb_cs & 3) || !pwc_aligned16(xb) || !pwc_aligned16(yb)) return PWC_EALIGN;
+    if ((xa_cs & 1) || (ya_cs & 1) || ((uintptr_t)xa & 7) || ((uintptr_t)ya & 7)) return PWC_EALIGN;
+    if ((long)N * OH >= (1L << 31) || (long)OW * (1 + CB / 4) >= (1L << 31)) return PWC_ERANGE;
+    ResizePairArgs a;
+    a.xa = xa; a.ya = ya; a.xb = xb; a.yb = yb;
+    a.xa_cs = xa_cs; a.ya_cs = ya_cs; a.xb_cs = xb_cs; a.yb_cs = yb_cs;
+    a.H = H; a.W = W; a.CB = CB; a.OH = OH; a.OW = OW;
+    a.sy = (float)H / (float)OH; a.sx = (float)W / (float)OW;
+    a.rows = N * OH;
+    const dim3 grid((unsigned)(((long)OW * (1 + CB / 4) + 255) / 256), (unsigned)(a.rows < 65535 ? a.rows : 65535));
+    hipLaunchKernelGGL(resize_pair_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return pwc_launch_status();
+}
+
 // ------------------------------------------------------------------ channel-slice copy
 // tf.concat (modules.py:264,305) when an input arrives as its own tensor: copies C
 // channels of every pixel into a channel slice of the destination.

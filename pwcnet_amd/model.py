@@ -169,8 +169,12 @@ class PWCDCNet(object):
                     nE_t, nE_off, ncx = self._level_buffer(l + 1, nlay, N, h2, w2, dev,
                                                            l + 1 == self.output_level)
                     nE = View(nE_t.data_ptr() + 4 * nE_off, nE_t.shape[3], N, h2, w2, nlay.n_phys)
-                    _resize(flows_v, sub_view(nE, nlay.offset("flow"), 2))
-                    _resize(feat_v, sub_view(nE, nlay.offset("feat_up"), feat_v.C))
+                    if feat_v.C % 4 == 0 and feat_v.cs % 4 == 0 and nE.cs % 4 == 0:
+                        _m._resize_pair(flows_v, sub_view(nE, nlay.offset("flow"), 2),
+                                        feat_v, sub_view(nE, nlay.offset("feat_up"), feat_v.C))
+                    else:
+                        _resize(flows_v, sub_view(nE, nlay.offset("flow"), 2))
+                        _resize(feat_v, sub_view(nE, nlay.offset("feat_up"), feat_v.C))
                     nxt = (nE_t, nE_off, nlay, ncx)
                     flows_pyramid.append(flows_t)
                     continue

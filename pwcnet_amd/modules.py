@@ -386,6 +386,16 @@ def _resize(src, dst, mul=1.0):
             "resize_bilinear", "resize_kernel", 0.0, 4.0 * src.C * src.N * (src.H * src.W + dst.H * dst.W))
 
 
+def _resize_pair(src_a, dst_a, src_b, dst_b):
+    """x2-style resize of a 2-channel map and a C-channel map of the same geometry in one launch."""
+    assert src_a.C == 2 and (src_a.N, src_a.H, src_a.W) == (src_b.N, src_b.H, src_b.W)
+    _launch(_lib.lib().pwc_resize_bilinear_pair_f32,
+            (_p(src_a.ptr), src_a.cs, _p(dst_a.ptr), dst_a.cs, _p(src_b.ptr), src_b.cs, _p(dst_b.ptr), dst_b.cs,
+             src_a.N, src_a.H, src_a.W, src_b.C, dst_a.H, dst_a.W, _lib.current_stream()),
+            "resize_bilinear_pair", "resize_kernel", 0.0,
+            4.0 * (2 + src_b.C) * src_a.N * (src_a.H * src_a.W + dst_a.H * dst_a.W))
+
+
 def resize_bilinear(x, size, mul=1.0):
     """tf.image.resize_bilinear(x, size) * mul with TF-1.8 legacy sampling (reference
     modules.py:283-284, model.py:127)."""

@@ -461,6 +461,22 @@ def test_resize_vs_oracle(pa, N, H, W, C, OH, OW, mul):
     close(pa.resize_bilinear(gpu(x), (OH, OW), mul), orc.resize_bilinear(x, (OH, OW), mul), rel=1e-6, floor=1e-6)
 
 
+@pytest.mark.parametrize("N,H,W,C", [(2, 7, 16, 32), (1, 14, 32, 32), (1, 5, 9, 8), (2, 6, 10, 288)])
+def test_resize_pair_vs_oracle(pa, N, H, W, C):
+    """flows (2 ch) + features (C ch) of one level resized x2 in ONE launch into channel slices of
+    the next level's buffer (modules.py:283-284)."""
+    from pwcnet_amd.modules import View, _resize_pair, sub_view
+    fl, ft = rnd((N, H, W, 2), 36), rnd((N, H, W, C), 37)
+    gfl, gft = gpu(fl), gpu(ft)
+    E = torch.full((N, 2 * H, 2 * W, 8 + C + 4), -2.0, device="cuda")       # [pad 4 | flow 2 pad 2 | feat C | pad 4]
+    Ev = View(E.data_ptr(), 8 + C + 4, N, 2 * H, 2 * W, 8 + C + 4)
+    _resize_pair(View(gfl.data_ptr(), 2, N, H, W, 2), sub_view(Ev, 4, 2), View(gft.data_ptr(), C, N, H, W, C), sub_view(Ev, 8, C))
+    torch.cuda.synchronize()
+    close(E[..., 4:6], orc.resize_bilinear(fl, (2 * H, 2 * W)), rel=1e-6, floor=1e-6)
+    close(E[..., 8:8 + C], orc.resize_bilinear(ft, (2 * H, 2 * W)), rel=1e-6, floor=1e-6)
+    assert float(E[..., :4].max()) == -2.0 and float(E[..., 6:8].max()) == -2.0 and float(E[..., 8 + C:].max()) == -2.0
+
+
 def test_resize_known_answer_and_golden(pa, golden_dir):
     x = np.arange(4, dtype=np.float32).reshape(1, 1, 4, 1)
     y = pa.resize_bilinear(gpu(x), (1, 8)).cpu().numpy().ravel()
