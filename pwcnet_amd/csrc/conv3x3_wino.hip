@@ -1,10 +1,11 @@
-// conv3x3_wino.hip -- 3x3 stride-1 dilation-1 'SAME' convolution by Winograd F(2x2, 3x3)
+// conv3x3_wino.hip -- 3x3 stride-1 'SAME' convolution (any dilation) by Winograd F(2x2, 3x3)
 // on the fp32 MFMA units of gfx950.
 //
-// Replaces the same tf.layers.Conv2D(...,(3,3),(1,1),'same') + tf.nn.leaky_relu calls as
-// conv3x3_mfma.hip (reference modules.py:64-67, 267-268, 306-307, 322-323) wherever
-// stride = dilation = 1 and Cout % 32 == 0: 16 multiplies per 2x2 outputs instead of 36,
-// i.e. 2.25x fewer MFMA instructions for the same result (fp32 error ~1e-7 relative).
+// Replaces the same tf.layers.Conv2D(...,(3,3),(1,1),'same',dilation_rate=d) + tf.nn.leaky_relu
+// calls as conv3x3_mfma.hip (reference modules.py:64-67, 267-268, 306-323) wherever stride = 1
+// and Cout % 16 == 0: 16 multiplies per 2x2 outputs instead of 36, i.e. 2.25x fewer MFMA
+// instructions for the same result (fp32 error ~1e-7 relative).  A dilation-d convolution is d*d
+// independent ordinary convolutions on the pixel sub-lattices (y mod d, x mod d).
 //
 //   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A      per 4x4 input tile d, 2x2 output Y
 //
@@ -24,7 +25,10 @@
 //   LDS per 16-channel stage: the raw 18 x 18 pixel patch (64-byte rows, see wpswz) and the
 //   transformed weights U[xi][32 cout][16 ch] (pre-swizzled by the packer), both filled by
 //   buffer_load_dwordx4 ... lds; out-of-image pixels are out-of-range buffer offsets and
-//   read as zeros (SAME padding).
+//   read as zeros (SAME padding).  One stage buffer, fetched in three parts that are each
+//   refetched as soon as they have been read (PIPE); 2 workgroups per CU.
+//   Other tile shapes of the same kernel (WinoGeom): two short sub-lattice images per
+//   workgroup, 4 x 64-pixel blocks; 16 instead of 32 output channels (NT = 1).
 #include "pwc_common.h"
 
 #ifndef WINO_BN32_MIN_WG
@@ -98,6 +102,7 @@ __device__ __forceinline__ float wino_minus_one() {
 }
 
 // ABL (scripts/exp_wino.hip only, 0 in the library): 1 = no patch DMA, 2 = no weight DMA, 4 = no MFMA,
+// 8 = s_setprio(1) around the MFMA clusters, 16 = k innermost in the MFMA order (both measured: no gain),
 // 64 = no input transform
 // PIPE = 1: the stage is fetched in three parts (patch, weights of positions 0-7, of 8-15), each
 // re-fetched for the next stage as soon as its LDS region is free, one barrier per part.
@@ -263,17 +268,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
                 for (int nt = 0; nt < NT; ++nt)
                     wf[nt] = *reinterpret_cast<const f32x4*>(smem + u_off + (xi * WN_BN + nt * 16) * 16);
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        if (ABL & 4) {
-                            if (FIRST && k == 0) acc[xi][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            asm volatile("" ::"v"(wf[nt][k]), "v"(v[xi >> 2][xi & 3][k]));
-                            continue;
-                        }
-                        const f32x4 c = (FIRST && k == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[xi][nt];
-                        acc[xi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][k], v[xi >> 2][xi & 3][k], c, 0, 0, 0);
+                for (int kk = 0; kk < 4 * NT; ++kk) {
+                    // ABL & 16: the 4 k-steps of one accumulator back to back (k innermost); default: the
+                    // NT accumulators of a position alternate
+                    const int k = (ABL & 16) ? kk % 4 : kk / NT, nt = (ABL & 16) ? kk / 4 : kk % NT;
+                    if (ABL & 4) {
+                        if (FIRST && k == 0) acc[xi][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        asm volatile("" ::"v"(wf[nt][k]), "v"(v[xi >> 2][xi & 3][k]));
+                        continue;
                     }
+                    const f32x4 c = (FIRST && k == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[xi][nt];
+                    acc[xi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][k], v[xi >> 2][xi & 3][k], c, 0, 0, 0);
+                }
             }
         };
         if (PIPE) {

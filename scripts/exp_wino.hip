@@ -31,14 +31,14 @@ int main(int argc, char** argv) {
     const double gf = 2.0 * N * H * W * 9.0 * C * CO / 1e9;
     const size_t L1 = (size_t)WinoGeom<2>::STAGE * 4;
     // interleaved A/B rounds without idle gaps (a D2H copy between runs lets the clocks drop)
-    const char* names[] = {"nopipe", "pipe", "pipe noDMA", "pipe setprio", "noDMA", "noMFMA", "none"};
+    const char* names[] = {"nopipe", "pipe", "pipe noDMA", "pipe same-acc chains", "noDMA", "noMFMA", "none"};
     float best[7]; for (auto& v : best) v = 1e9f;
     for (int round = 0; round < (pmc ? 1 : 5); ++round) {
         float t[7];
         t[0] = run(conv3x3_wino_kernel<0>, a, nblk, L1, pmc ? 1 : 10);
         t[1] = run(conv3x3_wino_kernel<0, 2, 1>, a, nblk, L1, pmc ? 1 : 10);
         t[2] = run(conv3x3_wino_kernel<3, 2, 1>, a, nblk, L1, pmc ? 1 : 10);
-        t[3] = run(conv3x3_wino_kernel<8, 2, 1>, a, nblk, L1, pmc ? 1 : 10);
+        t[3] = run(conv3x3_wino_kernel<16, 2, 1>, a, nblk, L1, pmc ? 1 : 10);
         t[4] = run(conv3x3_wino_kernel<3>, a, nblk, L1, pmc ? 1 : 10);
         t[5] = run(conv3x3_wino_kernel<4>, a, nblk, L1, pmc ? 1 : 10);
         t[6] = run(conv3x3_wino_kernel<7>, a, nblk, L1, pmc ? 1 : 10);
