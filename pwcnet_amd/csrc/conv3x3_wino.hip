@@ -48,6 +48,7 @@ struct WinoArgs {
     int tiles_x, tiles_y, ncb;   // 16x16-pixel blocks per (sub-)image, cout blocks of 32
     int y_vec4;
     int dil;                     // dilation d: the conv splits into d*d ordinary convs on the pixel sub-lattices
+    int ntiles;                  // (pixel block, cout block) tiles of the launch (= gridDim.x unless PERSIST)
 };
 
 __device__ __forceinline__ int wswz(int row) { return (4 - ((row >> 2) & 3)) & 3; }   // weight rows
@@ -106,8 +107,14 @@ __device__ __forceinline__ float wino_minus_one() {
 // 64 = no input transform
 // PIPE = 1: the stage is fetched in three parts (patch, weights of positions 0-7, of 8-15), each
 // re-fetched for the next stage as soon as its LDS region is free, one barrier per part.
-template <int ABL = 0, int NT = 2, int PIPE = 0, int GEO = 0>
+// PERSIST = 1 (needs PIPE; scripts/exp_wino.hip only): the grid is 2 workgroups per CU and each walks
+// tiles blockIdx.x, + gridDim.x, ...; the first stage of the next tile is requested before the
+// current tile's output transform and stores, so its fetch latency and the per-tile setup hide behind
+// them.  Correct, but the 7 offsets of the next tile live across the epilogue push the kernel over
+// 256 VGPRs (84 B of scratch per lane) and it measures 289 us against 255 us: not used by the library.
+template <int ABL = 0, int NT = 2, int PIPE = 0, int GEO = 0, int PERSIST = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) {
+    static_assert(!PERSIST || PIPE, "the persistent loop is built on the pipelined stage");
     typedef WinoGeom<NT, GEO> Geo;
     constexpr int SPLIT = GEO == 1, WIDE = GEO == 2;
     constexpr int WN_BN = Geo::BN, WN_NBU = Geo::NBU, WN_PRP = Geo::PRP, WN_NBP = Geo::NBP, WN_PH = Geo::PH;
@@ -124,64 +131,67 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
     const f32x4 M1 = {m1, m1, m1, m1};
 #define WSUB(p, q) __builtin_elementwise_fma((q), M1, (p))    /* p - q */
 
-    // block decode: cout block fastest, XCD-aware (the cout blocks of one pixel block share
-    // their input patch in one XCD's L2)
-    const int nblk = gridDim.x;
-    const int lb = pwc_xcd_remap(blockIdx.x, nblk);
-    const int cb = lb % a.ncb;
-    int rest = lb / a.ncb;
-    const int bx = rest % a.tiles_x;
-    rest /= a.tiles_x;
-    const int by = rest % a.tiles_y;
-    rest /= a.tiles_y;
     const int d = a.dil;
-    const int nsub = SPLIT ? (d * d) >> 1 : d * d;   // sub-lattices (SPLIT: pairs of them) of a dilated conv
-    const int sub = rest % nsub;
-    const int n = rest / nsub;
-    // sub-lattice (y mod d, x mod d) of tile-row group g (SPLIT: g = 0 for tile rows 0-3, 1 for 4-7)
-    const int sub_g[2] = {SPLIT ? 2 * sub : sub, SPLIT ? 2 * sub + 1 : sub};
-    const int ry_g[2] = {sub_g[0] / d, sub_g[1] / d};
-    const int rx_g[2] = {sub_g[0] - ry_g[0] * d, sub_g[1] - ry_g[1] * d};
-    const int y0 = by * Geo::BH, x0 = bx * Geo::BW;   // output origin of the block, in sub-lattice coordinates
-    const int n0 = cb * WN_BN;
     const int Cout_pad = (a.Cout + 15) & ~15;
     const int nc16 = a.Cin_phys >> 4;
-
-    // ---- LDS-DMA bookkeeping.  Both operands are fetched with buffer_load_dwordx4 ... lds:
-    // a per-lane BYTE offset that is fixed over the channel loop (VGPR), the stage advance in the
-    // scalar offset (SGPR) -- no vector instruction per fetch -- and the buffer range check gives
-    // the zeros of the SAME padding: out-of-image lanes carry the offset WN_OOB.
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.x + (size_t)n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.up, 0, 16 * a.Cin_phys * Cout_pad * 4, 0x00020000);
     constexpr int PPW = WN_NBP / 4;                // patch blocks per wave (6)
     constexpr int UPW = WN_NBU / 4;                // weight blocks per wave (8 for NT = 2)
     constexpr int UH = UPW / 2;                    // ... per half of the positions
     static_assert(WN_NBU % 8 == 0 && WN_NBP % 4 == 0, "blocks must split evenly over the waves");
-    unsigned p_voff[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int b = wave + 4 * i;
-        const int pr = b * 16 + (lane >> 2);                       // LDS row this lane fills
-        const int py = pr / WN_PS, rem = pr - py * WN_PS;
-        const int half = rem >= WN_PS / 2 ? 1 : 0, col = rem - half * (WN_PS / 2);
-        const int px = 2 * col + half;
-        const int g = SPLIT ? (py >= 10 ? 1 : 0) : 0, pyl = py - 10 * g;   // SPLIT: patch rows 0-9 / 10-19
-        const int y = ry_g[g] + d * (y0 - 1 + pyl), x = rx_g[g] + d * (x0 - 1 + px);
-        const int ch = (lane & 3) ^ wpswz(pr);                     // source chunk for this LDS slot
-        const bool ok = py < WN_PH && col < WN_PW / 2 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-        p_voff[i] = ok ? (unsigned)(((y * a.W + x) * a.x_cs + ch * 4) * 4) : WN_OOB;
-    }
-    // weight blocks: block wave + 4*i holds rows (xi, cout) = ((wave + 4*i) * 16 + lane/4); 4 blocks
-    // = 64 rows = 64 / WN_BN positions, so one per-lane offset plus a uniform stride covers all i
     static_assert(64 % WN_BN == 0, "weight block stride must be a whole number of positions");
+    const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.up, 0, 16 * a.Cin_phys * Cout_pad * 4, 0x00020000);
+
+    // ---- per-tile state (set by setup): block decode -- cout block fastest, XCD-aware (the cout
+    // blocks of one pixel block share their input patch in one XCD's L2) -- and the LDS-DMA
+    // bookkeeping.  Both operands are fetched with buffer_load_dwordx4 ... lds: a per-lane BYTE
+    // offset that is fixed over the channel loop (VGPR), the stage advance in the scalar offset
+    // (SGPR) -- no vector instruction per fetch -- and the buffer range check gives the zeros of
+    // the SAME padding: out-of-image lanes carry the offset WN_OOB.
+    int n, n0, y0, x0, ry_g[2], rx_g[2];
+    __amdgpu_buffer_rsrc_t xrsrc;
+    unsigned p_voff[PPW];
     unsigned u_voff;
-    {
+    auto setup = [&](int tile) {
+        const int lb = pwc_xcd_remap(tile, a.ntiles);
+        const int cb = lb % a.ncb;
+        int rest = lb / a.ncb;
+        const int bx = rest % a.tiles_x;
+        rest /= a.tiles_x;
+        const int by = rest % a.tiles_y;
+        rest /= a.tiles_y;
+        const int nsub = SPLIT ? (d * d) >> 1 : d * d;   // sub-lattices (SPLIT: pairs of them) of a dilated conv
+        const int sub = rest % nsub;
+        n = rest / nsub;
+        // sub-lattice (y mod d, x mod d) of tile-row group g (SPLIT: g = 0 for tile rows 0-3, 1 for 4-7)
+        const int sub_g[2] = {SPLIT ? 2 * sub : sub, SPLIT ? 2 * sub + 1 : sub};
+        ry_g[0] = sub_g[0] / d; ry_g[1] = sub_g[1] / d;
+        rx_g[0] = sub_g[0] - ry_g[0] * d; rx_g[1] = sub_g[1] - ry_g[1] * d;
+        y0 = by * Geo::BH; x0 = bx * Geo::BW;          // output origin of the block, in sub-lattice coordinates
+        n0 = cb * WN_BN;
+        xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)n * a.H * a.W * a.x_cs), 0,
+                                                  a.H * a.W * a.x_cs * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int b = wave + 4 * i;
+            const int pr = b * 16 + (lane >> 2);                       // LDS row this lane fills
+            const int py = pr / WN_PS, rem = pr - py * WN_PS;
+            const int half = rem >= WN_PS / 2 ? 1 : 0, col = rem - half * (WN_PS / 2);
+            const int px = 2 * col + half;
+            const int g = SPLIT ? (py >= 10 ? 1 : 0) : 0, pyl = py - 10 * g;   // SPLIT: patch rows 0-9 / 10-19
+            const int y = ry_g[g] + d * (y0 - 1 + pyl), x = rx_g[g] + d * (x0 - 1 + px);
+            const int ch = (lane & 3) ^ wpswz(pr);                     // source chunk for this LDS slot
+            const bool ok = py < WN_PH && col < WN_PW / 2 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            p_voff[i] = ok ? (unsigned)(((y * a.W + x) * a.x_cs + ch * 4) * 4) : WN_OOB;
+        }
+        // weight blocks: block wave + 4*i holds rows (xi, cout) = ((wave + 4*i) * 16 + lane/4); 4 blocks
+        // = 64 rows = 64 / WN_BN positions, so one per-lane offset plus a uniform stride covers all i
         const int ur = wave * 16 + (lane >> 2);
         const int xi = ur / WN_BN, co = ur - xi * WN_BN;
         u_voff = (n0 + co < Cout_pad) ? (unsigned)((((xi * nc16) * Cout_pad + n0 + co) * 16 + (lane & 3) * 4) * 4) : WN_OOB;
-    }
+    };
+    int tile = blockIdx.x;
+    setup(tile);
     const int u_step = (64 / WN_BN) * nc16 * Cout_pad * 64;       // bytes between a wave's consecutive weight blocks
     auto issue_patch = [&](int c16) {
 #pragma unroll
@@ -300,27 +310,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
         if (ABL & 8) __builtin_amdgcn_s_setprio(0);
     };
     if (PIPE) { issue_patch(0); issue_u(0, 0); }
+    for (;;) {
     stage(WinoBool<true>{}, 0);
     for (int c16 = 1; c16 < nc16; ++c16) stage(WinoBool<false>{}, c16);
+
+    // the tile's output coordinates, before setup() moves on to the next tile
+    const int on = n, on0 = n0, oy0 = y0, ox0 = x0;
+    const int ory[2] = {ry_g[0], ry_g[1]}, orx[2] = {rx_g[0], rx_g[1]};
+    const int next = tile + (int)gridDim.x;
+    const bool more = PERSIST && next < a.ntiles;
+    if (more) {
+        // all waves are past the last stage's patch and positions-0-7 reads (its barriers): those two
+        // LDS regions take the next tile's first stage while this tile's outputs are transformed and stored
+        setup(next);
+        issue_patch(0);
+        issue_u(0, 0);
+    }
 
     // ---- output transform  Y = A^T M A  (A^T = [1 1 1 0; 0 1 -1 -1]), bias, leaky-relu; stores go
     // through a buffer resource of image n so that pixels beyond the image edge are dropped by the
     // range check (no divergent branches)
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.y + (size_t)n * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
+        (void*)(a.y + (size_t)on * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
     const int og = SPLIT ? tr >> 2 : 0, otr = SPLIT ? tr & 3 : tr;
-    const int py0 = ry_g[og] + d * (y0 + 2 * otr), px0 = rx_g[og] + d * (x0 + 2 * tc);   // real coordinates of output (0,0)
+    const int py0 = ory[og] + d * (oy0 + 2 * otr), px0 = orx[og] + d * (ox0 + 2 * tc);   // real coordinates of output (0,0)
     unsigned y_voff[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int py = py0 + i * d, px = px0 + j * d;
-            y_voff[i][j] = (py < a.H && px < a.W) ? (unsigned)(((py * a.W + px) * a.y_cs + n0 + fq * 4) * 4) : WN_OOB;
+            y_voff[i][j] = (py < a.H && px < a.W) ? (unsigned)(((py * a.W + px) * a.y_cs + on0 + fq * 4) * 4) : WN_OOB;
         }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int co = n0 + nt * 16 + fq * 4;
+        const int co = on0 + nt * 16 + fq * 4;
         if (co >= a.Cout) continue;
         f32x4 s[2][4];
 #pragma unroll
@@ -352,6 +376,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
             }
         }
     }
+    if (!more) break;
+    tile = next;
+    }   // tiles
 #undef WSUB
 #undef WAIT_VM
 }
@@ -464,6 +491,7 @@ extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packe
     a.y_vec4 = ((y_cs & 3) == 0 && pwc_aligned16(y)) ? 1 : 0;
     const long nblk = pix_blocks * a.ncb;
     if (nblk >= (1L << 31)) return PWC_ERANGE;
+    a.ntiles = (int)nblk;
     // measured (scripts/exp_wino.hip): one LDS stage fetched in three pipelined parts with 2 co-resident
     // workgroups per CU beats a double-buffered whole stage (1 workgroup per CU)
 #define WINO_LAUNCH(NT, GEO)                                                                                \

@@ -17,6 +17,7 @@ static double checksum(const float* d, size_t n) {
     double s = 0; for (size_t i = 0; i < n; i += 5) s += (double)h[i] * (1 + (i % 11)); return s;
 }
 int main(int argc, char** argv) {
+    setvbuf(stdout, NULL, _IONBF, 0);
     const bool pmc = argc > 1;   // counter-collection mode: a few launches per variant
     const int N = 8, H = 112, W = 256, C = 128, CO = 128;
     const size_t nx = (size_t)N * H * W * C, nu = (size_t)16 * C * CO;
@@ -28,17 +29,18 @@ int main(int argc, char** argv) {
     WinoArgs a{}; a.x = x; a.up = u; a.bias = b; a.y = y; a.x_cs = C; a.y_cs = CO; a.N = N; a.H = H; a.W = W; a.Cin_phys = C; a.Cout = CO;
     a.apply_act = 1; a.slope = 0.1f; a.tiles_x = W / 16; a.tiles_y = H / 16; a.ncb = CO / 32; a.y_vec4 = 1; a.dil = 1;
     const long nblk = (long)N * a.tiles_x * a.tiles_y * a.ncb;
+    a.ntiles = (int)nblk;
     const double gf = 2.0 * N * H * W * 9.0 * C * CO / 1e9;
     const size_t L1 = (size_t)WinoGeom<2>::STAGE * 4;
     // interleaved A/B rounds without idle gaps (a D2H copy between runs lets the clocks drop)
-    const char* names[] = {"nopipe", "pipe", "pipe noDMA", "pipe same-acc chains", "noDMA", "noMFMA", "none"};
+    const char* names[] = {"nopipe", "pipe", "pipe noDMA", "pipe persistent", "noDMA", "noMFMA", "none"};
     float best[7]; for (auto& v : best) v = 1e9f;
     for (int round = 0; round < (pmc ? 1 : 5); ++round) {
         float t[7];
-        t[0] = run(conv3x3_wino_kernel<0>, a, nblk, L1, pmc ? 1 : 10);
-        t[1] = run(conv3x3_wino_kernel<0, 2, 1>, a, nblk, L1, pmc ? 1 : 10);
-        t[2] = run(conv3x3_wino_kernel<3, 2, 1>, a, nblk, L1, pmc ? 1 : 10);
-        t[3] = run(conv3x3_wino_kernel<16, 2, 1>, a, nblk, L1, pmc ? 1 : 10);
+        printf("[0]"); t[0] = run(conv3x3_wino_kernel<0>, a, nblk, L1, pmc ? 1 : 10);
+        printf("[1]"); t[1] = run(conv3x3_wino_kernel<0, 2, 1>, a, nblk, L1, pmc ? 1 : 10);
+        printf("[2]"); t[2] = run(conv3x3_wino_kernel<3, 2, 1>, a, nblk, L1, pmc ? 1 : 10);
+        printf("[3]"); t[3] = run(conv3x3_wino_kernel<0, 2, 1, 0, 1>, a, 512, L1, pmc ? 1 : 10);
         t[4] = run(conv3x3_wino_kernel<3>, a, nblk, L1, pmc ? 1 : 10);
         t[5] = run(conv3x3_wino_kernel<4>, a, nblk, L1, pmc ? 1 : 10);
         t[6] = run(conv3x3_wino_kernel<7>, a, nblk, L1, pmc ? 1 : 10);
@@ -46,6 +48,9 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 7; ++i) { printf(" %s %.1f |", names[i], t[i]); if (t[i] < best[i]) best[i] = t[i]; }
         printf("\n");
     }
+    hipMemset(y, 0, (size_t)N * H * W * CO * 4);
+    run(conv3x3_wino_kernel<0, 2, 1, 0, 1>, a, 512, L1, 1);
+    printf("persistent checksum %.3f\n", checksum(y, (size_t)N * H * W * CO));
     run(conv3x3_wino_kernel<0, 2, 1>, a, nblk, L1, 1);
     printf("pipe checksum %.3f\n", checksum(y, (size_t)N * H * W * CO));
     run(conv3x3_wino_kernel<0>, a, nblk, L1, 1);
