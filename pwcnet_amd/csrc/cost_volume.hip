@@ -576,10 +576,15 @@ constexpr int CC_PSTR = 24;                          // patch row stride in pixe
 constexpr int CC_QS = 8;                             // channel quads per stage
 constexpr int CC_F1 = CC_QS * 8 * CC_PSTR * 4;       // floats of the f1 patch image of a stage
 constexpr int CC_STAGE = CC_F1 + CC_QS * 64 * 4;     // + f0 tile: 8192 floats = 32 KB
+// LDS images of a stage: 1 (the next stage waits in registers until the current one is read; 3
+// workgroups per CU hide the latencies) measured faster than 2 (2 workgroups per CU)
+#ifndef CC_NBUF
+#define CC_NBUF 1
+#endif
 
 template <bool WARP>
-__global__ __launch_bounds__(256) void cost_volume_coarse_kernel(const CvCoarseArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 stages
+__global__ __launch_bounds__(256, 3) void cost_volume_coarse_kernel(const CvCoarseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // CC_NBUF stage images
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     int blk = blockIdx.x;
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(256) void cost_volume_coarse_kernel(const CvCoarseA
     for (int st = 0; st < nst; ++st) {
         const bool more = st + 1 < nst;
         if (more) gload(st + 1);
-        const float* b = smem + (st & 1) * CC_STAGE;
+        const float* b = smem + (CC_NBUF == 2 ? (st & 1) * CC_STAGE : 0);
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
             const int q = 2 * wave + qq;
@@ -688,7 +693,8 @@ __global__ __launch_bounds__(256) void cost_volume_coarse_kernel(const CvCoarseA
                 acc[d] = fmaf(u[0], w[0], fmaf(u[1], w[1], fmaf(u[2], w[2], fmaf(u[3], w[3], acc[d]))));
             }
         }
-        if (more) lstore(st + 1, (st + 1) & 1);
+        if (CC_NBUF == 1) __syncthreads();               // single LDS image: everyone is done reading it
+        if (more) lstore(st + 1, CC_NBUF == 2 ? (st + 1) & 1 : 0);
         __syncthreads();
     }
 
@@ -726,7 +732,7 @@ extern "C" int pwc_cost_volume_coarse_f32(const float* f0, int f0_cs, const floa
     a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
     const long nblk = (long)N * a.tiles_x * a.tiles_y * 9;
     if (nblk >= (1L << 31)) return PWC_ERANGE;
-    const size_t lds = (size_t)2 * CC_STAGE * sizeof(float);
+    const size_t lds = (size_t)CC_NBUF * CC_STAGE * sizeof(float);
     if (flow)
         hipLaunchKernelGGL(cost_volume_coarse_kernel<true>, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
     else

@@ -491,7 +491,7 @@ class CostVolumeLayer(_Module):
 
     # pixels per batch up to which the coarse-level kernel (warp + cost volume + f0 copy in one
     # launch) is used.  Measured at batch 8: 7x16 level 11.5 us vs 48 us for the three separate
-    # launches, 14x32 level 25 vs 44 us, 28x64 level 48 vs 41 us (the streaming kernels win)
+    # launches, 14x32 level 21 vs 44 us, 28x64 level 41 vs 41 us (no gain: the streaming kernels stay)
     COARSE_MAX_PIXELS = 4096
 
     def coarse_ok(self, f0):
