@@ -70,6 +70,15 @@ int pwc_warp_nearest_f32(const float* x, int x_cs, const float* flow, int flow_c
                          float flow_scale, float* out, int out_cs,
                          int N, int H, int W, int C, pwc_stream_t stream);
 
+/* ---- a2/a3 + the f0 part of tf.concat (modules.py:264) in one launch ----
+ * pwc_warp_bilinear_f32 (bilinear != 0) or pwc_warp_nearest_f32 (bilinear == 0), and in the same
+ * launch a copy of copy_C channels of every pixel of copy_src into copy_dst (copy_C == 0: none).
+ * copy_C % 4 == 0, copy strides % 4 == 0, 16-byte aligned. */
+int pwc_warp_copy_f32(int bilinear, const float* x, int x_cs, const float* flow, int flow_cs,
+                      float flow_scale, float* out, int out_cs, int N, int H, int W, int C,
+                      const float* copy_src, int copy_src_cs, float* copy_dst, int copy_dst_cs,
+                      int copy_C, pwc_stream_t stream);
+
 /* ---- a2+a1 (+ the f0 part of tf.concat, modules.py:264) for the COARSE pyramid levels ----
  * One launch for model.py:105-112 on small feature maps (7x16 ... 28x64 pixels per image), where
  * separate warp / cost-volume / copy launches are latency-bound: out as pwc_cost_volume_f32 of

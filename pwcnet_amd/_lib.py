@@ -28,6 +28,7 @@ SIGNATURES = {
     "pwc_warp_nearest_f32": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _vp]),
     "pwc_cost_volume_coarse_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_resize_bilinear_pair_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "pwc_warp_copy_f32": (_i, [_i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "pwc_warp_cost_volume_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_conv3x3_packed_floats": (_sz, [_i, _i]),
     "pwc_conv3x3_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -13,20 +13,34 @@ struct WarpArgs {
     int x_cs, flow_cs, out_cs;
     int H, W, C4;     // C4 = C / 4
     float flow_scale;
-    long total;       // N*H*W*C4
+    int rows;         // N * H
+    // optional second job of the same launch: copy CC4 channel quads of every pixel of cp_src into
+    // cp_dst (the features_0 part of the estimator input's tf.concat, modules.py:264)
+    const float* cp_src;
+    float* cp_dst;
+    int cp_src_cs, cp_dst_cs, CC4;
 };
 
+// grid.y walks the rows (n, y), grid.x the (x, channel quad) elements of a row -- first the warp's,
+// then the copy job's; 32-bit index math (the first version decomposed a flat 64-bit index with
+// four 64-bit divisions per element).
 template <bool BILINEAR>
 __global__ __launch_bounds__(256) void warp_kernel(const WarpArgs a) {
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < a.total;
-         idx += (long)gridDim.x * blockDim.x) {
-        const int cq = (int)(idx % a.C4);
-        const long pix = idx / a.C4;
-        const int gx = (int)(pix % a.W);
-        const long r = pix / a.W;
-        const int gy = (int)(r % a.H);
-        const long n = r / a.H;
-        const float* fp = a.flow + (size_t)pix * a.flow_cs;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    const unsigned nw = (unsigned)a.W * (unsigned)a.C4;
+    if (e >= nw + (unsigned)a.W * (unsigned)a.CC4) return;
+    const bool is_copy = e >= nw;
+    const unsigned ee = is_copy ? e - nw : e, cv = is_copy ? (unsigned)a.CC4 : (unsigned)a.C4;
+    const int gx = (int)(ee / cv), cq = (int)(ee - (unsigned)gx * cv);
+    for (int row = blockIdx.y; row < a.rows; row += gridDim.y) {
+        const size_t pix = (size_t)row * a.W + gx;
+        if (is_copy) {
+            *reinterpret_cast<f32x4*>(a.cp_dst + pix * a.cp_dst_cs + cq * 4) =
+                *reinterpret_cast<const f32x4*>(a.cp_src + pix * a.cp_src_cs + cq * 4);
+            continue;
+        }
+        const int n = row / a.H, gy = row - n * a.H;
+        const float* fp = a.flow + pix * a.flow_cs;
         const float fx = fp[0] * a.flow_scale, fy = fp[1] * a.flow_scale;
         const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs + cq * 4;
         f32x4 v;
@@ -53,41 +67,54 @@ __global__ __launch_bounds__(256) void warp_kernel(const WarpArgs a) {
             xx = min(max(xx, 0), a.W - 1);
             v = *reinterpret_cast<const f32x4*>(xn + ((size_t)yy * a.W + xx) * a.x_cs);
         }
-        *reinterpret_cast<f32x4*>(a.out + (size_t)pix * a.out_cs + cq * 4) = v;
+        *reinterpret_cast<f32x4*>(a.out + pix * a.out_cs + cq * 4) = v;
     }
 }
 
 static int warp_common(bool bilinear, const float* x, int x_cs, const float* flow, int flow_cs,
                        float flow_scale, float* out, int out_cs, int N, int H, int W, int C,
+                       const float* cp_src, int cp_src_cs, float* cp_dst, int cp_dst_cs, int cp_C,
                        pwc_stream_t stream) {
     if (!x || !flow || !out) return PWC_EINVAL;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return PWC_EINVAL;
     if (x_cs < C || out_cs < C || flow_cs < 2) return PWC_EINVAL;
     if ((C & 3) || (x_cs & 3) || (out_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(out)) return PWC_EALIGN;
+    if (cp_C < 0 || (cp_C > 0 && (!cp_src || !cp_dst || cp_src_cs < cp_C || cp_dst_cs < cp_C))) return PWC_EINVAL;
+    if (cp_C > 0 && ((cp_C & 3) || (cp_src_cs & 3) || (cp_dst_cs & 3) || !pwc_aligned16(cp_src) || !pwc_aligned16(cp_dst)))
+        return PWC_EALIGN;
+    if ((long)N * H >= (1L << 31) || (long)W * (C + cp_C) >= (1L << 31)) return PWC_ERANGE;
     WarpArgs a;
     a.x = x; a.flow = flow; a.out = out;
     a.x_cs = x_cs; a.flow_cs = flow_cs; a.out_cs = out_cs;
     a.H = H; a.W = W; a.C4 = C / 4; a.flow_scale = flow_scale;
-    a.total = (long)N * H * W * a.C4;
-    long blocks = (a.total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    a.rows = N * H;
+    a.cp_src = cp_src; a.cp_dst = cp_dst; a.cp_src_cs = cp_src_cs; a.cp_dst_cs = cp_dst_cs; a.CC4 = cp_C / 4;
+    const dim3 grid((unsigned)(((long)W * (a.C4 + a.CC4) + 255) / 256), (unsigned)(a.rows < 65535 ? a.rows : 65535));
     if (bilinear)
-        hipLaunchKernelGGL(warp_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(warp_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(warp_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(warp_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     return pwc_launch_status();
 }
 
 extern "C" int pwc_warp_bilinear_f32(const float* x, int x_cs, const float* flow, int flow_cs,
                                      float flow_scale, float* out, int out_cs, int N, int H, int W, int C,
                                      pwc_stream_t stream) {
-    return warp_common(true, x, x_cs, flow, flow_cs, flow_scale, out, out_cs, N, H, W, C, stream);
+    return warp_common(true, x, x_cs, flow, flow_cs, flow_scale, out, out_cs, N, H, W, C, nullptr, 0, nullptr, 0, 0, stream);
 }
 
 extern "C" int pwc_warp_nearest_f32(const float* x, int x_cs, const float* flow, int flow_cs,
                                     float flow_scale, float* out, int out_cs, int N, int H, int W, int C,
                                     pwc_stream_t stream) {
-    return warp_common(false, x, x_cs, flow, flow_cs, flow_scale, out, out_cs, N, H, W, C, stream);
+    return warp_common(false, x, x_cs, flow, flow_cs, flow_scale, out, out_cs, N, H, W, C, nullptr, 0, nullptr, 0, 0, stream);
+}
+
+extern "C" int pwc_warp_copy_f32(int bilinear, const float* x, int x_cs, const float* flow, int flow_cs,
+                                 float flow_scale, float* out, int out_cs, int N, int H, int W, int C,
+                                 const float* copy_src, int copy_src_cs, float* copy_dst, int copy_dst_cs,
+                                 int copy_C, pwc_stream_t stream) {
+    return warp_common(bilinear != 0, x, x_cs, flow, flow_cs, flow_scale, out, out_cs, N, H, W, C, copy_src,
+                       copy_src_cs, copy_dst, copy_dst_cs, copy_C, stream);
 }
 
 // ------------------------------------------------------------------ resize (a7)

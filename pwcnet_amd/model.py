@@ -138,6 +138,7 @@ class PWCDCNet(object):
                     self.cv_layer._run(f0, f1, cv_out, flow=flow_v, flow_scale=self.scales[l] if l > 0 else 1.0,
                                        f0_copy=f0_dst, coarse=True)
                 else:
+                    copied = False
                     if l == 0:
                         self.cv_layer._run(f0, f1, cv_out)
                     elif self.warp_type == "bilinear" and self.fuse_warp:
@@ -146,9 +147,15 @@ class PWCDCNet(object):
                         f1w_t = torch.empty((N, h, w, C), dtype=torch.float32, device=dev)
                         _keep(f1w_t)
                         f1w = View(f1w_t.data_ptr(), C, N, h, w, C)
-                        self.warp_layer._run(f1, flow_v, f1w, flow_scale=self.scales[l])
+                        # the f0 part of the concat rides in the warp launch
+                        fuse_copy = C % 4 == 0 and E.cs % 4 == 0
+                        self.warp_layer._run(f1, flow_v, f1w, flow_scale=self.scales[l],
+                                             copy=(f0, f0_dst) if fuse_copy else None)
                         self.cv_layer._run(f0, f1w, cv_out)
-                    _copy_channels(f0, f0_dst, C)
+                        if fuse_copy:
+                            copied = True
+                    if not copied:
+                        _copy_channels(f0, f0_dst, C)
 
                 flows_t = torch.empty((N, h, w, 2), dtype=torch.float32, device=dev)
                 _keep(flows_t)

@@ -461,13 +461,25 @@ class WarpingLayer(_Module):
         super().__init__(name)
         self.warp = warp_type
 
-    def _run(self, x, flow, out, flow_scale=1.0):
+    def _run(self, x, flow, out, flow_scale=1.0, copy=None):
+        """copy = (src view, dst view): also copies src's channels into dst in the same launch (the
+        features_0 part of the estimator input's concat, modules.py:264)."""
         assert self.warp in ["nearest", "bilinear"]
         L = _lib.lib()
+        nbytes = 4.0 * x.N * x.H * x.W * (2 * x.C + 2)
+        if copy is not None:
+            src, dst = copy
+            assert (src.N, src.H, src.W) == (x.N, x.H, x.W) and dst.C == src.C
+            _launch(L.pwc_warp_copy_f32,
+                    (1 if self.warp == "bilinear" else 0, _p(x.ptr), x.cs, _p(flow.ptr), flow.cs, float(flow_scale),
+                     _p(out.ptr), out.cs, x.N, x.H, x.W, x.C, _p(src.ptr), src.cs, _p(dst.ptr), dst.cs, src.C,
+                     _lib.current_stream()),
+                    f"warp_{self.warp}+copy", f"warp_kernel<{self.warp}>", 0.0, nbytes + 8.0 * x.N * x.H * x.W * src.C)
+            return
         fn = L.pwc_warp_bilinear_f32 if self.warp == "bilinear" else L.pwc_warp_nearest_f32
         _launch(fn, (_p(x.ptr), x.cs, _p(flow.ptr), flow.cs, float(flow_scale), _p(out.ptr), out.cs,
                      x.N, x.H, x.W, x.C, _lib.current_stream()),
-                f"warp_{self.warp}", f"warp_kernel<{self.warp}>", 0.0, 4.0 * x.N * x.H * x.W * (2 * x.C + 2))
+                f"warp_{self.warp}", f"warp_kernel<{self.warp}>", 0.0, nbytes)
 
     def __call__(self, x, flow):
         assert self.warp in ["nearest", "bilinear"]

@@ -417,6 +417,26 @@ def test_fused_warp_cost_volume_vs_oracle(pa, N, H, W, C):
     close(out, exp, rel=4e-6, floor=4e-7)
 
 
+@pytest.mark.parametrize("kind", ["bilinear", "nearest"])
+def test_warp_with_fused_copy(pa, kind):
+    """pwc_warp_copy_f32: the warp plus a channel-slice copy (the concat of features_0) in one launch."""
+    from pwcnet_amd.modules import View, sub_view
+    N, H, W, C = 2, 9, 21, 24
+    x, f0 = rnd((N, H, W, C), 51), rnd((N, H, W, C), 52)
+    flow = util.flow_field(N, H, W, seed=53) / 2.5
+    gx, g0, gf = gpu(x), gpu(f0), gpu(flow)
+    out = torch.empty((N, H, W, C), device="cuda")
+    E = torch.full((N, H, W, C + 12), -4.0, device="cuda")
+    Ev = View(E.data_ptr(), C + 12, N, H, W, C + 12)
+    pa.WarpingLayer(kind)._run(View(gx.data_ptr(), C, N, H, W, C), View(gf.data_ptr(), 2, N, H, W, 2),
+                               View(out.data_ptr(), C, N, H, W, C), flow_scale=2.5,
+                               copy=(View(g0.data_ptr(), C, N, H, W, C), sub_view(Ev, 8, C)))
+    torch.cuda.synchronize()
+    close(out, orc.warp(x, flow, kind, flow_scale=2.5), rel=2e-6, floor=1e-6)
+    assert torch.equal(E[..., 8:8 + C], g0)
+    assert float(E[..., :8].max()) == -4.0 and float(E[..., 8 + C:].max()) == -4.0
+
+
 @pytest.mark.parametrize("N,H,W,C,with_flow", [
     (2, 7, 16, 192, False), (2, 14, 32, 128, True), (1, 28, 64, 96, True), (3, 9, 21, 32, True),
     (1, 5, 3, 8, True), (1, 17, 10, 48, False), (2, 8, 8, 20, True)])
