@@ -247,6 +247,37 @@ def test_infer_cli_end_to_end(pa, tmp_path):
     assert all(os.path.exists(tmp_path / "o" / f"flow_level{l}.png") for l in range(5))
 
 
+def test_infer_continuous_cli(pa, tmp_path):
+    """infer_continuous.py (counterpart of reference test_continuous.py): a 4-frame sequence ->
+    3 consecutive pairs in one batch -> per-pair .flo + montage; checked against the oracle."""
+    import subprocess, sys
+    from PIL import Image
+    from pwcnet_amd import ckpt, flow_io
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.RandomState(7)
+    base = rng.uniform(0, 255, size=(66, 130, 3)).astype(np.uint8)
+    seq = tmp_path / "seq"
+    seq.mkdir()
+    frames = [np.roll(base, 2 * i, axis=1) for i in range(4)]
+    for i, f in enumerate(frames):
+        Image.fromarray(f).save(seq / f"frame_{i:02d}.png")
+    w = util.model_weights(False)
+    ckpt.save_weights(str(tmp_path / "m.ckpt"), w)
+    out = subprocess.run([sys.executable, os.path.join(root, "infer_continuous.py"), "-i", str(seq / "frame_*.png"),
+                          "-r", str(tmp_path / "m.ckpt"), "--out", str(tmp_path / "o")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Figure saved" in out.stdout
+    net = orc.OraclePWCDCNet(w)
+    for i in range(3):
+        flow = flow_io.read_flo(str(tmp_path / "o" / "seq" / f"frame_{i:02d}.flo"))
+        im = np.stack([frames[i][:64, :128], frames[i + 1][:64, :128]]).astype(np.float32) / 255.0
+        assert flow.shape == (64, 128, 2)
+        assert float(np.abs(flow - net(im[0:1], im[1:2])[0][0]).max()) <= 1e-3
+        assert os.path.exists(tmp_path / "o" / "seq" / f"frame_{i:02d}.png")
+    assert not os.path.exists(tmp_path / "o" / "seq" / "frame_03.flo")
+
+
 def test_evaluate_cli_end_to_end(pa, tmp_path):
     """evaluate.py: list of PNG pairs + ground-truth .flo -> sharded forward ->
     EPE; with the oracle's own flows as ground truth the EPE must vanish, and the saved flows
