@@ -354,3 +354,33 @@ def test_winograd_and_direct_convs_agree_end_to_end(pa):
     assert float((a - b).abs().max()) <= 2e-4
     e, _ = orc.OraclePWCDCNet(w)(im0, im1)
     assert float(np.abs(a.cpu().numpy() - e).max()) <= 1e-3 and float(np.abs(b.cpu().numpy() - e).max()) <= 1e-3
+
+
+def test_bench_json_contract(pa):
+    """bench.py prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline`
+    (small configuration so that the test takes seconds)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--batch", "2", "--height", "128", "--width", "192", "--cpu-seconds", "1"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "pairs/s" and d["scaling"] == "weak" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["value"] > 0
+    assert d["parity"]["max_abs_flows_final"] <= d["parity"]["tolerance"]
