@@ -210,3 +210,39 @@ def epe(flows_gt, flows):
     """losses.py:11-13: mean over all pixels of the L2 norm of the flow difference."""
     d = np.asarray(flows_gt, np.float64) - np.asarray(flows, np.float64)
     return float(np.mean(np.sqrt(np.sum(d * d, axis=3))))
+
+
+# ---------------------------------------------------------------- losses (reference losses.py)
+def resize_nearest(x, out_hw):
+    """tf.image.resize_nearest_neighbor, TF 1.8, align_corners=False (losses.py:27,43):
+    src = min(floor(dst * in/out), in - 1), scale computed in float32."""
+    n, h, w, c = x.shape
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    sy, sx = np.float32(h) / np.float32(oh), np.float32(w) / np.float32(ow)
+    iy = np.minimum(np.floor(np.arange(oh, dtype=np.float32) * sy).astype(np.int64), h - 1)
+    ix = np.minimum(np.floor(np.arange(ow, dtype=np.float32) * sx).astype(np.int64), w - 1)
+    return x[:, iy][:, :, ix]
+
+
+def L1loss(x, y):
+    """losses.py:4-5: reduce_mean over the batch of reduce_sum over (h, w) of the L1 norm over channels."""
+    return float(np.abs(x.astype(np.float64) - y).sum(axis=3).sum(axis=(1, 2)).mean())
+
+
+def L2loss(x, y):
+    """losses.py:7-8."""
+    return float(np.sqrt(((x.astype(np.float64) - y) ** 2).sum(axis=3)).sum(axis=(1, 2)).mean())
+
+
+def multiscale_loss(flows_gt, flows_pyramid, weights):
+    """losses.py:15-32."""
+    gt = flows_gt.astype(np.float32) / np.float32(20.0)
+    return sum(float(wt) * L2loss(resize_nearest(gt, fs.shape[1:3]), fs) for wt, fs in zip(weights, flows_pyramid))
+
+
+def multirobust_loss(flows_gt, flows_pyramid, weights, epsilon=0.01, q=0.4):
+    """losses.py:34-48 as evidently intended (the reference body uses an undefined name `loss_level`
+    where it means the level's L1 loss)."""
+    gt = flows_gt.astype(np.float32) / np.float32(20.0)
+    return sum(float(wt) * (L1loss(resize_nearest(gt, fs.shape[1:3]), fs) + epsilon) ** q
+               for wt, fs in zip(weights, flows_pyramid))

@@ -44,6 +44,8 @@ SIGNATURES = {
     "pwc_conv3x3_direct_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_resize_bilinear_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_copy_channels_f32": (_i, [_vp, _i, _vp, _i, _l, _i, _vp]),
+    "pwc_flow_norm_workspace_floats": (_sz, [_i, _i, _i]),
+    "pwc_flow_norm_sums_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp]),
 }
 
 _lib = None

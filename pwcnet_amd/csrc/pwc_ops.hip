@@ -319,3 +319,77 @@ extern "C" const char* pwc_error_string(int code) {
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown pwc error";
     }
 }
+
+// ------------------------------------------------------------------ losses (forward)
+// reference losses.py:4-13 (L1loss / L2loss / EPE) and the per-level term of multiscale_loss /
+// multirobust_loss (losses.py:15-48): sum over the pixels of image n of
+//     || pred[n,y,x,0:2] - gt_scale * gt[n, floor(y*GH/H), floor(x*GW/W), 0:2] ||_ord ,  ord in {1, 2}
+// -- tf.image.resize_nearest_neighbor (TF 1.8, align_corners=False: src = floor(dst * in/out),
+// clipped) is folded into the read; GH = H, GW = W, gt_scale = 1: plain norm of the difference.
+// Deterministic: fixed-shape block partial sums, then one block per image adds them in order.
+struct FlowNormArgs {
+    const float* pred;
+    const float* gt;
+    float* partial;      // [N][gridDim.x]
+    int pred_cs, gt_cs;
+    int H, W, GH, GW;
+    float sy, sx, gt_scale;
+    int ord;
+};
+
+__global__ __launch_bounds__(256) void flow_norm_partial_kernel(const FlowNormArgs a) {
+    __shared__ float red[256];
+    const int n = blockIdx.y;
+    const int npix = a.H * a.W;
+    float s = 0.f;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
+        const int y = p / a.W, x = p - y * a.W;
+        const int gy = min((int)floorf((float)y * a.sy), a.GH - 1), gx = min((int)floorf((float)x * a.sx), a.GW - 1);
+        const float* pp = a.pred + ((size_t)n * npix + p) * a.pred_cs;
+        const float* gp = a.gt + (((size_t)n * a.GH + gy) * a.GW + gx) * a.gt_cs;
+        const float dx = gp[0] * a.gt_scale - pp[0], dy = gp[1] * a.gt_scale - pp[1];
+        s += a.ord == 1 ? fabsf(dx) + fabsf(dy) : sqrtf(dx * dx + dy * dy);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.partial[(size_t)n * gridDim.x + blockIdx.x] = red[0];
+}
+
+__global__ void flow_norm_final_kernel(const float* __restrict__ partial, int nparts, int nimg, float* __restrict__ out) {
+    // one thread per image: the few hundred partials are added in index order (deterministic)
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nimg) return;
+    float s = 0.f;
+    for (int i = 0; i < nparts; ++i) s += partial[(size_t)n * nparts + i];
+    out[n] = s;
+}
+
+extern "C" size_t pwc_flow_norm_workspace_floats(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    long parts = ((long)H * W + 255) / 256;
+    if (parts > 256) parts = 256;
+    return (size_t)N * parts;
+}
+
+extern "C" int pwc_flow_norm_sums_f32(const float* pred, int pred_cs, const float* gt, int gt_cs, int N, int H, int W,
+                                      int GH, int GW, float gt_scale, int ord, float* workspace,
+                                      size_t workspace_floats, float* out_sums, pwc_stream_t stream) {
+    if (!pred || !gt || !workspace || !out_sums) return PWC_EINVAL;
+    if (N <= 0 || H <= 0 || W <= 0 || GH <= 0 || GW <= 0 || pred_cs < 2 || gt_cs < 2) return PWC_EINVAL;
+    if (ord != 1 && ord != 2) return PWC_EUNSUPPORTED;
+    if ((long)H * W >= (1L << 31) || N > 65535) return PWC_ERANGE;
+    if (workspace_floats < pwc_flow_norm_workspace_floats(N, H, W)) return PWC_EINVAL;
+    FlowNormArgs a;
+    a.pred = pred; a.gt = gt; a.partial = workspace; a.pred_cs = pred_cs; a.gt_cs = gt_cs;
+    a.H = H; a.W = W; a.GH = GH; a.GW = GW;
+    a.sy = (float)GH / (float)H; a.sx = (float)GW / (float)W; a.gt_scale = gt_scale; a.ord = ord;
+    const int parts = (int)(pwc_flow_norm_workspace_floats(N, H, W) / N);
+    hipLaunchKernelGGL(flow_norm_partial_kernel, dim3((unsigned)parts, (unsigned)N), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(flow_norm_final_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                       (const float*)workspace, parts, N, out_sums);
+    return pwc_launch_status();
+}

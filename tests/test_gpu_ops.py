@@ -516,3 +516,33 @@ def test_copy_channels(pa):
     _copy_channels(View(src4.data_ptr(), 32, 2, 5, 7, 32), sub_view(View(dst.data_ptr(), 48, 2, 5, 7, 48), 8, 32), 32)
     torch.cuda.synchronize()
     assert torch.equal(dst[..., 8:40], src4)
+
+
+# ------------------------------------------------------------------ losses (forward)
+@pytest.mark.parametrize("N,H,W", [(2, 7, 16), (3, 64, 128), (1, 448, 1024), (4, 5, 3)])
+def test_losses_vs_oracle(pa, N, H, W):
+    """pwcnet_amd.losses (reference losses.py:4-48, forward values) against the oracle."""
+    from pwcnet_amd import losses
+    a, b = rnd((N, H, W, 2), 61) * 3.0, rnd((N, H, W, 2), 62) * 3.0
+    ga, gb = gpu(a), gpu(b)
+    assert float(losses.L1loss(ga, gb)) == pytest.approx(orc.L1loss(a, b), rel=2e-5)
+    assert float(losses.L2loss(ga, gb)) == pytest.approx(orc.L2loss(a, b), rel=2e-5)
+    assert float(losses.EPE(ga, gb)) == pytest.approx(orc.epe(a, b), rel=2e-5)
+    # strided views (a flow stored in a wider buffer)
+    wide = torch.full((N, H, W, 6), 7.0, device="cuda")
+    wide[..., 2:4] = gb
+    assert float(losses.EPE(ga, wide[..., 2:4])) == pytest.approx(orc.epe(a, b), rel=2e-5)
+
+
+def test_multiscale_losses_vs_oracle(pa):
+    from pwcnet_amd import losses
+    gt = rnd((2, 64, 128, 2), 63) * 40.0
+    pyr = [rnd((2, 64 // 2 ** (6 - l), 128 // 2 ** (6 - l), 2), 64 + l) for l in range(5)]
+    wts = [0.32, 0.08, 0.02, 0.01, 0.005]
+    g_gt, g_pyr = gpu(gt), [gpu(p) for p in pyr]
+    assert float(losses.multiscale_loss(g_gt, g_pyr, wts)) == pytest.approx(orc.multiscale_loss(gt, pyr, wts), rel=2e-5)
+    assert float(losses.multirobust_loss(g_gt, g_pyr, wts, 0.01, 0.4)) == pytest.approx(
+        orc.multirobust_loss(gt, pyr, wts, 0.01, 0.4), rel=2e-5)
+    # a non-integer downsampling ratio exercises floor(dst * in/out)
+    odd = [rnd((2, 3, 5, 2), 70)]
+    assert float(losses.multiscale_loss(g_gt, [gpu(odd[0])], [1.0])) == pytest.approx(orc.multiscale_loss(gt, odd, [1.0]), rel=2e-5)

@@ -205,3 +205,24 @@ def test_ops_match_golden(golden_dir):
     np.testing.assert_allclose(orc.resize_bilinear(g["rs_x"], (12, 20)), g["rs_x2"], atol=1e-6)
     np.testing.assert_allclose(orc.conv3x3(g["conv_x"], g["conv_k"], g["conv_b"], 2, 1, 0.1), g["conv_s2"], atol=1e-5)
     np.testing.assert_allclose(orc.conv3x3(g["conv_x"], g["conv_k"], g["conv_b"], 1, 4, 0.1), g["conv_d4"], atol=1e-5)
+
+
+# ------------------------------------------------------------------ losses (reference losses.py)
+def test_losses_restatement_known_answers():
+    """L1loss / L2loss / EPE / multiscale_loss on hand-computable inputs (losses.py:4-32) and the
+    TF-legacy nearest-neighbour downsampling (src = floor(dst * in/out))."""
+    x = np.zeros((2, 2, 3, 2), np.float32)
+    y = np.zeros_like(x)
+    y[0, :, :, 0], y[0, :, :, 1] = 3.0, 4.0            # image 0: every pixel differs by (3, 4)
+    assert orc.L1loss(x, y) == pytest.approx((6 * 7 + 0) / 2)
+    assert orc.L2loss(x, y) == pytest.approx((6 * 5 + 0) / 2)
+    assert orc.epe(x, y) == pytest.approx(6 * 5 / 12)
+    g = np.arange(8 * 8, dtype=np.float32).reshape(1, 8, 8, 1)
+    d = orc.resize_nearest(g, (4, 2))
+    np.testing.assert_array_equal(d[0, :, :, 0], g[0, ::2, ::4, 0])
+    d3 = orc.resize_nearest(g, (3, 3))                    # 8/3 = 2.667: rows/cols 0, 2, 5
+    np.testing.assert_array_equal(d3[0, :, :, 0], g[0][np.ix_([0, 2, 5], [0, 2, 5])][..., 0])
+    gt = np.full((1, 8, 8, 2), 20.0, np.float32)          # gt / 20 = 1 everywhere
+    pyr = [np.zeros((1, 2, 2, 2), np.float32), np.ones((1, 4, 4, 2), np.float32)]
+    assert orc.multiscale_loss(gt, pyr, [0.5, 2.0]) == pytest.approx(0.5 * 4 * np.sqrt(2.0) + 2.0 * 0.0)
+    assert orc.multirobust_loss(gt, pyr, [1.0, 1.0], epsilon=0.01, q=0.4) == pytest.approx((8 + 0.01) ** 0.4 + 0.01 ** 0.4)
