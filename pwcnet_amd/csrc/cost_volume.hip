@@ -120,8 +120,8 @@ __global__ __launch_bounds__(64 * CvGeom<R>::NW) void cost_volume_kernel(const C
             float fx = 0.f, fy = 0.f;
             if (inside) {
                 const float* fp = fln + (size_t)(y * a.W + x) * a.flow_cs;
-                fx = fp[0] * a.flow_scale;
-                fy = fp[1] * a.flow_scale;
+                fx = pwc_mul_rounded(fp[0], a.flow_scale);   // rounded product (see warp_kernel)
+                fy = pwc_mul_rounded(fp[1], a.flow_scale);
             }
             ld_fx[i] = fx;
             ld_fy[i] = fy;
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256, 3) void cost_volume_coarse_kernel(const CvCoar
             // bilinear_warp, modules.py:107-137: un-clipped floors give the weights, the four corner
             // indices are clipped independently
             const float* fl = a.flow + (((size_t)n * a.H + yy) * a.W + xx) * a.flow_cs;
-            const float fx = fl[0] * a.flow_scale, fy = fl[1] * a.flow_scale;
+            const float fx = pwc_mul_rounded(fl[0], a.flow_scale), fy = pwc_mul_rounded(fl[1], a.flow_scale);   // rounded product (see warp_kernel)
             const float fx0 = floorf(fx), fy0 = floorf(fy);
             const float fx1 = fx0 + 1.f, fy1 = fy0 + 1.f;
             const float hl = (float)(a.H - 1), wl = (float)(a.W - 1);

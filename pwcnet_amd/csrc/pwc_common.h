@@ -26,6 +26,15 @@ static inline void pwc_same_pad(int in, int stride, int dil, int* out, int* befo
     *before = total / 2;
 }
 
+// a * b rounded to fp32 and NOT contractible into a following add/sub (hipcc fuses `a * b - c` into
+// one fma otherwise -- __fmul_rn does not stop that): the reference computes such products as ops of
+// their own (resize coordinate in = i * scale, flow * scale), floor / fraction come from the ROUNDED value
+__device__ __forceinline__ float pwc_mul_rounded(float a, float b) {
+    float r = a * b;
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
 __device__ __forceinline__ float pwc_lrelu(float v, float slope) {
     // tf.nn.leaky_relu(x, alpha) = max(alpha*x, x)
     return fmaxf(v, slope * v);

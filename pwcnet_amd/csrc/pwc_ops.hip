@@ -41,7 +41,9 @@ __global__ __launch_bounds__(256) void warp_kernel(const WarpArgs a) {
         }
         const int n = row / a.H, gy = row - n * a.H;
         const float* fp = a.flow + pix * a.flow_cs;
-        const float fx = fp[0] * a.flow_scale, fy = fp[1] * a.flow_scale;
+        // the product is ROUNDED before floor / weights are taken from it (the reference multiplies in
+        // its own op, model.py:109); a contracted fma(flow, scale, -floor) is not the same number
+        const float fx = pwc_mul_rounded(fp[0], a.flow_scale), fy = pwc_mul_rounded(fp[1], a.flow_scale);
         const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs + cq * 4;
         f32x4 v;
         if (BILINEAR) {
@@ -141,13 +143,13 @@ __global__ __launch_bounds__(256) void resize_kernel(const ResizeArgs a) {
     const unsigned e = blockIdx.x * 256u + threadIdx.x;
     if (e >= (unsigned)a.OW * CV) return;
     const unsigned ox = CV == 1 ? e : e / CV, cv = CV == 1 ? 0 : e - ox * CV;
-    const float fx = (float)ox * a.sx;
+    const float fx = pwc_mul_rounded((float)ox, a.sx);   // rounded product, then floor / fraction (TF: in = i * scale)
     const int x0 = (int)floorf(fx);
     const int x1 = min(x0 + 1, a.W - 1);
     const float xl = fx - (float)x0;
     for (int row = blockIdx.y; row < a.rows; row += gridDim.y) {
         const int n = row / a.OH, oy = row - n * a.OH;
-        const float fy = (float)oy * a.sy;
+        const float fy = pwc_mul_rounded((float)oy, a.sy);
         const int y0 = (int)floorf(fy);
         const int y1 = min(y0 + 1, a.H - 1);
         const float yl = fy - (float)y0;
@@ -211,13 +213,13 @@ __global__ __launch_bounds__(256) void resize_pair_kernel(const ResizePairArgs a
     const unsigned e = blockIdx.x * 256u + threadIdx.x;
     if (e >= (unsigned)a.OW * upp) return;
     const unsigned ox = e / upp, un = e - ox * upp;
-    const float fx = (float)ox * a.sx;
+    const float fx = pwc_mul_rounded((float)ox, a.sx);   // rounded product, then floor / fraction (TF: in = i * scale)
     const int x0 = (int)floorf(fx);
     const int x1 = min(x0 + 1, a.W - 1);
     const float xl = fx - (float)x0;
     for (int row = blockIdx.y; row < a.rows; row += gridDim.y) {
         const int n = row / a.OH, oy = row - n * a.OH;
-        const float fy = (float)oy * a.sy;
+        const float fy = pwc_mul_rounded((float)oy, a.sy);
         const int y0 = (int)floorf(fy);
         const int y1 = min(y0 + 1, a.H - 1);
         const float yl = fy - (float)y0;
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(256) void flow_norm_partial_kernel(const FlowNormAr
     float s = 0.f;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
         const int y = p / a.W, x = p - y * a.W;
-        const int gy = min((int)floorf((float)y * a.sy), a.GH - 1), gx = min((int)floorf((float)x * a.sx), a.GW - 1);
+        const int gy = min((int)floorf(pwc_mul_rounded((float)y, a.sy)), a.GH - 1), gx = min((int)floorf(pwc_mul_rounded((float)x, a.sx)), a.GW - 1);
         const float* pp = a.pred + ((size_t)n * npix + p) * a.pred_cs;
         const float* gp = a.gt + (((size_t)n * a.GH + gy) * a.GW + gx) * a.gt_cs;
         const float dx = gp[0] * a.gt_scale - pp[0], dy = gp[1] * a.gt_scale - pp[1];

@@ -546,3 +546,65 @@ def test_multiscale_losses_vs_oracle(pa):
     # a non-integer downsampling ratio exercises floor(dst * in/out)
     odd = [rnd((2, 3, 5, 2), 70)]
     assert float(losses.multiscale_loss(g_gt, [gpu(odd[0])], [1.0])) == pytest.approx(orc.multiscale_loss(gt, odd, [1.0]), rel=2e-5)
+
+
+# ------------------------------------------------------------------ seeded random sweeps
+def _sweep_cases(seed, n):
+    rs = np.random.RandomState(seed)
+    return [tuple(int(v) for v in (rs.randint(1, 4), rs.randint(1, 70), rs.randint(1, 150))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_conv_winograd_random_sweep(pa, case):
+    """Seeded random shapes through every geometry of the Winograd kernel (16x16 / split / 4x64
+    blocks, 16 or 32 couts per workgroup, dilation 1..16, ragged edges) against the oracle."""
+    rs = np.random.RandomState(1000 + case)
+    N = int(rs.randint(1, 4))
+    dil = int(rs.choice([1, 1, 1, 2, 2, 3, 4, 8, 16]))
+    H, W = int(rs.randint(1, 40) * (1 if dil < 4 else 3)), int(rs.randint(1, 90) * (1 if dil < 4 else 2))
+    cin, cout = int(rs.choice([16, 32, 48, 64, 96])), int(rs.choice([16, 32, 48, 64, 96, 128]))
+    x = rnd((N, H, W, cin), 2000 + case)
+    k = rnd((3, 3, cin, cout), 3000 + case) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 4000 + case) * 0.1
+    slope = None if case % 5 == 0 else 0.1
+    close(run_conv_wino(x, k, b, slope, dil=dil), orc.conv3x3(x, k, b, 1, dil, slope), rel=2e-5)
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_conv_mfma_random_sweep(pa, case):
+    """Seeded random shapes / strides / dilations through the automatic plan of the direct MFMA kernel."""
+    rs = np.random.RandomState(5000 + case)
+    N, H, W = int(rs.randint(1, 4)), int(rs.randint(2, 60)), int(rs.randint(2, 120))
+    stride = int(rs.choice([1, 2]))
+    if stride == 2:
+        H, W = 2 * (H // 2 + 1), 2 * (W // 2 + 1)           # the reference only sees even sizes under stride 2
+    dil = 1 if stride == 2 else int(rs.choice([1, 2, 4]))
+    cin, cout = int(rs.choice([16, 32, 64, 96, 160])), int(rs.choice([16, 32, 64, 96, 128, 192]))
+    x = rnd((N, H, W, cin), 6000 + case)
+    k = rnd((3, 3, cin, cout), 7000 + case) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 8000 + case) * 0.1
+    close(run_conv_mfma(x, k, b, stride, dil, 0.1), orc.conv3x3(x, k, b, stride, dil, 0.1), rel=2e-5)
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_cost_volume_warp_resize_random_sweep(pa, case):
+    """Seeded random shapes through the cost-volume (streaming and coarse), warp and resize kernels."""
+    rs = np.random.RandomState(9000 + case)
+    N, H, W = int(rs.randint(1, 4)), int(rs.randint(1, 40)), int(rs.randint(1, 100))
+    C = int(rs.choice([4, 16, 32, 64, 96]))
+    f0, f1 = rnd((N, H, W, C), 9100 + case), rnd((N, H, W, C), 9200 + case)
+    flow = util.flow_field(N, H, W, seed=9300 + case) / 5.0
+    close(pa.CostVolumeLayer(4)(gpu(f0), gpu(f1)), orc.cost_volume(f0, f1, 4), rel=4e-6, floor=4e-7)
+    for wt in ("bilinear", "nearest"):
+        close(pa.WarpingLayer(wt)(gpu(f1), gpu(flow * 5.0)), orc.warp(f1, flow * 5.0, wt), rel=2e-6, floor=1e-6)
+    oh, ow = int(rs.randint(1, 3 * H + 1)), int(rs.randint(1, 3 * W + 1))
+    close(pa.resize_bilinear(gpu(f0), (oh, ow)), orc.resize_bilinear(f0, (oh, ow)), rel=1e-6, floor=1e-6)
+    if C % 32 == 0 or True:
+        from pwcnet_amd.modules import View
+        out = torch.empty((N, H, W, 81), device="cuda")
+        g0, g1, gf = gpu(f0), gpu(f1), gpu(flow)
+        pa.CostVolumeLayer(4)._run(View(g0.data_ptr(), C, N, H, W, C), View(g1.data_ptr(), C, N, H, W, C),
+                                   View(out.data_ptr(), 81, N, H, W, 81), flow=View(gf.data_ptr(), 2, N, H, W, 2),
+                                   flow_scale=5.0, coarse=N * H * W <= 4096)
+        torch.cuda.synchronize()
+        close(out, orc.cost_volume(f0, orc.warp(f1, flow, "bilinear", flow_scale=5.0), 4), rel=4e-6, floor=4e-7)
