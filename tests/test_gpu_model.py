@@ -384,3 +384,21 @@ def test_bench_json_contract(pa):
         assert k in c, k
     assert c["kind"] == "port" and c["value"] > 0
     assert d["parity"]["max_abs_flows_final"] <= d["parity"]["tolerance"]
+
+
+@pytest.mark.parametrize("gain,use_dc", [(1.35, False), (1.6, False), (1.25, True)])
+def test_e2e_large_flows_vs_oracle(pa, gain, use_dc):
+    """Kernels scaled up so that the network's flows reach several pixels (glorot weights give
+    ~1 px): the warps then move features by whole pixels at every level and the 1e-3 px bound
+    is tested at realistic magnitudes."""
+    w = util.model_weights(use_dc, gain=gain)
+    net = pa.PWCDCNet(use_dc=use_dc)
+    net.load_weights(w)
+    im0, im1 = util.smooth_images(2, 128, 192, seed=21, shift=(3, -5))
+    final, pyr = net(gpu(im0), gpu(im1))
+    e_final, e_pyr = orc.OraclePWCDCNet(w, use_dc=use_dc)(im0, im1)
+    mag = float(np.abs(e_final).max())
+    err = float(np.abs(final.cpu().numpy() - e_final).max())
+    print(f"gain {gain} use_dc {use_dc}: max |flow| {mag:.3f} px, max abs err {err:.3e}")
+    assert np.isfinite(mag) and mag >= 2.0, mag
+    assert err <= 1e-3
