@@ -2,26 +2,42 @@
 """bench.py -- image-pairs/sec of the PWC-Net forward at 448x1024 on N MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N > 1 is launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py`,
-  one rank per GPU.  A step = one PWCDCNet forward over this rank's batch of synthetic
-  pairs (default 8 x 448x1024, BASELINE.json configs[1]); inputs are resident in HBM
-  before the timed region.  Pairs shard across ranks with no data-path collective
-  (weak scaling); one RCCL all-gather of per-rank stats per run.  Rank 0 prints ONE
-  JSON line.
+  * `--gpus N` with no WORLD_SIZE in the environment: this process re-launches itself as
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    bench.py ...` (one rank per GPU, RCCL) and relays rank 0's JSON line -- for N = 1 the
+    forward runs in this process (`--spawn` forces the launcher, and with it the nccl
+    process group, at N = 1 too);
+  * launched BY torch.distributed.run (WORLD_SIZE set): runs as that rank; `--gpus` must
+    equal WORLD_SIZE or the run aborts (a silently ignored N measured the wrong thing).
+  A step = one PWCDCNet forward over this rank's batch of synthetic pairs (default
+  8 x 448x1024 per GPU, BASELINE.json configs[1]); inputs are resident in HBM before the
+  timed region.  Pairs shard across ranks with no data-path collective (weak scaling);
+  one RCCL all-gather of per-rank stats per run.  Rank 0 prints ONE JSON line.
+  `--config configs3` = PWCDCNet use_dc=True batch 8; `--config configs4` = 960x1920
+  batch 8 per GPU (BASELINE.json configs[4] is that on 2 GPUs: add --gpus 2);
+  `--config configs2` = configs[1] per GPU on 8 GPUs.
 
 Extra objects in the line:
-  roofline      dominant kernel (by summed duration): algorithmic flops / HIP-event
-                duration measured over the timed region, vs the fp32-MFMA peak;
-  roofline_hbm  the cost-volume (+fused warp) kernel against the HBM peak;
-  kernels       per-kernel launches / ms per step;
-  cpu_baseline  the CPU oracle (oracle/, a port -- the TF reference cannot run) timed on
-                the host cores on whole 448x1024 pairs, N=1 / rank 0 only;
-  parity        max-abs / EPE of flows_final between the HIP path and the oracle on the
-                cpu_baseline pair.
+  roofline       dominant kernel (by summed duration).  For the Winograd kernel `achieved`
+                 is the rate of the multiplies the MFMA units EXECUTE (a fraction of a
+                 hardware peak, always <= 1); the direct-convolution ("algorithmic") rate it
+                 replaces and the reduction factor are separate keys;
+  roofline_hbm   correlation + warp kernels, op-level leg: every pyramid level of the
+                 workload, flows ~ N(0, 3^2) px, buffers rotated through
+                 > 256 MB so the Infinity Cache does not serve them, HIP events per launch,
+                 bytes = N*h*w*(2C+81)*4 (cost volume) + N*h*w*(2C+2)*4 (warp);
+  roofline_hbm_in_step  the same kernels as they run inside the timed forward;
+  kernels        per-kernel launches / ms per step (untimed, fully instrumented pass);
+  cpu_baseline   the CPU oracle (oracle/, a port -- the TF reference cannot run) timed on
+                 the host cores on whole pairs of the bench shape, N=1 / rank 0 only;
+  parity         max-abs / EPE of flows_final between the HIP path and the oracle on the
+                 cpu_baseline pair.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,10 +49,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 chip peak
-PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
+
+CONFIGS = {
+    # name -> overrides (BASELINE.json `configs` indices)
+    "configs1": {},
+    "configs2": {"gpus": 8},
+    "configs3": {"use_dc": True},
+    "configs4": {"height": 960, "width": 1920},
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -45,10 +69,49 @@ def parse():
     ap.add_argument("--height", type=int, default=448)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--use-dc", action="store_true", help="dense-connection estimator (configs[3])")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="preset of BASELINE.json `configs` (overrides height/width/use-dc; configs2 also --gpus)")
+    ap.add_argument("--spawn", action="store_true", help="go through torch.distributed.run even for --gpus 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget")
     ap.add_argument("--no-op-timing", action="store_true", help="skip the per-launch HIP events")
-    return ap.parse_args()
+    ap.add_argument("--no-op-leg", action="store_true", help="skip the op-level correlation/warp leg")
+    ap.add_argument("--persistent-outputs", action="store_true",
+                    help="PWCDCNet(persistent_outputs=True): replays write into the plan's own output tensors")
+    args = ap.parse_args(argv)
+    if args.config:
+        for k, v in CONFIGS[args.config].items():
+            if k == "gpus":
+                if args.gpus == 1:
+                    args.gpus = v
+            else:
+                setattr(args, k, v)
+    return args
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn(args):
+    """Re-launch this script with one rank per GPU under torch.distributed.run; rank 0's
+    stdout (the JSON line) is this process's stdout."""
+    n_dev = torch.cuda.device_count()
+    if args.gpus > n_dev:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)]
+    cmd += [a for a in sys.argv[1:] if a != "--spawn"]
+    if args.config == "configs2" and "--gpus" not in sys.argv[1:]:
+        cmd += ["--gpus", str(args.gpus)]
+    return subprocess.call(cmd, env=env)
 
 
 # HIP events bracket the instrumented kernels in every SAMPLE_EVERY-th step of the timed region only:
@@ -58,15 +121,22 @@ SAMPLE_EVERY = 8
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and (args.gpus > 1 or args.spawn):
+        sys.exit(spawn(args))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"`python bench.py --gpus {args.gpus}` (it spawns the ranks itself) or pass the "
+                         "matching --nproc-per-node")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if env_world is not None:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl = RCCL on ROCm
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -79,7 +149,7 @@ def main():
     # identical seeded glorot-uniform weights on every rank
     specs = W.conv_specs(use_dc=args.use_dc)
     wts = W.init_weights(specs, seed=0)
-    net = pwcnet_amd.PWCDCNet(use_dc=args.use_dc)
+    net = pwcnet_amd.PWCDCNet(use_dc=args.use_dc, persistent_outputs=args.persistent_outputs)
     net.load_weights(wts)
 
     g = torch.Generator(device=dev)
@@ -102,18 +172,18 @@ def main():
     # dominant kernel.  (An event pair per launch costs ~19 % of the step on MI355X, so the
     # timed region below instruments only the dominant kernel and the correlation/warp
     # kernels -- a handful of launches per step.)
-    full = None
+    full_summary = None
     dominant = None
-    if not args.no_op_timing:
+    full_steps = min(args.steps, 5)
+    if not args.no_op_timing and full_steps > 0:
         full = OpTimer()
         with full:
-            for _ in range(min(args.steps, 5)):
+            for _ in range(full_steps):
                 net(im0, im1)
         full_summary = full.summary()
-        full_steps = min(args.steps, 5)
         dominant = max(full_summary.items(), key=lambda kv: kv[1]["ms"])[0]
 
-    timer = None if args.no_op_timing else OpTimer(only=(dominant, "cost_volume", "warp_kernel"))
+    timer = None if dominant is None else OpTimer(only=(dominant, "cost_volume", "warp_kernel"))
     sync_all()
     t0 = time.perf_counter()
     if timer is not None:
@@ -126,6 +196,7 @@ def main():
             out = net(im0, im1)
     sync_all()
     elapsed = time.perf_counter() - t0
+    del out
 
     stats = gather_stats(dict(pairs=float(B * args.steps), seconds=elapsed), dist, dev)
     max_elapsed = max(s["seconds"] for s in stats)
@@ -135,6 +206,11 @@ def main():
             dist.destroy_process_group()
         return
 
+    cfg_idx = None
+    if (B, H, Wd) == (8, 448, 1024):
+        cfg_idx = 3 if args.use_dc else (1 if world == 1 else (2 if world == 8 else None))
+    elif (B, H, Wd, args.use_dc, world) == (8, 960, 1920, False, 2):
+        cfg_idx = 4
     line = {
         "metric": "image_pairs_per_sec_448x1024" if (H, Wd) == (448, 1024) else f"image_pairs_per_sec_{H}x{Wd}",
         "value": total_pairs / max_elapsed,
@@ -149,13 +225,16 @@ def main():
         "dtype": "f32",
         "data": "synthetic (uniform[0,1) images, seeded glorot-uniform weights; trained weights absent)",
         "config": {
-            "workload": (f"batch={B} {H}x{Wd} random-init PWC-Net (PWCDCNet use_dc={args.use_dc}) forward "
-                         f"per GPU on {world}xMI355X"
-                         + (" = BASELINE.json configs[1]" if (B, H, Wd, args.use_dc) == (8, 448, 1024, False) else "")),
+            "workload": (f"batch={B} pairs per GPU, {H}x{Wd}, random-init PWC-Net (PWCDCNet use_dc={args.use_dc}) "
+                         f"forward on {world}xMI355X"
+                         + (f" = BASELINE.json configs[{cfg_idx}]" if cfg_idx is not None else "")),
             "global_batch": B * world,
+            "per_gpu_batch": B,
             "height": H,
             "width": Wd,
-            "parallelism": f"dp{world}: pairs sharded across ranks, no data-path collective",
+            "parallelism": f"dp{world}: pairs sharded across ranks, no data-path collective"
+                           + ("" if dist is None else "; RCCL all-gather of per-rank stats"),
+            "outputs": "persistent (plan-owned)" if args.persistent_outputs else "fresh tensors per call",
         },
     }
 
@@ -163,45 +242,51 @@ def main():
         summ = timer.summary()          # events recorded INSIDE the timed region (sampled steps)
         n_sampled = len(range(0, args.steps, SAMPLE_EVERY))
         dd = summ[dominant]
-        ach = dd["flops"] / (dd["ms"] * 1e-3) / 1e12
-        line["roofline"] = {"kernel": dominant, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                            "avg_launch_us": 1e3 * dd["ms"] / dd["launches"],
-                            "launches_per_step": dd["launches"] / n_sampled,
-                            "flops_per_launch": dd["flops"] / dd["launches"],
-                            "measured": f"HIP events around each launch of this kernel in every {SAMPLE_EVERY}th step of the "
-                                        f"timed region ({n_sampled} of {args.steps} steps)"}
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+        alg = dd["flops"] / (dd["ms"] * 1e-3) / 1e12
+        exe = dd["exec_flops"] / (dd["ms"] * 1e-3) / 1e12
+        roof = {"kernel": dominant, "bound": "mfma", "achieved": exe, "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": exe / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "avg_launch_us": 1e3 * dd["ms"] / dd["launches"],
+                "launches_per_step": dd["launches"] / n_sampled,
+                "flops_per_launch": dd["exec_flops"] / dd["launches"],
+                "algorithmic_tflops": alg,
+                "algorithmic_flops_per_launch": dd["flops"] / dd["launches"],
+                "algorithmic_over_executed": dd["flops"] / dd["exec_flops"],
+                "measured": f"HIP events around each launch of this kernel in every {SAMPLE_EVERY}th step of the "
+                            f"timed region ({n_sampled} of {args.steps} steps)",
+                "note": "achieved/frac = multiply-adds the MFMA units execute (Winograd: 16 per 2x2 outputs "
+                        "and 36 per 4x4 outputs instead of 9 per output, physical Cin); algorithmic_* = "
+                        "2*M*9*Cin*Cout of the direct convolution the launch replaces (SURVEY.md 8d)"}
+        prof = os.path.join(ROOT, "profiles")
+        pmc = os.path.join(prof, "pmc_traffic.json")
         if os.path.exists(pmc) and (B, H, Wd, args.use_dc) == (8, 448, 1024, False):
             # HBM bytes per launch from the committed PMC passes of this same workload
             # (scripts/gpu_pmc_traffic.sh; counters cannot be collected from inside the process)
             t = json.load(open(pmc))
             fam = t["kernels"].get(dominant.split("<")[0])
             if fam:
-                line["roofline"]["traffic"] = fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"]
-                line["roofline"]["traffic_unit"] = "bytes per launch (mean over the kernel's launches)"
-                line["roofline"]["traffic_source"] = "profiles/pmc_traffic.json: " + t["source"]
-        if dominant.startswith("conv3x3_wino"):
-            # Winograd F(2x2,3x3) executes 16 multiplies per 2x2 outputs instead of 36: `achieved`
-            # counts the ALGORITHMIC (direct-convolution) flops, so it can exceed the MFMA peak
-            line["roofline"]["executed_mfma_tflops"] = ach / 2.25
-            line["roofline"]["mfma_pipe_frac"] = ach / 2.25 / PEAK_F32_MFMA_TFLOPS
-            line["roofline"]["note"] = ("Winograd F(2x2,3x3): algorithmic flops = 2*M*9*Cin*Cout per launch; the MFMA "
-                                        "units execute 2.25x fewer (executed_mfma_tflops, mfma_pipe_frac)")
+                roof["traffic"] = fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"]
+                roof["traffic_unit"] = "bytes per launch (mean over the kernel's launches)"
+                roof["traffic_source"] = "profiles/pmc_traffic.json: " + t["source"]
+            busy = t.get("mfma_busy", {}).get(dominant.split("<")[0])
+            if busy:
+                roof["mfma_busy_pmc"] = busy
+        line["roofline"] = roof
         hb = [(k, d) for k, d in summ.items() if k.startswith(("cost_volume", "warp_kernel"))]
         if hb:
             ms = sum(d["ms"] for _, d in hb)
             by = sum(d["bytes"] for _, d in hb)
             a3 = by / (ms * 1e-3) / 1e9
-            line["roofline_hbm"] = {"kernel": "+".join(k for k, _ in hb), "bound": "hbm", "achieved": a3,
-                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a3 / PEAK_HBM_GBS,
-                                    "traffic": None, "ms_per_step": ms / n_sampled,
-                                    "per_kernel": {k: {"avg_us": 1e3 * d["ms"] / d["launches"],
-                                                       "gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9}
-                                                   for k, d in hb},
-                                    "measured": f"HIP events in every {SAMPLE_EVERY}th step of the timed region; bytes = N*h*w*(2C+81)*4 "
-                                                "(cost volume), N*h*w*(2C+2)*4 (warp), N*h*w*(3C+2+81)*4 (coarse-level fused warp + cost "
-                                                "volume + f0 copy), all 5 pyramid levels"}
+            line["roofline_hbm_in_step"] = {
+                "kernel": "+".join(k for k, _ in hb), "bound": "hbm", "achieved": a3,
+                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a3 / PEAK_HBM_GBS,
+                "ms_per_step": ms / n_sampled,
+                "per_kernel": {k: {"avg_us": 1e3 * d["ms"] / d["launches"],
+                                   "gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9} for k, d in hb},
+                "measured": f"HIP events in every {SAMPLE_EVERY}th step of the timed region (random-init net: flows "
+                            "~ 0); bytes = N*h*w*(2C+81)*4 (cost volume), N*h*w*(2C+2)*4 (warp), "
+                            "N*h*w*(2C+2+81)*4 (fused warp + cost volume), all 5 pyramid levels; the f0 concat "
+                            "copy that rides in some launches is NOT counted"}
         # per-kernel table from the untimed, fully instrumented profile pass
         kernels = {}
         for k, d in full_summary.items():
@@ -221,12 +306,101 @@ def main():
         line["kernels"] = kernels
         line["gpu_busy_ms_per_step_profile_pass"] = sum(d["ms"] for d in full_summary.values()) / full_steps
 
+    if not args.no_op_leg:
+        line["roofline_hbm"] = corr_warp_op_leg(net, B, H, Wd, dev)
+
     if world == 1 and not args.no_cpu_baseline:
         line.update(cpu_baseline_and_parity(net, wts, args, dev))
 
     print(json.dumps(line))
+    sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def corr_warp_op_leg(net, B, H, Wd, dev, reps=12):
+    """Op-level roofline of the correlation + warp kernels: for every pyramid
+    level of the workload the production launch sequence of PWCDCNet._forward (level 0: cost
+    volume; levels >= 1: warp by flows_up*scales[l], then cost volume) on random features and
+    flows ~ N(0, 3^2) level-pixels.  Each launch is bracketed by HIP events on the launch
+    stream; the operand sets rotate through > 256 MB so neither L2 nor the Infinity Cache
+    holds them between repetitions."""
+    from pwcnet_amd import modules as M
+    from pwcnet_amd.profiler import OpTimer
+    from pwcnet_amd.weights import pyramid_channels
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    chans = pyramid_channels(net.num_levels)
+    levels = []
+    for l in range(net.output_level + 1):
+        h, w = H >> (net.num_levels - l), Wd >> (net.num_levels - l)
+        levels.append((l, h, w, chans[l]))
+    timer = OpTimer()
+    per_level = {}
+    for l, h, w, C in levels:
+        # the estimator input buffer of this level, as PWCDCNet lays it out (non-DC geometry)
+        lay = net.of_estimators[l]._layout(81, C, l > 0, list(range(32)) if l > 0 else None)
+        est_cs = lay.n_phys
+        set_bytes = 4 * B * h * w * (3 * C + 2 + est_cs)
+        nsets = max(2, int(300e6 // set_bytes) + 1)
+        nsets = min(nsets, 64)
+        sets = []
+        for _ in range(nsets):
+            f0 = torch.randn((B, h, w, C), generator=g, device=dev)
+            f1 = torch.randn((B, h, w, C), generator=g, device=dev)
+            # flows_up are px/20 of the full-resolution motion; the warp multiplies by scales[l]
+            sc = net.scales[l] if l > 0 else 1.0
+            fl = torch.randn((B, h, w, 2), generator=g, device=dev) * (3.0 / sc)
+            E = torch.zeros((B, h, w, est_cs), device=dev)
+            f1w = torch.empty_like(f1)
+            sets.append((f0, f1, fl, E, f1w))
+
+        def run(s):
+            f0, f1, fl, E, f1w = s
+            v0 = M.View(f0.data_ptr(), C, B, h, w, C)
+            v1 = M.View(f1.data_ptr(), C, B, h, w, C)
+            Ev = M.View(E.data_ptr(), est_cs, B, h, w, est_cs)
+            cv_out = M.sub_view(Ev, lay.offset("cv"), 81)
+            f0_dst = M.sub_view(Ev, lay.offset("f0"), C)
+            flv = M.View(fl.data_ptr(), 2, B, h, w, 2)
+            net._corr_level(l, v0, v1, flv if l > 0 else None, cv_out, f0_dst, Ev, dev)
+
+        for s in sets[:2]:
+            run(s)
+        torch.cuda.synchronize()
+        with timer:
+            for r in range(reps):
+                run(sets[r % nsets])
+        torch.cuda.synchronize()
+        per_level[l] = dict(h=h, w=w, C=C, sets=nsets)
+        del sets
+    summ = timer.summary()
+    ms = sum(d["ms"] for d in summ.values())
+    by = sum(d["bytes"] for d in summ.values())
+    ach = by / (ms * 1e-3) / 1e9
+    return {"kernel": "+".join(summ), "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": ach / PEAK_HBM_GBS, "traffic": None,
+            "us_per_forward": 1e3 * ms / reps,
+            "algorithmic_bytes_per_forward": by / reps,
+            "per_kernel": {k: {"avg_us": 1e3 * d["ms"] / d["launches"], "gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
+                               "launches_per_forward": d["launches"] / reps} for k, d in summ.items()},
+            "measured": f"op-level leg: production launch sequence of every pyramid level (batch {B}), flows ~ "
+                        f"N(0,3^2) px, {reps} repetitions over operand sets rotating through > 256 MB, HIP events per "
+                        "launch; bytes = N*h*w*(2C+81)*4 per cost volume + N*h*w*(2C+2)*4 per warp "
+                        "(N*h*w*(2C+2+81)*4 for a fused launch); concat-copy bytes not counted"}
+
+
+def _physical_cores(cpus):
+    """Number of distinct (package, core) pairs among the logical CPUs `cpus` (sysfs topology);
+    falls back to len(cpus)."""
+    seen = set()
+    try:
+        for c in cpus:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+    except OSError:
+        return max(1, len(cpus))
+    return max(1, len(seen))
 
 
 def cpu_baseline_and_parity(net, wts, args, dev):
@@ -234,6 +408,15 @@ def cpu_baseline_and_parity(net, wts, args, dev):
     pairs of the bench shape, and compares the HIP forward with it on the first pair."""
     from oracle import oracle as orc
     H, Wd = args.height, args.width
+    # threads = physical cores this process may run on.  TF's intra-op pool would take every
+    # logical CPU, but for this OpenMP port the SMT siblings are a loss: measured on the GPU box
+    # (2 x 64 cores, 256 logical CPUs) 1.29 pairs/s on 128 threads vs 0.089 pairs/s on 256.
+    try:
+        usable = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = list(range(os.cpu_count() or 1))
+    threads = _physical_cores(usable)
+    orc.set_num_threads(threads)
     onet = orc.OraclePWCDCNet(wts, use_dc=args.use_dc)
     rng = np.random.RandomState(4321)
     n_done, t_cpu, first = 0, 0.0, None
@@ -251,9 +434,11 @@ def cpu_baseline_and_parity(net, wts, args, dev):
     got = final.cpu().numpy()
     return {
         "cpu_baseline": {"value": n_done / t_cpu, "unit": "pairs/s", "cores": orc.num_threads(), "kind": "port",
-                         "host_cpu_count": os.cpu_count(),
-                         "sample": f"{n_done} whole {H}x{Wd} pair(s), {t_cpu:.1f} s of CPU time; oracle/ C "
-                                   "restatement (OpenMP), same weights; the TF-1.8 reference cannot run here"},
+                         "host_cpu_count": os.cpu_count(), "cpus_in_affinity_mask": len(usable),
+                         "sample": f"{n_done} whole {H}x{Wd} pair(s), {t_cpu:.1f} s of wall time on "
+                                   f"{orc.num_threads()} OpenMP threads = one per physical core in this process's "
+                                   "affinity mask (SMT siblings measured 14x slower); oracle/ C restatement, same "
+                                   "weights; the TF-1.8 reference cannot run here"},
         "parity": {"max_abs_flows_final": float(np.abs(got - e_final).max()),
                    "epe": orc.epe(e_final, got), "tolerance": 1e-3,
                    "max_abs_flow_value": float(np.abs(e_final).max())},

@@ -187,13 +187,13 @@ int pwc_copy_channels_f32(const float* src, int src_cs, float* dst, int dst_cs,
 /* ---- losses (forward): reference losses.py:4-13 (L1loss, L2loss, EPE) and the per-level term of
  * multiscale_loss / multirobust_loss (losses.py:15-48) ----
  * out_sums[n] = sum over the H x W pixels of image n of
- *     || pred[n,y,x,0:2] - gt_scale * gt[n, floor(y*GH/H), floor(x*GW/W), 0:2] ||_ord ,  ord = 1 or 2;
+ *     || pred[n,y,x,0:2] - gt[n, floor(y*GH/H), floor(x*GW/W), 0:2] / gt_div ||_ord ,  ord = 1 or 2;
  * the nearest-neighbour downsampling of the ground truth (tf.image.resize_nearest_neighbor,
  * losses.py:27,43) is folded into the read (GH = H, GW = W for none).  Deterministic (fixed-order
  * partial sums in `workspace`, at least pwc_flow_norm_workspace_floats(N,H,W) floats). */
 size_t pwc_flow_norm_workspace_floats(int N, int H, int W);
 int pwc_flow_norm_sums_f32(const float* pred, int pred_cs, const float* gt, int gt_cs,
-                           int N, int H, int W, int GH, int GW, float gt_scale, int ord,
+                           int N, int H, int W, int GH, int GW, float gt_div, int ord,
                            float* workspace, size_t workspace_floats, float* out_sums,
                            pwc_stream_t stream);
 

@@ -110,3 +110,132 @@ def resize_bilinear_legacy(x, out_hw, dtype=np.float32):
     top = tl + (tr - tl) * xl_
     bot = bl + (br - bl) * xl_
     return top + (bot - top) * yl_
+
+
+# ---------------------------------------------------------------------------- assembly
+# Second, independent restatement of the ASSEMBLY (reference model.py:95-134 and the module
+# bodies modules.py:49-71, 239-285, 295-326), written against the reference text only -- not
+# against oracle/oracle.py -- so that a misreading of the concat order, the residuals, the
+# dense-connection prepend order, `scales[l]` or the final `*20.` in one of the two shows up as
+# a disagreement in tests/test_oracle.py.  Every tensor op the reference issues appears as ONE
+# numpy call in the reference's own order (tf.concat -> np.concatenate with the same list, `+=`
+# -> +, tf.image.resize_bilinear -> resize_bilinear_legacy, ...).  float64 by default: this is
+# the "exact arithmetic" rendering of the graph, the C oracle is its float32 rendering.
+
+class _Scope:
+    """Variable naming of tf.variable_scope + tf.layers.Conv2D: the k-th Conv2D created inside
+    a scope is '<scope>/conv2d' (k = 0) or '<scope>/conv2d_k'; re-entering a scope by name
+    restarts k (that is what lets the second extractor call re-use the first one's variables,
+    reference model.py:97-98, modules.py:58)."""
+
+    def __init__(self, weights, path):
+        self.w, self.path, self.k = weights, path, 0
+
+    def sub(self, name):
+        return _Scope(self.w, self.path + "/" + name)
+
+    def conv2d(self, x, filters, strides, dilation_rate, dtype):
+        n = self.path + "/conv2d" + ("" if self.k == 0 else f"_{self.k}")
+        self.k += 1
+        kern, bias = self.w[n + "/kernel"], self.w[n + "/bias"]
+        assert kern.shape == (3, 3, x.shape[3], filters), (n, kern.shape, x.shape, filters)
+        return conv3x3_same(x, kern, bias, stride=strides, dilation=dilation_rate, dtype=dtype)
+
+
+class LiteralPWCDCNet:
+    """reference model.py:74-134, literally."""
+
+    def __init__(self, weights, num_levels=6, search_range=4, warp_type="bilinear", use_dc=False,
+                 output_level=4, name="pwcdcnet", dtype=np.float64):
+        self.w, self.dtype = weights, dtype
+        self.num_levels = num_levels                       # model.py:78
+        self.s_range = search_range                        # model.py:79
+        self.warp_type = warp_type                         # model.py:80
+        self.use_dc = use_dc                               # model.py:81
+        assert output_level < num_levels                   # model.py:82
+        self.output_level = output_level                   # model.py:83
+        self.name = name                                   # model.py:84
+        self.scales = [None, 0.625, 1.25, 2.5, 5.0, 10., 20.]   # model.py:93
+
+    # -- modules.py:49-71
+    def fp_extractor(self, vs, images):
+        sc = vs.sub("fp_extractor")                        # modules.py:58 (re-entered: k restarts)
+        filters = [16, 32, 64, 96, 128, 192]               # modules.py:46
+        features_pyramid = []
+        x = images
+        for l in range(self.num_levels):                   # modules.py:61-68
+            x = leaky_relu(sc.conv2d(x, filters[l], 2, 1, self.dtype), 0.1)
+            x = leaky_relu(sc.conv2d(x, filters[l], 1, 1, self.dtype), 0.1)
+            x = leaky_relu(sc.conv2d(x, filters[l], 1, 1, self.dtype), 0.1)
+            features_pyramid.append(x)
+        return features_pyramid[::-1]                      # modules.py:71
+
+    # -- modules.py:140-154 -> :83-137
+    def warp_layer(self, x, flow):
+        if self.warp_type == "nearest":
+            return nearest_warp(x, flow).astype(self.dtype)
+        return bilinear_warp(x, flow, dtype=self.dtype)
+
+    # -- modules.py:239-285
+    def of_estimator(self, vs, l, cv, features_0=None, flows_up_prev=None, features_up_prev=None,
+                     is_output=False):
+        sc = vs.sub(f"optflow_{l}")                        # model.py:89, modules.py:260
+        features = cv                                      # modules.py:261
+        for f in [features_0, flows_up_prev, features_up_prev]:      # modules.py:262
+            if f is not None:
+                features = np.concatenate([features, f], axis=3)    # modules.py:264
+        for f in [128, 128, 96, 64, 32]:                   # modules.py:235,266
+            conv = sc.conv2d(features, f, 1, 1, self.dtype)           # modules.py:267
+            conv = leaky_relu(conv, 0.1)                   # modules.py:268
+            if self.use_dc:
+                features = np.concatenate([conv, features], axis=3)  # modules.py:270
+            else:
+                features = conv                            # modules.py:272
+        flows = sc.conv2d(features, 2, 1, 1, self.dtype)   # modules.py:274 (no activation)
+        if flows_up_prev is not None:
+            flows = flows + flows_up_prev                  # modules.py:277
+        if is_output:
+            return flows, features                         # modules.py:280
+        h, w = flows.shape[1:3]
+        flows_up = resize_bilinear_legacy(flows, (2 * h, 2 * w), dtype=self.dtype)        # modules.py:283
+        features_up = resize_bilinear_legacy(features, (2 * h, 2 * w), dtype=self.dtype)  # modules.py:284
+        return flows, flows_up, features_up
+
+    # -- modules.py:295-326
+    def context(self, vs, flows, features):
+        sc = vs.sub("context")
+        x = np.concatenate([flows, features], axis=3)      # modules.py:305
+        for filt, rate in [(128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1)]:   # modules.py:306-323
+            x = leaky_relu(sc.conv2d(x, filt, 1, rate, self.dtype), 0.1)
+        x = sc.conv2d(x, 2, 1, 1, self.dtype)              # modules.py:324-325
+        return flows + x                                   # modules.py:326
+
+    # -- model.py:95-134
+    def __call__(self, images_0, images_1, with_features=False):
+        vs = _Scope(self.w, self.name)                     # model.py:96
+        images_0 = np.asarray(images_0, self.dtype)
+        images_1 = np.asarray(images_1, self.dtype)
+        pyramid_0 = self.fp_extractor(vs, images_0)        # model.py:97
+        pyramid_1 = self.fp_extractor(vs, images_1)        # model.py:98
+        flows_pyramid = []
+        flows_up, features_up = None, None                 # model.py:101
+        for l, (features_0, features_1) in enumerate(zip(pyramid_0, pyramid_1)):   # model.py:102
+            if l == 0:
+                features_1_warped = features_1             # model.py:107
+            else:
+                features_1_warped = self.warp_layer(features_1, flows_up * self.scales[l])   # model.py:109
+            cv = cost_volume(features_0, features_1_warped, self.s_range, 0.1, dtype=self.dtype)   # model.py:112
+            if l < self.output_level:
+                flows, flows_up, features_up = self.of_estimator(vs, l, cv, features_0, flows_up, features_up)   # model.py:115-116
+            else:
+                flows, features = self.of_estimator(vs, l, cv, features_0, flows_up, features_up,
+                                                    is_output=True)                 # model.py:119-120
+                flows = self.context(vs, flows, features)  # model.py:122
+                flows_pyramid.append(flows)                # model.py:123
+                upscale = 2 ** (self.num_levels - self.output_level)   # model.py:125
+                h, w = flows.shape[1:3]
+                flows_final = resize_bilinear_legacy(flows, (h * upscale, w * upscale), dtype=self.dtype) * 20.   # model.py:127
+                if with_features:
+                    return flows_final, flows_pyramid, pyramid_0        # model.py:130
+                return flows_final, flows_pyramid          # model.py:132
+            flows_pyramid.append(flows)                    # model.py:134

@@ -325,9 +325,10 @@ extern "C" const char* pwc_error_string(int code) {
 // ------------------------------------------------------------------ losses (forward)
 // reference losses.py:4-13 (L1loss / L2loss / EPE) and the per-level term of multiscale_loss /
 // multirobust_loss (losses.py:15-48): sum over the pixels of image n of
-//     || pred[n,y,x,0:2] - gt_scale * gt[n, floor(y*GH/H), floor(x*GW/W), 0:2] ||_ord ,  ord in {1, 2}
+//     || pred[n,y,x,0:2] - gt[n, floor(y*GH/H), floor(x*GW/W), 0:2] / gt_div ||_ord ,  ord in {1, 2}
 // -- tf.image.resize_nearest_neighbor (TF 1.8, align_corners=False: src = floor(dst * in/out),
-// clipped) is folded into the read; GH = H, GW = W, gt_scale = 1: plain norm of the difference.
+// clipped) is folded into the read; GH = H, GW = W, gt_div = 1: plain norm of the difference.  The ground truth is DIVIDED
+// (losses.py:20 `flows_gt/20.`), not multiplied by a reciprocal: x/20 and x*(1/20) differ by 1 ulp.
 // Deterministic: fixed-shape block partial sums, then one block per image adds them in order.
 struct FlowNormArgs {
     const float* pred;
@@ -335,7 +336,7 @@ struct FlowNormArgs {
     float* partial;      // [N][gridDim.x]
     int pred_cs, gt_cs;
     int H, W, GH, GW;
-    float sy, sx, gt_scale;
+    float sy, sx, gt_div;
     int ord;
 };
 
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256) void flow_norm_partial_kernel(const FlowNormAr
         const int gy = min((int)floorf(pwc_mul_rounded((float)y, a.sy)), a.GH - 1), gx = min((int)floorf(pwc_mul_rounded((float)x, a.sx)), a.GW - 1);
         const float* pp = a.pred + ((size_t)n * npix + p) * a.pred_cs;
         const float* gp = a.gt + (((size_t)n * a.GH + gy) * a.GW + gx) * a.gt_cs;
-        const float dx = gp[0] * a.gt_scale - pp[0], dy = gp[1] * a.gt_scale - pp[1];
+        const float dx = gp[0] / a.gt_div - pp[0], dy = gp[1] / a.gt_div - pp[1];
         s += a.ord == 1 ? fabsf(dx) + fabsf(dy) : sqrtf(dx * dx + dy * dy);
     }
     red[threadIdx.x] = s;
@@ -378,17 +379,18 @@ extern "C" size_t pwc_flow_norm_workspace_floats(int N, int H, int W) {
 }
 
 extern "C" int pwc_flow_norm_sums_f32(const float* pred, int pred_cs, const float* gt, int gt_cs, int N, int H, int W,
-                                      int GH, int GW, float gt_scale, int ord, float* workspace,
+                                      int GH, int GW, float gt_div, int ord, float* workspace,
                                       size_t workspace_floats, float* out_sums, pwc_stream_t stream) {
     if (!pred || !gt || !workspace || !out_sums) return PWC_EINVAL;
     if (N <= 0 || H <= 0 || W <= 0 || GH <= 0 || GW <= 0 || pred_cs < 2 || gt_cs < 2) return PWC_EINVAL;
     if (ord != 1 && ord != 2) return PWC_EUNSUPPORTED;
+    if (!(gt_div != 0.f)) return PWC_EINVAL;
     if ((long)H * W >= (1L << 31) || N > 65535) return PWC_ERANGE;
     if (workspace_floats < pwc_flow_norm_workspace_floats(N, H, W)) return PWC_EINVAL;
     FlowNormArgs a;
     a.pred = pred; a.gt = gt; a.partial = workspace; a.pred_cs = pred_cs; a.gt_cs = gt_cs;
     a.H = H; a.W = W; a.GH = GH; a.GW = GW;
-    a.sy = (float)GH / (float)H; a.sx = (float)GW / (float)W; a.gt_scale = gt_scale; a.ord = ord;
+    a.sy = (float)GH / (float)H; a.sx = (float)GW / (float)W; a.gt_div = gt_div; a.ord = ord;
     const int parts = (int)(pwc_flow_norm_workspace_floats(N, H, W) / N);
     hipLaunchKernelGGL(flow_norm_partial_kernel, dim3((unsigned)parts, (unsigned)N), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(flow_norm_final_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)stream,

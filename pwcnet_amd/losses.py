@@ -16,8 +16,8 @@ from . import _lib
 from .modules import _p, as_view
 
 
-def _norm_sums(pred, gt, ord, gt_scale=1.0):
-    """Per-image sums over the pixels of ||pred - gt_scale * nearest_downsample(gt)||_ord."""
+def _norm_sums(pred, gt, ord, gt_div=1.0):
+    """Per-image sums over the pixels of ||pred - nearest_downsample(gt) / gt_div||_ord."""
     pv, pred = as_view(pred, "flows")
     gv, gt = as_view(gt, "flows_gt")
     assert pv.C == 2 and gv.C == 2 and pv.N == gv.N, "flows must be (N,h,w,2)"
@@ -25,7 +25,7 @@ def _norm_sums(pred, gt, ord, gt_scale=1.0):
     ws = torch.empty((max(L.pwc_flow_norm_workspace_floats(pv.N, pv.H, pv.W), 1),), dtype=torch.float32, device=pred.device)
     out = torch.empty((pv.N,), dtype=torch.float32, device=pred.device)
     _lib.check(L.pwc_flow_norm_sums_f32(_p(pv.ptr), pv.cs, _p(gv.ptr), gv.cs, pv.N, pv.H, pv.W, gv.H, gv.W,
-                                        float(gt_scale), int(ord), _p(ws.data_ptr()), ws.numel(),
+                                        float(gt_div), int(ord), _p(ws.data_ptr()), ws.numel(),
                                         _p(out.data_ptr()), _lib.current_stream()), "flow norm sums")
     return out, pv
 
@@ -53,7 +53,7 @@ def multiscale_loss(flows_gt, flows_pyramid, weights, name="multiscale_loss"):
     nearest-neighbour-downsampled to every pyramid level inside."""
     loss = None
     for weight, fs in zip(weights, flows_pyramid):
-        sums, _ = _norm_sums(fs, flows_gt, 2, gt_scale=1.0 / 20.0)
+        sums, _ = _norm_sums(fs, flows_gt, 2, gt_div=20.0)
         term = float(weight) * sums.mean()
         loss = term if loss is None else loss + term
     return loss
@@ -63,7 +63,7 @@ def multirobust_loss(flows_gt, flows_pyramid, weights, epsilon=0.01, q=0.4, name
     """reference losses.py:34-48 (see the module docstring about its undefined name)."""
     loss = None
     for weight, fs in zip(weights, flows_pyramid):
-        sums, _ = _norm_sums(fs, flows_gt, 1, gt_scale=1.0 / 20.0)
+        sums, _ = _norm_sums(fs, flows_gt, 1, gt_div=20.0)
         term = float(weight) * (sums.mean() + float(epsilon)) ** float(q)
         loss = term if loss is None else loss + term
     return loss

@@ -14,6 +14,8 @@ TF graph.  Inside ``__call__`` the modules' zero-copy ``_run`` forms are compose
     flow read; `fuse_warp=True` instead gathers the warp inside the cost-volume kernel
     (measured slower on MI355X than the streaming warp kernel + LDS-DMA cost volume).
 """
+import collections
+
 import torch
 
 from . import _lib
@@ -21,13 +23,13 @@ from . import modules as _m
 from .modules import (ContextNetwork, CostVolumeLayer, FeaturePyramidExtractor_custom, LaunchPlan,
                       OpticalFlowEstimator_custom, VariableStore, View, WarpingLayer, _copy_channels,
                       _keep, _resize, as_view, sub_view, variable_scope)
-from .weights import ChannelLayout, SCALES
+from .weights import ChannelLayout, SCALES, conv_specs
 
 
 class PWCDCNet(object):
     def __init__(self, num_levels=6, search_range=4, warp_type="bilinear", use_dc=False,
                  output_level=4, name="pwcdcnet", seed=0, fuse_warp=False, use_plans=True, winograd=True,
-                 coarse_cv=True):
+                 coarse_cv=True, persistent_outputs=False, max_plans=4):
         self.num_levels = num_levels
         self.s_range = search_range
         self.warp_type = warp_type
@@ -51,26 +53,61 @@ class PWCDCNet(object):
             mod.winograd = bool(winograd)
         _lib.lib()  # fail now, loudly, if the HIP library is missing
         self.store = VariableStore(seed=seed)
-        self._buffers = {}
-        # launch plans (one per input shape): the forward is recorded once and replayed;
-        # returned tensors are then persistent buffers that the NEXT call overwrites
-        # (like fetching into pre-allocated outputs) -- clone() what must outlive it.
+        # launch plans (one per input shape, device, stream): the forward is recorded once and
+        # replayed.  Every plan owns its intermediate buffers (two forwards of one shape on
+        # different streams never share them); at most `max_plans` plans are kept (LRU), an
+        # evicted plan releases its buffers.
+        # Returned tensors are FRESH on every call, like the arrays sess.run hands back
+        # (reference test.py:51,55): the plan's output pointers are re-pointed at newly allocated
+        # tensors before each replay.  persistent_outputs=True opts into the zero-copy form in
+        # which a call returns the plan's own tensors and the NEXT call of that shape overwrites
+        # them (fetching into pre-allocated outputs).
         self.use_plans = use_plans
-        self._plans = {}
+        self.persistent_outputs = bool(persistent_outputs)
+        self.max_plans = max(1, int(max_plans))
+        self._plans = collections.OrderedDict()
+        self._buffers = {}     # buffer set of the forward being run (a plan's, or the eager one's)
+        self._eager_buffers = collections.OrderedDict()   # use_plans=False: (shape, device, stream) -> buffers
 
     # ------------------------------------------------------------------ variables
     @property
     def vars(self):
         return [v for v in self.store.vars.values() if self.name in v.name]
 
-    def load_weights(self, weights):
+    def load_weights(self, weights, strict=True):
         """weights: {'<name>/<scope>/conv2d[_k]/kernel' | '.../bias': array} (the
-        reference checkpoint's variable names, without the ':0')."""
+        reference checkpoint's variable names, without the ':0').
+
+        strict (default): the dict must hold exactly the variables of THIS configuration
+        (weights.conv_specs: names and shapes) -- like tf.train.Saver.restore, which raises on a
+        missing or mis-shaped tensor (reference test.py:39-40) instead of leaving the model on
+        its random initial values.  strict=False assigns whatever is given (shapes of variables
+        that already exist are still checked)."""
+        if strict:
+            specs = conv_specs(num_levels=self.num_levels, search_range=self.s_range, use_dc=self.use_dc,
+                               output_level=self.output_level, name=self.name)
+            want = {}
+            for vname, cin, cout in specs:
+                want[vname + "/kernel"] = (3, 3, cin, cout)
+                want[vname + "/bias"] = (cout,)
+            missing = sorted(set(want) - set(weights))
+            extra = sorted(set(weights) - set(want))
+            if missing or extra:
+                raise ValueError(
+                    f"load_weights: variable set does not match {self.name} (use_dc={self.use_dc}): "
+                    f"{len(missing)} missing (e.g. {missing[:3]}), {len(extra)} unexpected (e.g. {extra[:3]}); "
+                    "pass strict=False to assign a partial set")
+            for k, shp in want.items():
+                got = tuple(getattr(weights[k], "shape", ()))
+                if got != shp:
+                    raise ValueError(f"load_weights: {k} has shape {got}, this model needs {shp}")
         for k, v in weights.items():
             self.store.assign(k, v)
 
     # ------------------------------------------------------------------ buffers
     def _zeros(self, tag, shape, device):
+        """Zero-initialised level buffer of the forward being run (self._buffers is the buffer
+        set of the current plan / of the current (shape, device, stream) in eager mode)."""
         key = (tag,) + tuple(shape) + (str(device),)
         b = self._buffers.get(key)
         if b is None:
@@ -80,31 +117,72 @@ class PWCDCNet(object):
 
     # ------------------------------------------------------------------ forward
     def __call__(self, images_0, images_1, with_features=False, reuse=False):
+        """(flows_final, flows_pyramid[, pyramid_0]) as reference model.py:95-134.  The returned
+        tensors are new on every call unless the model was built with persistent_outputs=True
+        (then they are the launch plan's own tensors, overwritten by the next call of that shape)."""
         iv0, images_0 = as_view(images_0, "images_0")
         iv1, images_1 = as_view(images_1, "images_1")
         assert iv0[2:] == iv1[2:], "image batches must have equal shapes"
+        dev = images_0.device
+        stream = torch.cuda.current_stream().cuda_stream
         if not self.use_plans or iv0.ptr == iv1.ptr or _m._RECORDER is not None:
-            return self._forward(iv0, iv1, images_0.device, with_features)
-        key = (iv0[1:], str(images_0.device), torch.cuda.current_stream().cuda_stream, bool(with_features),
-               self.store.version)
+            # eager: buffers per (shape, device, stream), same LRU bound as the plans
+            bkey = (iv0[1:], str(dev), stream)
+            bufs = self._eager_buffers.pop(bkey, None)
+            self._eager_buffers[bkey] = self._buffers = {} if bufs is None else bufs
+            while len(self._eager_buffers) > self.max_plans:
+                self._eager_buffers.popitem(last=False)
+            return self._forward(iv0, iv1, dev, with_features)
+        key = (iv0[1:], str(dev), stream, bool(with_features), self.store.version)
         plan = self._plans.get(key)
         if plan is not None:
-            plan.replay({"images_0": iv0.ptr, "images_1": iv1.ptr})
-            return plan.outputs
+            self._plans.move_to_end(key)
+            patch = {"images_0": iv0.ptr, "images_1": iv1.ptr}
+            if self.persistent_outputs:
+                plan.replay(patch)
+                return plan.outputs
+            outputs = self._fresh_outputs(plan, patch)
+            plan.replay(patch)
+            if with_features:
+                # pyramid_0 are slices of the extractor's activations (plan-owned): copy them,
+                # stream-ordered after the replay
+                outputs = outputs + ([t.clone() for t in plan.outputs[2]],)
+            return outputs
         plan = LaunchPlan()
+        plan.buffers = self._buffers = {}
         _m._RECORDER = plan
         try:
-            outputs = self._forward(iv0, iv1, images_0.device, with_features)
+            outputs = self._forward(iv0, iv1, dev, with_features)
         finally:
             _m._RECORDER = None
+        out_ptrs = {}
+        small = [outputs[0]] + list(outputs[1])
+        for i, t in enumerate(small):
+            out_ptrs[t.data_ptr()] = f"out{i}"
         for ci, call in enumerate(plan.calls):
             for ai, arg in enumerate(call[1]):
-                if isinstance(arg, _lib.ctypes.c_void_p) and arg.value in (iv0.ptr, iv1.ptr):
+                if not isinstance(arg, _lib.ctypes.c_void_p):
+                    continue
+                if arg.value in (iv0.ptr, iv1.ptr):
                     plan.patch.setdefault("images_0" if arg.value == iv0.ptr else "images_1", []).append((ci, ai))
+                elif arg.value in out_ptrs:
+                    plan.patch.setdefault(out_ptrs[arg.value], []).append((ci, ai))
         plan.outputs = outputs
-        self._plans = {k: v for k, v in self._plans.items() if k[-1] == self.store.version}
+        for k in [k for k in self._plans if k[-1] != self.store.version]:
+            del self._plans[k]
         self._plans[key] = plan
+        while len(self._plans) > self.max_plans:
+            self._plans.popitem(last=False)          # least recently used; its buffers go with it
         return outputs
+
+    def _fresh_outputs(self, plan, patch):
+        """New flows_final / flows_pyramid tensors for this replay; their pointers are patched
+        into the recorded launches like the inputs'."""
+        old = plan.outputs
+        new = [torch.empty_like(t) for t in [old[0]] + list(old[1])]
+        for i, t in enumerate(new):
+            patch[f"out{i}"] = t.data_ptr()
+        return new[0], new[1:]
 
     def _forward(self, iv0, iv1, dev, with_features):
         N = iv0.N
@@ -133,29 +211,7 @@ class PWCDCNet(object):
                 cv_out = sub_view(E, lay.offset("cv"), (2 * self.s_range + 1) ** 2)
                 f0_dst = sub_view(E, lay.offset("f0"), C)
                 flow_v = sub_view(E, lay.offset("flow"), 2) if l > 0 else None
-                if self.coarse_cv and self.cv_layer.coarse_ok(f0) and (l == 0 or self.warp_type == "bilinear"):
-                    # coarse levels: warp + cost volume + the f0 part of the concat in ONE launch
-                    self.cv_layer._run(f0, f1, cv_out, flow=flow_v, flow_scale=self.scales[l] if l > 0 else 1.0,
-                                       f0_copy=f0_dst, coarse=True)
-                else:
-                    copied = False
-                    if l == 0:
-                        self.cv_layer._run(f0, f1, cv_out)
-                    elif self.warp_type == "bilinear" and self.fuse_warp:
-                        self.cv_layer._run(f0, f1, cv_out, flow=flow_v, flow_scale=self.scales[l])
-                    else:
-                        f1w_t = torch.empty((N, h, w, C), dtype=torch.float32, device=dev)
-                        _keep(f1w_t)
-                        f1w = View(f1w_t.data_ptr(), C, N, h, w, C)
-                        # the f0 part of the concat rides in the warp launch
-                        fuse_copy = C % 4 == 0 and E.cs % 4 == 0
-                        self.warp_layer._run(f1, flow_v, f1w, flow_scale=self.scales[l],
-                                             copy=(f0, f0_dst) if fuse_copy else None)
-                        self.cv_layer._run(f0, f1w, cv_out)
-                        if fuse_copy:
-                            copied = True
-                    if not copied:
-                        _copy_channels(f0, f0_dst, C)
+                self._corr_level(l, f0, f1, flow_v, cv_out, f0_dst, E, dev)
 
                 flows_t = torch.empty((N, h, w, 2), dtype=torch.float32, device=dev)
                 _keep(flows_t)
@@ -205,6 +261,34 @@ class PWCDCNet(object):
                     return flows_final, flows_pyramid, pyramid_0
                 else:
                     return flows_final, flows_pyramid
+
+    def _corr_level(self, l, f0, f1, flow_v, cv_out, f0_dst, E, dev):
+        """Warping + cost volume of pyramid level l (reference model.py:105-112) plus the
+        features_0 part of the estimator input's concat (modules.py:264): f1 is warped by
+        flow_v * scales[l] (l > 0) and correlated with f0 into cv_out; f0 is copied to f0_dst."""
+        N, h, w, C = f0.N, f0.H, f0.W, f0.C
+        if self.coarse_cv and self.cv_layer.coarse_ok(f0) and (l == 0 or self.warp_type == "bilinear"):
+            # coarse levels: warp + cost volume + the f0 part of the concat in ONE launch
+            self.cv_layer._run(f0, f1, cv_out, flow=flow_v, flow_scale=self.scales[l] if l > 0 else 1.0,
+                               f0_copy=f0_dst, coarse=True)
+            return
+        copied = False
+        if l == 0:
+            self.cv_layer._run(f0, f1, cv_out)
+        elif self.warp_type == "bilinear" and self.fuse_warp:
+            self.cv_layer._run(f0, f1, cv_out, flow=flow_v, flow_scale=self.scales[l])
+        else:
+            f1w_t = torch.empty((N, h, w, C), dtype=torch.float32, device=dev)
+            _keep(f1w_t)
+            f1w = View(f1w_t.data_ptr(), C, N, h, w, C)
+            # the f0 part of the concat rides in the warp launch
+            fuse_copy = C % 4 == 0 and E.cs % 4 == 0
+            self.warp_layer._run(f1, flow_v, f1w, flow_scale=self.scales[l],
+                                 copy=(f0, f0_dst) if fuse_copy else None)
+            self.cv_layer._run(f0, f1w, cv_out)
+            copied = fuse_copy
+        if not copied:
+            _copy_channels(f0, f0_dst, C)
 
     def _level_buffer(self, l, lay, N, h, w, dev, is_out):
         """Zero-initialised estimator buffer of level l.  At the output level with dense

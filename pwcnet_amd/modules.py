@@ -77,7 +77,7 @@ class LaunchPlan:
     allocations) runs once per input shape."""
 
     def __init__(self):
-        self.calls = []      # [fn, args(list), what, kernel name, flops, bytes]
+        self.calls = []      # [fn, args(list), what, kernel name, flops, bytes, executed flops]
         self.keep = []       # tensors whose memory the recorded pointers reference
         self.patch = {}      # input name -> [(call index, arg index)]
         self.outputs = None
@@ -87,9 +87,9 @@ class LaunchPlan:
             for ci, ai in self.patch.get(name, ()):
                 self.calls[ci][1][ai] = _p(ptr)
         timer = active_timer()
-        for fn, args, what, kname, flops, nbytes in self.calls:
+        for fn, args, what, kname, flops, nbytes, xflops in self.calls:
             if timer is not None and kname is not None and timer.wants(kname):
-                with timer.launch(kname, flops, nbytes):
+                with timer.launch(kname, flops, nbytes, xflops):
                     rc = fn(*args)
             else:
                 rc = fn(*args)
@@ -100,14 +100,16 @@ class LaunchPlan:
 _RECORDER = None
 
 
-def _launch(fn, args, what, kname=None, flops=0.0, nbytes=0.0):
+def _launch(fn, args, what, kname=None, flops=0.0, nbytes=0.0, exec_flops=None):
     """Enqueue one library call on torch's current stream (timed when an OpTimer is
-    active, recorded when a LaunchPlan is being built)."""
-    with timed(kname, flops, nbytes):
+    active, recorded when a LaunchPlan is being built).  flops / nbytes: ALGORITHMIC work
+    of the launch; exec_flops: what the MFMA units execute when that
+    differs (Winograd)."""
+    with timed(kname, flops, nbytes, exec_flops):
         rc = fn(*args)
     _lib.check(rc, what)
     if _RECORDER is not None:
-        _RECORDER.calls.append([fn, list(args), what, kname, flops, nbytes])
+        _RECORDER.calls.append([fn, list(args), what, kname, flops, nbytes, exec_flops])
 
 
 def _keep(*tensors):
@@ -258,7 +260,9 @@ class _ConvRunner:
                     (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
                      x.N, x.H, x.W, x.C, cout, dilation, act, sl, s),
                     f"conv3x3_wino {name}", "conv3x3_wino_kernel",
-                    2.0 * x.N * Ho * Wo * 9 * cin * cout, 4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout))
+                    2.0 * x.N * Ho * Wo * 9 * cin * cout, 4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout),
+                    # executed: 16 multiplies per 2x2 output tile, per physical input channel
+                    exec_flops=2.0 * x.N * (-(-Ho // 2)) * (-(-Wo // 2)) * 16 * x.C * cout)
         elif use_mfma:
             key = (name, "mfma", x.C, None if cin_map is None else cin_map.tobytes(), self.store.version)
             packed = cache.get(key)
@@ -474,7 +478,8 @@ class WarpingLayer(_Module):
                     (1 if self.warp == "bilinear" else 0, _p(x.ptr), x.cs, _p(flow.ptr), flow.cs, float(flow_scale),
                      _p(out.ptr), out.cs, x.N, x.H, x.W, x.C, _p(src.ptr), src.cs, _p(dst.ptr), dst.cs, src.C,
                      _lib.current_stream()),
-                    f"warp_{self.warp}+copy", f"warp_kernel<{self.warp}>", 0.0, nbytes + 8.0 * x.N * x.H * x.W * src.C)
+                    # algorithmic bytes of the WARP only; the concat copy riding along is not credited
+                    f"warp_{self.warp}+copy", f"warp_kernel<{self.warp}>", 0.0, nbytes)
             return
         fn = L.pwc_warp_bilinear_f32 if self.warp == "bilinear" else L.pwc_warp_nearest_f32
         _launch(fn, (_p(x.ptr), x.cs, _p(flow.ptr), flow.cs, float(flow_scale), _p(out.ptr), out.cs,
@@ -526,7 +531,8 @@ class CostVolumeLayer(_Module):
                      _p(f0_copy.ptr) if f0_copy is not None else None, f0_copy.cs if f0_copy is not None else 0,
                      f0.N, f0.H, f0.W, f0.C, self.s_range, 0.1, s),
                     "cost_volume_coarse", "cost_volume_coarse_kernel", flops,
-                    4.0 * npix * (2 * f0.C + D + (2 if flow is not None else 0) + (f0.C if f0_copy is not None else 0)))
+                    # (2C+81) or fused (2C+2+81) bytes per pixel; the f0 concat copy is not credited
+                    4.0 * npix * (2 * f0.C + D + (2 if flow is not None else 0)))
             return
         assert f0_copy is None
         if flow is None:

@@ -43,7 +43,9 @@ class OpTimer:
         return False
 
     @contextlib.contextmanager
-    def launch(self, kernel, flops=0.0, nbytes=0.0):
+    def launch(self, kernel, flops=0.0, nbytes=0.0, exec_flops=None):
+        """exec_flops: multiply-add flops the launch EXECUTES when that differs from the
+        algorithmic `flops` (Winograd kernels); defaults to `flops`."""
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
@@ -51,14 +53,16 @@ class OpTimer:
             yield
         finally:
             e.record()
-            self.records.append((kernel, float(flops), float(nbytes), s, e))
+            self.records.append((kernel, float(flops), float(nbytes), s, e,
+                                 float(flops if exec_flops is None else exec_flops)))
 
     def summary(self):
-        """{kernel: dict(launches, ms, flops, bytes)} -- synchronises the device."""
+        """{kernel: dict(launches, ms, flops, bytes, exec_flops)} -- synchronises the device."""
         torch.cuda.synchronize()
         out = collections.OrderedDict()
-        for k, fl, by, s, e in self.records:
-            d = out.setdefault(k, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        for k, fl, by, s, e, xf in self.records:
+            d = out.setdefault(k, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, exec_flops=0.0))
+            d["exec_flops"] += xf
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
             d["flops"] += fl
@@ -67,10 +71,10 @@ class OpTimer:
 
 
 @contextlib.contextmanager
-def timed(kernel, flops=0.0, nbytes=0.0):
+def timed(kernel, flops=0.0, nbytes=0.0, exec_flops=None):
     t = _ACTIVE
     if t is None or kernel is None or not t.wants(kernel):
         yield
     else:
-        with t.launch(kernel, flops, nbytes):
+        with t.launch(kernel, flops, nbytes, exec_flops):
             yield

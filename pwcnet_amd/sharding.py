@@ -46,8 +46,20 @@ def gather_flows(flows, n_total, dist=None):
     world = dist.get_world_size()
     sizes = [hi - lo for lo, hi in (shard_range(n_total, world, r) for r in range(world))]
     assert flows.shape[0] == sizes[dist.get_rank()], "shard does not match shard_range"
-    pad = torch.zeros((max(sizes),) + tuple(flows.shape[1:]), dtype=flows.dtype, device=flows.device)
-    pad[:flows.shape[0]] = flows
+    # a rank without pairs (n_total < world) only holds a placeholder: every rank pads to the
+    # trailing shape of the ranks that do hold pairs, agreed on by one small all-gather
+    mine = torch.tensor(list(flows.shape[1:]) if flows.shape[0] > 0 else [0] * (flows.dim() - 1),
+                        dtype=torch.int64, device=flows.device)
+    shapes = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(shapes, mine)
+    held = [tuple(int(v) for v in t.cpu().tolist()) for t, n in zip(shapes, sizes) if n > 0]
+    if not held:
+        return flows[:0]
+    trail = held[0]
+    assert all(h == trail for h in held), f"gather_flows: ranks hold different shapes {held}"
+    pad = torch.zeros((max(sizes),) + trail, dtype=flows.dtype, device=flows.device)
+    if flows.shape[0] > 0:
+        pad[:flows.shape[0]] = flows
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)

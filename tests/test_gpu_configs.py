@@ -1,0 +1,202 @@
+"""GPU parity tests at the FULL sizes of BASELINE.json `configs` (1, 3, 4), the fresh-output
+contract of PWCDCNet.__call__, per-stream plans, and bench.py's self-spawned launch.
+
+Tolerance: BASELINE.json north_star -- max-abs 1e-3 per flow component on flows_final (px).
+The oracle is run on single pairs (seconds of CPU each); batches are checked pair-wise.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pa():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU (torch.cuda.is_available() is False)")
+    import pwcnet_amd
+    return pwcnet_amd
+
+
+def gpu(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def make_net(pa, use_dc=False, **kw):
+    w = util.model_weights(use_dc)
+    net = pa.PWCDCNet(use_dc=use_dc, **kw)
+    net.load_weights(w)
+    return net, w
+
+
+# ------------------------------------------------------------------ BASELINE configs at size
+def test_config1_batch8_448x1024_winograd_pairs_vs_oracle(pa):
+    """configs[1]: batch 8 at 448x1024 on the default (Winograd) path -- the N = 8 tile plans, not
+    the single-pair ones: pairs 0 and 7 of the batch against the oracle run on those pairs."""
+    net, w = make_net(pa, False)
+    im0, im1 = util.smooth_images(8, 448, 1024, seed=41, shift=(5, -3))
+    final, pyr = net(gpu(im0), gpu(im1))
+    got = final.cpu().numpy()
+    assert got.shape == (8, 448, 1024, 2)
+    onet = orc.OraclePWCDCNet(w)
+    for i in (0, 7):
+        e_final, e_pyr = onet(im0[i:i + 1], im1[i:i + 1])
+        err = float(np.abs(got[i:i + 1] - e_final).max())
+        assert err <= 1e-3, (i, err)
+        for p, e in zip(pyr, e_pyr):
+            assert float(np.abs(p[i:i + 1].cpu().numpy() - e).max()) <= 5e-5
+
+
+def test_config3_dc_448x1024_vs_oracle_and_batch8(pa):
+    """configs[3]: PWCDCNet use_dc=True at 448x1024 -- the 2717-channel first conv of level 4 and
+    the 3165-channel context input at size; one pair against the oracle, then a batch of 8 in
+    which pairs 0 and 7 must reproduce the single-pair runs."""
+    net, w = make_net(pa, True)
+    im0, im1 = util.smooth_images(8, 448, 1024, seed=42, shift=(4, 2))
+    one, _ = net(gpu(im0[:1]), gpu(im1[:1]))
+    e_final, _ = orc.OraclePWCDCNet(w, use_dc=True)(im0[:1], im1[:1])
+    err = float(np.abs(one.cpu().numpy() - e_final).max())
+    assert err <= 1e-3, err
+    last, _ = net(gpu(im0[7:8]), gpu(im1[7:8]))
+    f8, _ = net(gpu(im0), gpu(im1))
+    assert f8.shape == (8, 448, 1024, 2)
+    # different batch sizes may pick different tile plans (same arithmetic, other summation order)
+    assert float((f8[0:1] - one).abs().max()) <= 2e-4
+    assert float((f8[7:8] - last).abs().max()) <= 2e-4
+
+
+def test_config4_960x1920_vs_oracle(pa):
+    """configs[4] frame size (KITTI-shaped): odd-sized coarse levels 15x30 / 30x60."""
+    net, w = make_net(pa, False)
+    im0, im1 = util.smooth_images(2, 960, 1920, seed=43, shift=(-6, 4))
+    final, pyr = net(gpu(im0), gpu(im1))
+    assert final.shape == (2, 960, 1920, 2)
+    assert [tuple(p.shape[1:3]) for p in pyr] == [(15, 30), (30, 60), (60, 120), (120, 240), (240, 480)]
+    e_final, e_pyr = orc.OraclePWCDCNet(w)(im0[1:2], im1[1:2])
+    err = float(np.abs(final[1:2].cpu().numpy() - e_final).max())
+    assert err <= 1e-3, err
+    for p, e in zip(pyr, e_pyr):
+        assert float(np.abs(p[1:2].cpu().numpy() - e).max()) <= 5e-5
+
+
+# ------------------------------------------------------------------ output ownership
+def test_outputs_are_fresh_tensors_by_default(pa):
+    """sess.run hands back new arrays on every call (reference test.py:51,55): a result held
+    across a later forward must not change."""
+    net, _ = make_net(pa, False)
+    x0, x1 = util.smooth_images(2, 64, 128, seed=51)
+    y0, y1 = util.smooth_images(2, 64, 128, seed=52, shift=(-2, 3))
+    a, pyr_a, feats_a = net(gpu(x0), gpu(x1), with_features=True)      # recording call
+    a_ref, pyr_ref, feats_ref = a.clone(), [p.clone() for p in pyr_a], [f.clone() for f in feats_a]
+    b, pyr_b, feats_b = net(gpu(y0), gpu(y1), with_features=True)      # first replay
+    c, pyr_c, feats_c = net(gpu(x0), gpu(x1), with_features=True)      # second replay
+    torch.cuda.synchronize()
+    assert torch.equal(a, a_ref) and all(torch.equal(p, q) for p, q in zip(pyr_a, pyr_ref))
+    assert all(torch.equal(p, q) for p, q in zip(feats_a, feats_ref))
+    assert not torch.equal(a, b)
+    assert torch.equal(c, a) and all(torch.equal(p, q) for p, q in zip(pyr_c, pyr_a))
+    assert all(torch.equal(p, q) for p, q in zip(feats_c, feats_a))
+    ptrs = {t.data_ptr() for t in (a, b, c)}
+    assert len(ptrs) == 3
+
+
+def test_persistent_outputs_opt_in_aliases(pa):
+    net, _ = make_net(pa, False, persistent_outputs=True)
+    x0, x1 = util.smooth_images(1, 64, 128, seed=53)
+    y0, y1 = util.smooth_images(1, 64, 128, seed=54, shift=(1, 1))
+    a, _ = net(gpu(x0), gpu(x1))
+    a_ref = a.clone()
+    b, _ = net(gpu(y0), gpu(y1))
+    assert b.data_ptr() == a.data_ptr() and not torch.equal(a, a_ref)   # overwritten, as documented
+
+
+def test_plans_are_per_stream_and_bounded(pa):
+    """Two forwards of one shape on different streams own different buffers (no race), and the
+    number of kept plans is bounded (LRU)."""
+    net, _ = make_net(pa, False, max_plans=2)
+    x0, x1 = util.smooth_images(2, 64, 128, seed=55)
+    y0, y1 = util.smooth_images(2, 64, 128, seed=56, shift=(2, -1))
+    gx0, gx1, gy0, gy1 = gpu(x0), gpu(x1), gpu(y0), gpu(y1)
+    ref_x, _ = net(gx0, gx1)
+    ref_y, _ = net(gy0, gy1)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(3):                      # record on each stream, then replay concurrently
+        with torch.cuda.stream(s1):
+            ox, _ = net(gx0, gx1)
+        with torch.cuda.stream(s2):
+            oy, _ = net(gy0, gy1)
+        outs.append((ox, oy))
+    torch.cuda.synchronize()
+    for ox, oy in outs:
+        assert torch.equal(ox, ref_x) and torch.equal(oy, ref_y)
+    assert len(net._plans) <= 2
+    bufs = [id(p.buffers) for p in net._plans.values()]
+    assert len(set(bufs)) == len(bufs)
+    for shape in ((1, 64, 64), (1, 64, 192), (1, 128, 128)):
+        im = util.images(shape[0], shape[1], shape[2], seed=57)
+        net(gpu(im[0]), gpu(im[1]))
+    assert len(net._plans) <= 2
+
+
+def test_load_weights_strict(pa):
+    w = util.model_weights(False)
+    net = pa.PWCDCNet()
+    with pytest.raises(ValueError, match="missing"):
+        net.load_weights({k: v for k, v in w.items() if "optflow_3" not in k})
+    with pytest.raises(ValueError, match="unexpected"):
+        net.load_weights(dict(w, **{"pwcdcnet/optflow_5/conv2d/kernel": np.zeros((3, 3, 4, 4), np.float32)}))
+    with pytest.raises(ValueError, match="missing|unexpected|shape"):
+        pa.PWCDCNet(use_dc=True).load_weights(w)            # non-DC checkpoint into a DC model
+    bad = dict(w)
+    k = "pwcdcnet/context/conv2d/kernel"
+    bad[k] = np.zeros((3, 3, 35, 128), np.float32)
+    with pytest.raises(ValueError, match="shape"):
+        net.load_weights(bad)
+    net.load_weights({k: w[k]}, strict=False)               # partial set, explicitly allowed
+    net.load_weights(w)
+
+
+# ------------------------------------------------------------------ bench.py launch
+def _run_bench(extra, timeout=900):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--batch", "2", "--height", "128", "--width", "192", "--cpu-seconds", "1"] + extra,
+                         capture_output=True, text=True, timeout=timeout)
+    return out
+
+
+def test_bench_spawns_its_ranks_with_rccl(pa):
+    """`bench.py --gpus 1 --spawn`: the self-launch path the driver's `--gpus N` takes -- one
+    torch.distributed.run rank per GPU, nccl (= RCCL) process group, stats all-gathered on
+    device tensors."""
+    out = _run_bench(["--gpus", "1", "--spawn"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 2 and d["config"]["per_gpu_batch"] == 2
+    assert "RCCL" in d["config"]["parallelism"]
+    assert d["roofline"]["frac"] <= 1.0 and d["roofline_hbm"]["frac"] <= 1.0
+    assert d["parity"]["max_abs_flows_final"] <= d["parity"]["tolerance"]
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus(pa):
+    """--gpus must never be silently ignored."""
+    more = torch.cuda.device_count() + 1
+    out = _run_bench(["--gpus", str(more)])
+    assert out.returncode != 0 and "GPU(s) are visible" in (out.stderr + out.stdout)
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)

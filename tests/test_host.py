@@ -153,6 +153,25 @@ def test_reference_index_without_data_blob_reports_missing(golden_dir):
     assert ckpt.crc32c(b"123456789") == 0xE3069283          # CRC-32C check value
 
 
+def test_load_weights_strict_rejects_wrong_variable_sets():
+    """tf.train.Saver.restore raises on a missing / mis-shaped tensor; so does load_weights
+    (checked before anything is copied to a device, so this runs without a GPU)."""
+    import pwcnet_amd
+    from pwcnet_amd import weights as W
+    w = W.init_weights(W.conv_specs())
+    net = pwcnet_amd.PWCDCNet()
+    with pytest.raises(ValueError, match="missing"):
+        net.load_weights({})
+    with pytest.raises(ValueError, match="missing"):
+        net.load_weights({k.replace("pwcdcnet/", "other/"): v for k, v in w.items()})
+    with pytest.raises(ValueError):
+        pwcnet_amd.PWCDCNet(use_dc=True).load_weights(w)
+    bad = dict(w)
+    bad["pwcdcnet/context/conv2d/bias"] = np.zeros((64,), np.float32)
+    with pytest.raises(ValueError, match="shape"):
+        net.load_weights(bad)
+
+
 # ------------------------------------------------------------------ sharding
 def test_shard_range_partitions():
     for n, world in [(64, 8), (8, 8), (10, 4), (3, 8), (0, 2)]:
@@ -232,6 +251,43 @@ def test_sharded_evaluation_world2_gloo(tmp_path):
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "EVAL_OK 2" in out.stdout
+
+
+_EMPTY_RANK_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from pwcnet_amd import sharding
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+N, h, wd = 1, 6, 10                        # ONE pair over 2 ranks: rank 1 holds nothing
+rs = np.random.RandomState(5)
+im = rs.rand(N, 2, h, wd, 3).astype(np.float32)
+gt = rs.normal(size=(N, h, wd, 2)).astype(np.float32)
+def load_pair(i):
+    return torch.from_numpy(im[i, 0]), torch.from_numpy(im[i, 1]), torch.from_numpy(gt[i])
+def forward(a, b):
+    return torch.stack([(a - b)[..., 0], (a + b)[..., 1]], dim=3)
+res = sharding.evaluate_pairs(forward, load_pair, N, batch=3, dist=dist, device="cpu", gather=True)
+pred = np.stack([im[:, 0, ..., 0] - im[:, 1, ..., 0], im[:, 0, ..., 1] + im[:, 1, ..., 1]], axis=3)
+assert tuple(res["flows"].shape) == (N, h, wd, 2) and np.allclose(res["flows"].numpy(), pred, atol=1e-6)
+assert res["pairs"] == 1 and len(res["per_pair_epe"]) == 1
+if r == 0:
+    print("EMPTY_RANK_OK", w)
+dist.destroy_process_group()
+"""
+
+
+def test_sharded_evaluation_with_an_empty_rank_gloo(tmp_path):
+    """n_pairs < world: the rank without pairs must pad to the shape the other ranks hold."""
+    script = tmp_path / "empty_worker.py"
+    script.write_text(_EMPTY_RANK_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29619", str(script), ROOT],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "EMPTY_RANK_OK 2" in out.stdout
 
 
 # ------------------------------------------------------------------ flow IO (f2)
