@@ -54,6 +54,11 @@ const char* pwc_error_string(int code);
 int pwc_cost_volume_f32(const float* f0, int f0_cs, const float* f1w, int f1w_cs,
                         float* out, int out_cs, int N, int H, int W, int C,
                         int search_range, float slope, pwc_stream_t stream);
+/* 1 if pwc_cost_volume_f32 runs its rolling-window kernel for this geometry (C = 32, search_range 4,
+ * 16-byte aligned operands, out_cs % 4 == 0, at least 4096 pixels per image), 0 for the tile kernel.
+ * Same results either way; exported so that profilers can name the launch. */
+int pwc_cost_volume_uses_rolling_kernel(int H, int W, int C, int search_range, int f0_cs, int f1_cs,
+                                        int out_cs);
 
 /* ---- a2: WarpingLayer(warp_type='bilinear') = bilinear_warp, modules.py:99-137 ----
  * out[n,y,x,:] = sum_{i,j} w_ij * x[n, clip(y+floor(fy)+i), clip(x+floor(fx)+j), :]

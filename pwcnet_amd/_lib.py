@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libpwc_hip.so")
 SOURCES = ["conv3x3_mfma.hip", "conv3x3_wino.hip", "conv3x3_direct.hip", "cost_volume.hip", "pwc_ops.hip"]
-HEADERS = ["pwc_common.h", os.path.join("..", "..", "include", "pwc_hip.h")]
+HEADERS = ["pwc_common.h", "cost_volume_roll.hip", os.path.join("..", "..", "include", "pwc_hip.h")]
 
 _vp, _i, _f, _l, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long, ctypes.c_size_t
 
@@ -24,6 +24,7 @@ SIGNATURES = {
     "pwc_version": (_i, []),
     "pwc_error_string": (ctypes.c_char_p, [_i]),
     "pwc_cost_volume_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "pwc_cost_volume_uses_rolling_kernel": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "pwc_warp_bilinear_f32": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _vp]),
     "pwc_warp_nearest_f32": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _vp]),
     "pwc_cost_volume_coarse_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),

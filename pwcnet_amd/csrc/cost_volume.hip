@@ -25,6 +25,7 @@
 //     so that HBM stores are contiguous 324-byte pixel records, not 4-byte scatters.
 //   Tiles are visited in XCD-aware order (neighbouring tiles share halo rows in one L2).
 #include "pwc_common.h"
+#include "cost_volume_roll.hip"   // rolling-window kernel for C = 32 (static: compiled into this unit)
 
 struct CvArgs {
     const float* f0;
@@ -750,11 +751,19 @@ static int cv_check(const float* f0, int f0_cs, const float* f1, int f1_cs, floa
     return PWC_OK;
 }
 
+extern "C" int pwc_cost_volume_uses_rolling_kernel(int H, int W, int C, int search_range, int f0_cs, int f1_cs, int out_cs) {
+    // pointers are taken as 16-byte aligned (what pwc_cost_volume_f32 checks at run time)
+    const float* al = reinterpret_cast<const float*>(16);
+    return cv_roll_eligible(al, f0_cs, al, f1_cs, al, out_cs, nullptr, 0, H, W, C, search_range) ? 1 : 0;
+}
+
 extern "C" int pwc_cost_volume_f32(const float* f0, int f0_cs, const float* f1w, int f1w_cs, float* out,
                                    int out_cs, int N, int H, int W, int C, int search_range, float slope,
                                    pwc_stream_t stream) {
     int rc = cv_check(f0, f0_cs, f1w, f1w_cs, out, out_cs, N, H, W, C, search_range);
     if (rc) return rc;
+    if (cv_roll_eligible(f0, f0_cs, f1w, f1w_cs, out, out_cs, nullptr, 0, H, W, C, search_range))
+        return cv_roll_launch(f0, f0_cs, f1w, f1w_cs, out, out_cs, nullptr, 0, N, H, W, slope, (hipStream_t)stream);
     CvArgs a;
     a.f0 = f0; a.f1 = f1w; a.flow = nullptr; a.out = out;
     a.f0_cs = f0_cs; a.f1_cs = f1w_cs; a.flow_cs = 0; a.out_cs = out_cs;

@@ -539,7 +539,10 @@ class CostVolumeLayer(_Module):
             _launch(L.pwc_cost_volume_f32,
                     (_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(out.ptr), out.cs, f0.N, f0.H, f0.W, f0.C,
                      self.s_range, 0.1, s),
-                    "cost_volume", f"cost_volume_dma_kernel<R{self.s_range}>", flops, 4.0 * npix * (2 * f0.C + D))
+                    "cost_volume",
+                    ("cost_volume_roll_kernel" if L.pwc_cost_volume_uses_rolling_kernel(f0.H, f0.W, f0.C, self.s_range, f0.cs, f1.cs,
+                                                                                      out.cs) and out.ptr % 16 == 0
+                     else f"cost_volume_dma_kernel<R{self.s_range}>"), flops, 4.0 * npix * (2 * f0.C + D))
         else:
             _launch(L.pwc_warp_cost_volume_f32,
                     (_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(flow.ptr), flow.cs, float(flow_scale), _p(out.ptr),

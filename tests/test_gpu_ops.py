@@ -346,6 +346,35 @@ def test_cost_volume_golden_and_strided_io(pa, golden_dir):
     assert float(out[..., 81:].min()) == 5.0
 
 
+@pytest.mark.parametrize("N,H,W", [(1, 64, 64), (2, 70, 75), (3, 100, 75), (1, 129, 33), (9, 64, 96), (1, 17, 256)])
+def test_cost_volume_rolling_kernel_vs_oracle(pa, N, H, W):
+    """C = 32, search range 4, >= 4096 pixels: pwc_cost_volume_f32 takes the rolling-window kernel
+    (cost_volume_roll.hip).  Ragged cases on purpose: W not a multiple of the 32-column strip, H not a
+    multiple of the 4-row step, segments of unequal height, more work items than workgroups is covered
+    by the full-size test; out_cs = 84 / 160 (the model's buffers) and strided inputs."""
+    from pwcnet_amd import _lib
+    from pwcnet_amd.modules import View, sub_view
+    L = _lib.lib()
+    C = 32
+    assert L.pwc_cost_volume_uses_rolling_kernel(H, W, C, 4, C, C, 84) == 1
+    assert L.pwc_cost_volume_uses_rolling_kernel(H, W, C, 4, C, C, 81) == 0      # out_cs % 4 != 0: tile kernel
+    assert L.pwc_cost_volume_uses_rolling_kernel(H, W, 64, 4, 64, 64, 84) == 0
+    f0, f1 = rnd((N, H, W, C), 60 + H), rnd((N, H, W, C), 61 + W)
+    exp = orc.cost_volume(f0, f1, 4)
+    big0 = torch.zeros(N, H, W, C + 8, device="cuda"); big0[..., 4:4 + C] = gpu(f0)
+    big1 = torch.zeros(N, H, W, C + 4, device="cuda"); big1[..., :C] = gpu(f1)
+    for ocs in (84, 160):
+        out = torch.full((N, H, W, ocs), 7.0, device="cuda")
+        v0 = sub_view(View(big0.data_ptr(), C + 8, N, H, W, C + 8), 4, C)
+        v1 = View(big1.data_ptr(), C + 4, N, H, W, C)
+        pa.CostVolumeLayer(4)._run(v0, v1, View(out.data_ptr(), ocs, N, H, W, 81))
+        close(out[..., :81], exp, rel=2e-6, floor=2e-7)
+        assert float(out[..., 81:].min()) == 7.0 and float(out[..., 81:].max()) == 7.0   # nothing beyond channel 80 touched
+    # the tile kernel (dense out_cs = 81) gives the same numbers up to summation order
+    cv = pa.CostVolumeLayer(4)(gpu(f0), gpu(f1))
+    close(cv, exp, rel=2e-6, floor=2e-7)
+
+
 def test_cost_volume_known_answers_gpu(pa):
     f = rnd((1, 16, 16, 32), 15)
     v, h = 2, -3
@@ -372,6 +401,24 @@ def test_cost_volume_full_size_properties(pa):
         np.testing.assert_allclose(a[:, ys, xs, d], b[:, yd, xd, dm], atol=1e-6)
     exp = orc.cost_volume(f0[3:4], f1[3:4], 4)
     np.testing.assert_allclose(a[3:4], exp, atol=1e-6)
+
+
+def test_cost_volume_rolling_kernel_full_size(pa):
+    """BASELINE level-4 size through the rolling kernel: batch 16 (512 work items on 256 persistent
+    workgroups: the item loop), output into a 160-channel estimator buffer; the whole result against the
+    tile kernel, two images against the oracle."""
+    from pwcnet_amd.modules import View
+    N, H, W, C = 16, 112, 256, 32
+    f0, f1 = rnd((N, H, W, C), 28), rnd((N, H, W, C), 29)
+    g0, g1 = gpu(f0), gpu(f1)
+    out = torch.zeros((N, H, W, 160), device="cuda")
+    pa.CostVolumeLayer(4)._run(View(g0.data_ptr(), C, N, H, W, C), View(g1.data_ptr(), C, N, H, W, C),
+                               View(out.data_ptr(), 160, N, H, W, 81))
+    tile = pa.CostVolumeLayer(4)(g0, g1)                   # dense output: tile kernel
+    assert float((out[..., :81] - tile).abs().max()) <= 1e-6
+    assert float(out[..., 81:].abs().max()) == 0.0
+    for n in (0, 15):
+        np.testing.assert_allclose(out[n:n + 1, ..., :81].cpu().numpy(), orc.cost_volume(f0[n:n + 1], f1[n:n + 1], 4), atol=1e-6)
 
 
 # ------------------------------------------------------------------ warp
