@@ -39,6 +39,17 @@
 //          never waited for.
 //
 // Algorithmic bytes: N*H*W*(2C+81)*4; HBM-bound (8.9 flop/B).
+//
+// Measured (8 x 112 x 256 x 32, 133 MB; scripts/exp_cv2.hip, operands rotated through > 256 MB): 47 us against the
+// tile kernel's 62 us; inside the forward (operands partly in the Infinity Cache) 40.7 us against 54-60 us.  What
+// bounds it now: the workgroup moves 76.6 MB of LDS-DMA + 74 MB of stores for the 133 algorithmic MB, and the
+// steady state (reads and writes mixed, all 256 workgroups in step) runs at ~3.8 TB/s of that traffic, the
+// 12-row prologue (reads only) at 4.5 TB/s, the last copy-out with nothing behind it.  The fp32 VALU is the
+// second wall: scripts/exp_valu.hip measures 3.3-4.5 cycles per wave64 v_fma_f32 (82-95 TFLOP/s) and 5.9-8.1
+// per v_pk_fma_f32 (up to 107 TFLOP/s) -- 1.19 GFMA cannot take less than ~13 us of VALU issue, bookkeeping
+// not counted.  A matrix-pipe form (4 x 4-pixel blocks: the +-4 window is an exact 3 x 3 grid of 16-pixel
+// N-blocks, 56 % of the products useful, LDS reads 10x fewer) was built and measures the same 46-49 us
+// (scripts/exp_cost_volume_roll_mfma.hip): with the arithmetic out of the way the memory system is the bound.
 #pragma once
 #include "pwc_common.h"
 

@@ -16,7 +16,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 recs = []
 orig = M._launch
-def timed_launch(fn, args, what, kname=None, flops=0.0, nbytes=0.0):
+def timed_launch(fn, args, what, kname=None, flops=0.0, nbytes=0.0, exec_flops=None):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record(); rc = fn(*args); e.record()
     M._lib.check(rc, what)
