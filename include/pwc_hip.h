@@ -202,6 +202,51 @@ int pwc_flow_norm_sums_f32(const float* pred, int pred_cs, const float* gt, int 
                            float* workspace, size_t workspace_floats, float* out_sums,
                            pwc_stream_t stream);
 
+/* ==== f4: training path (reference train.py:66-92: tf.gradients of the forward + tf.train.AdamOptimizer) ====
+ * Gradient tensors have the layout of the activation they belong to.  `accumulate` != 0: the kernel adds
+ * into its output (an activation with several consumers collects its gradient from all of them). */
+
+/* tf.nn.leaky_relu gradient, in place: dy[p,c] *= (y[p,c] > 0 ? 1 : slope), y = the activation's OUTPUT. */
+int pwc_lrelu_grad_f32(const float* y, int y_cs, float* dy, int dy_cs, long npix, int C, float slope,
+                       pwc_stream_t stream);
+/* dst[p,0:C] = (accumulate ? dst : 0) + alpha * src[p,0:C] (channel-slice add / scaled copy). */
+int pwc_add_f32(const float* src, int src_cs, float* dst, int dst_cs, long npix, int C, float alpha,
+                int accumulate, pwc_stream_t stream);
+/* out[c] (+)= sum over pixels of dy[p,c]: bias gradient of tf.layers.Conv2D.  Deterministic. */
+size_t pwc_channel_sums_workspace_floats(long npix, int C);
+int pwc_channel_sums_f32(const float* dy, int dy_cs, long npix, int C, float* workspace,
+                         size_t workspace_floats, float* out, int accumulate, pwc_stream_t stream);
+/* Transpose of pwc_resize_bilinear_f32 (tf.image.resize_bilinear legacy, modules.py:283-284) for integer
+ * factors OH/H = OW/W in 1..4: dx (+)= mul * R^T dy.  Gather form, deterministic. */
+int pwc_resize_bilinear_grad_f32(const float* dy, int dy_cs, float* dx, int dx_cs, int N, int H, int W, int C,
+                                 int OH, int OW, float mul, int accumulate, pwc_stream_t stream);
+/* Gradient of pwc_warp_bilinear_f32 (bilinear_warp, modules.py:99-137; floor / clip carry no gradient):
+ * dx += scatter of the corner weights (fp32 atomics; dx may be null), dflow (+)= flow_scale * d/d(flow*scale). */
+int pwc_warp_bilinear_grad_f32(const float* x, int x_cs, const float* flow, int flow_cs, float flow_scale,
+                               const float* dy, int dy_cs, float* dx, int dx_cs, float* dflow, int dflow_cs,
+                               int dflow_accumulate, int N, int H, int W, int C, pwc_stream_t stream);
+/* Gradient of pwc_cost_volume_f32 (modules.py:158-204) w.r.t. both feature maps, leaky-relu and mean
+ * included: cv = the forward output, dcv = its gradient.  df0 / df1w may be null.  search_range 4. */
+int pwc_cost_volume_grad_f32(const float* f0, int f0_cs, const float* f1w, int f1w_cs, const float* cv, int cv_cs,
+                             const float* dcv, int dcv_cs, float* df0, int df0_cs, float* df1w, int df1w_cs,
+                             int accumulate, int N, int H, int W, int C, int search_range, float slope,
+                             pwc_stream_t stream);
+/* Gradient w.r.t. pred of  scale * sum_p || pred[p] - gt[nearest(p)] / gt_div ||_ord  (losses.py:4-8,20-29). */
+int pwc_flow_norm_grad_f32(const float* pred, int pred_cs, const float* gt, int gt_cs, int N, int H, int W,
+                           int GH, int GW, float gt_div, int ord, float scale, float* dpred, int dpred_cs,
+                           int accumulate, pwc_stream_t stream);
+/* tf.train.AdamOptimizer update of a flat parameter buffer (TF 1.8 adam.py; train.py:90) with the gradient
+ * of gamma * l2_loss(var) folded in (train.py:75): g = grad_scale * grads + l2_gamma * p; lr_t from the host. */
+int pwc_adam_step_f32(float* params, const float* grads, float* m, float* v, long n, float lr_t, float beta1,
+                      float beta2, float eps, float l2_gamma, float grad_scale, pwc_stream_t stream);
+/* Weight gradient of tf.layers.Conv2D(...,(3,3),(s,s),'same',dilation_rate=d) on the fp32 MFMA units:
+ * dw_hwio[ty][tx][ci][co] (+)= sum_pixels x_pad[...] * dy, ci in the variable's LOGICAL order (cin_map maps the
+ * physical channels of x, -1 = padding; null = identity).  Deterministic (fixed-order split-k sums). */
+size_t pwc_conv3x3_wgrad_workspace_floats(int N, int H, int W, int Cin_phys, int Cout, int stride);
+int pwc_conv3x3_wgrad_f32(const float* x, int x_cs, const float* dy, int dy_cs, const int32_t* cin_map, int Cin,
+                          int Cin_phys, int Cout, float* dw_hwio, int accumulate, int N, int H, int W, int stride,
+                          int dilation, float* workspace, size_t workspace_floats, pwc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,8 @@ import torch  # noqa: F401  (loads libamdhip64 before libpwc_hip.so)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libpwc_hip.so")
-SOURCES = ["conv3x3_mfma.hip", "conv3x3_wino.hip", "conv3x3_direct.hip", "cost_volume.hip", "pwc_ops.hip"]
+SOURCES = ["conv3x3_mfma.hip", "conv3x3_wino.hip", "conv3x3_direct.hip", "cost_volume.hip", "pwc_ops.hip",
+           "pwc_backward.hip", "conv3x3_wgrad.hip"]
 HEADERS = ["pwc_common.h", "cost_volume_roll.hip", os.path.join("..", "..", "include", "pwc_hip.h")]
 
 _vp, _i, _f, _l, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long, ctypes.c_size_t
@@ -45,6 +46,17 @@ SIGNATURES = {
     "pwc_conv3x3_direct_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_resize_bilinear_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_copy_channels_f32": (_i, [_vp, _i, _vp, _i, _l, _i, _vp]),
+    "pwc_lrelu_grad_f32": (_i, [_vp, _i, _vp, _i, _l, _i, _f, _vp]),
+    "pwc_add_f32": (_i, [_vp, _i, _vp, _i, _l, _i, _f, _i, _vp]),
+    "pwc_channel_sums_workspace_floats": (_sz, [_l, _i]),
+    "pwc_channel_sums_f32": (_i, [_vp, _i, _l, _i, _vp, _sz, _vp, _i, _vp]),
+    "pwc_resize_bilinear_grad_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "pwc_warp_bilinear_grad_f32": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "pwc_cost_volume_grad_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "pwc_flow_norm_grad_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _vp, _i, _i, _vp]),
+    "pwc_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _vp]),
+    "pwc_conv3x3_wgrad_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "pwc_conv3x3_wgrad_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "pwc_flow_norm_workspace_floats": (_sz, [_i, _i, _i]),
     "pwc_flow_norm_sums_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp]),
 }

@@ -30,6 +30,15 @@ def gather_stats(stats, dist=None, device="cpu"):
     return [dict(zip(keys, t.cpu().tolist())) for t in out]
 
 
+def allreduce_sum_(flat, dist=None):
+    """In-place sum of a flat (gradient) buffer over the ranks -- one collective per training step (RCCL over xGMI
+    under `nccl`; gloo in the CPU tests).  Returns the world size (1: nothing done) so that the caller can average."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return 1
+    dist.all_reduce(flat)
+    return dist.get_world_size()
+
+
 def epe(flows_gt, flows):
     """End-point error, reference losses.py:11-13: mean over (batch, y, x) of the L2 norm of
     the flow difference; both flows unscaled (pixels)."""

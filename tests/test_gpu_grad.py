@@ -1,0 +1,264 @@
+"""GPU tests of the training path: every backward kernel and the assembled train step
+against torch.autograd on the float64 CPU restatement of the forward (oracle/torch_ref.py).
+
+Tolerances are relative to the largest reference gradient (fp32 kernels vs a float64 reference)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as tr
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def go():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU (torch.cuda.is_available() is False)")
+    from pwcnet_amd import grad_ops
+    return grad_ops
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    return np.random.RandomState(seed).uniform(lo, hi, size=shape).astype(np.float32)
+
+
+def gpu(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def t64(a, grad=True):
+    return torch.tensor(np.asarray(a, np.float64), dtype=torch.float64, requires_grad=grad)
+
+
+def close(got, exp, rel=2e-5):
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else got
+    exp = exp.detach().cpu().double().numpy() if isinstance(exp, torch.Tensor) else exp
+    assert got.shape == exp.shape, (got.shape, exp.shape)
+    tol = rel * max(float(np.abs(exp).max()), 1e-6)
+    err = float(np.abs(got - exp).max())
+    assert err <= tol, f"max abs err {err:.3e} > tol {tol:.3e} (max |ref| {float(np.abs(exp).max()):.3e})"
+
+
+def V(t):
+    from pwcnet_amd.modules import as_view
+    return as_view(t)[0]
+
+
+def test_lrelu_grad_and_channel_sums(go):
+    y, dy = rnd((2, 5, 7, 16), 1), rnd((2, 5, 7, 16), 2)
+    gy, gdy = gpu(y), gpu(dy)
+    go.lrelu_grad_(V(gy), V(gdy))
+    close(gdy, dy * np.where(y > 0, 1.0, 0.1))
+    out = torch.zeros(16, device="cuda")
+    go.channel_sums(V(gdy), out, gdy.device)
+    close(out, gdy.cpu().numpy().reshape(-1, 16).sum(0), rel=1e-5)
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_resize_grad(go, k):
+    x = rnd((2, 5, 6, 8), 3)
+    dy = rnd((2, 5 * k, 6 * k, 8), 4)
+    xt = t64(x)
+    (tr.resize_legacy(xt, (5 * k, 6 * k)) * t64(dy, False)).sum().backward()
+    dx = torch.zeros((2, 5, 6, 8), device="cuda")
+    gdy = gpu(dy)                       # (Views do not own memory: keep every tensor alive in a variable)
+    go.resize_grad(V(gdy), V(dx))
+    close(dx, xt.grad)
+    go.resize_grad(V(gdy), V(dx), mul=0.5, accumulate=True)
+    close(dx, 1.5 * xt.grad)
+
+
+def test_warp_grad(go):
+    N, H, W, C = 2, 12, 20, 8
+    x, dy = rnd((N, H, W, C), 5), rnd((N, H, W, C), 6)
+    flow = util.flow_field(N, H, W, seed=7, sigma=2.0) + 0.137     # keep away from exact integers
+    scale = 1.25
+    xt, ft = t64(x), t64(flow)
+    (tr.bilinear_warp(xt, ft * scale) * t64(dy, False)).sum().backward()
+    dx = torch.zeros((N, H, W, C), device="cuda")
+    dfl = torch.zeros((N, H, W, 2), device="cuda")
+    gx, gfl, gdy = gpu(x), gpu(flow), gpu(dy)
+    go.warp_grad(V(gx), V(gfl), scale, V(gdy), V(dx), V(dfl))
+    close(dx, xt.grad, rel=1e-5)
+    close(dfl, ft.grad, rel=1e-4)
+
+
+@pytest.mark.parametrize("N,H,W,C", [(1, 9, 11, 8), (2, 16, 24, 32), (1, 8, 8, 20)])
+def test_cost_volume_grad(go, N, H, W, C):
+    f0, f1, dcv = rnd((N, H, W, C), 8), rnd((N, H, W, C), 9), rnd((N, H, W, 81), 10)
+    a, b = t64(f0), t64(f1)
+    cv = tr.cost_volume(a, b)
+    (cv * t64(dcv, False)).sum().backward()
+    df0 = torch.zeros((N, H, W, C), device="cuda")
+    df1 = torch.zeros((N, H, W, C), device="cuda")
+    g0, g1, gcv, gdcv = gpu(f0), gpu(f1), gpu(cv.detach().numpy()), gpu(dcv)
+    go.cost_volume_grad(V(g0), V(g1), V(gcv), V(gdcv), V(df0), V(df1))
+    close(df0, a.grad)
+    close(df1, b.grad)
+
+
+def test_flow_norm_grad(go):
+    N, H, W = 2, 16, 24
+    pred, gt = rnd((N, 4, 6, 2), 11), rnd((N, H, W, 2), 12) * 20
+    pt = t64(pred)
+    loss = 0.32 * tr.L2loss(tr.resize_nearest(t64(gt, False) / 20.0, (4, 6)), pt)
+    loss.backward()
+    dp = torch.zeros((N, 4, 6, 2), device="cuda")
+    gpred, ggt = gpu(pred), gpu(gt)
+    go.flow_norm_grad(V(gpred), V(ggt), V(dp), gt_div=20.0, ord=2, scale=0.32 / N)
+    close(dp, pt.grad)
+
+
+@pytest.mark.parametrize("stride,dil,H,W,cin,cout", [
+    (1, 1, 12, 16, 16, 32), (1, 1, 9, 11, 48, 16), (2, 1, 12, 16, 3, 16), (2, 1, 8, 8, 32, 64),
+    (1, 4, 16, 16, 64, 64), (1, 1, 6, 10, 160, 128), (1, 1, 7, 9, 32, 2), (1, 16, 20, 36, 96, 64)])
+def test_conv_wgrad_and_dgrad(go, stride, dil, H, W, cin, cout):
+    N = 2
+    x, k, b = rnd((N, H, W, cin), 13), rnd((3, 3, cin, cout), 14) * 0.2, rnd((cout,), 15)
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    dy = rnd((N, Ho, Wo, cout), 16)
+    xt, kt, bt = t64(x), t64(k), t64(b)
+    (tr.conv3x3_same(xt, kt, bt, stride, dil) * t64(dy, False)).sum().backward()
+    gx, gdy = gpu(x), gpu(dy)
+    dw = torch.zeros((3, 3, cin, cout), device="cuda")
+    go.conv3x3_wgrad(V(gx), V(gdy), dw, cin, stride, dil)
+    close(dw, kt.grad, rel=3e-5)
+    db = torch.zeros((cout,), device="cuda")
+    go.channel_sums(V(gdy), db, gdy.device)
+    close(db, bt.grad, rel=1e-5)
+    if cin % 4 == 0:
+        dx = torch.zeros((N, H, W, cin), device="cuda")
+        gk = gpu(k)
+        keep = []
+        go.conv3x3_dgrad(V(gdy), gk, V(dx), stride, dil, keep=keep, dy_tensor=gdy)
+        torch.cuda.synchronize()
+        close(dx, xt.grad, rel=3e-5)
+
+
+def test_conv_wgrad_with_channel_map(go):
+    """input in a padded physical layout (ChannelLayout): gradient comes back in the variable's logical order."""
+    N, H, W = 1, 10, 12
+    phys2log = np.array([0, 1, 2, -1, 3, 4, 5, 6, 7, 8, -1, -1, 9, 10, -1, -1], np.int32)    # 11 logical in 16 physical
+    xl = rnd((N, H, W, 11), 17)
+    xp = np.zeros((N, H, W, 16), np.float32)
+    xp[..., phys2log >= 0] = xl[..., phys2log[phys2log >= 0]]
+    k, dy = rnd((3, 3, 11, 32), 18), rnd((N, H, W, 32), 19)
+    xt, kt = t64(xl), t64(k)
+    (tr.conv3x3_same(xt, kt, torch.zeros(32, dtype=torch.float64)) * t64(dy, False)).sum().backward()
+    dw = torch.zeros((3, 3, 11, 32), device="cuda")
+    gxp, gdy, gmap = gpu(xp), gpu(dy), torch.from_numpy(phys2log).cuda()
+    go.conv3x3_wgrad(V(gxp), V(gdy), dw, 11, 1, 1, cin_map=gmap)
+    close(dw, kt.grad, rel=3e-5)
+
+
+def test_adam_step(go):
+    n = 1000
+    p, g = rnd((n,), 20), rnd((n,), 21)
+    m, v = np.abs(rnd((n,), 22)) * 0.1, np.abs(rnd((n,), 23)) * 0.01
+    gp, gg, gm, gv = gpu(p), gpu(g), gpu(m), gpu(v)
+    import math
+    step, lr, gamma = 7, 1e-4, 4e-4
+    lr_t = lr * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+    go.adam_step_(gp, gg, gm, gv, lr_t, l2_gamma=gamma)
+    pt, mt, vt = tr.adam_step(t64(p, False), t64(g, False) + gamma * t64(p, False), t64(m, False), t64(v, False), step, lr)
+    close(gp, pt, rel=1e-6)
+    close(gm, mt, rel=1e-6)
+    close(gv, vt, rel=3e-6)
+
+
+# ------------------------------------------------------------------ assembled training step
+def _ref_grads(w, im0, im1, gt, weights):
+    wt = {k: t64(v) for k, v in w.items()}
+    _, pyr = tr.TorchPWCDCNet(wt)(t64(im0, False), t64(im1, False))
+    loss = tr.multiscale_loss(t64(gt, False), pyr, weights)
+    loss.backward()
+    return float(loss.detach()), {k: v.grad for k, v in wt.items()}, [p.detach() for p in pyr]
+
+
+def test_train_step_gradients_vs_autograd():
+    """Whole backward (loss gradient, context, 5 estimators, cost volumes, warps, resizes, shared-weight
+    extractor) against torch.autograd on the float64 restatement: every variable's gradient."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    from pwcnet_amd.train import Trainer
+    N, H, W = 2, 64, 128
+    w = util.model_weights(False, gain=1.25)
+    im0, im1 = util.smooth_images(N, H, W, seed=61, shift=(3, -2))
+    gt = (util.flow_field(N, H, W, seed=62, sigma=2.0, outliers=False)).astype(np.float32)
+    weights = (0.32, 0.08, 0.02, 0.01, 0.005)
+    ref_loss, ref_g, ref_pyr = _ref_grads(w, im0, im1, gt, weights)
+    tn = Trainer(weights=weights, gamma=0.0, lr=1e-4)
+    tn.load_weights(w)
+    pyr = tn.forward(gpu(im0), gpu(im1))
+    for a, b in zip(pyr, ref_pyr):
+        close(a, b, rel=2e-4)
+    ggt = gpu(gt)
+    loss = float(tn.loss_value(ggt))
+    assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss)
+    tn.backward(ggt)
+    torch.cuda.synchronize()
+    got = tn.gradients()
+    worst = 0.0
+    for k in sorted(ref_g):
+        r = ref_g[k].numpy()
+        err = float(np.abs(got[k] - r).max()) / max(float(np.abs(r).max()), 1e-12)
+        worst = max(worst, err)
+        assert err <= 2e-3, f"{k}: relative gradient error {err:.3e}"
+    print(f"worst relative gradient error over {len(ref_g)} variables: {worst:.3e}")
+
+
+def test_train_step_reduces_the_loss_and_matches_adam():
+    """A few optimisation steps on one batch: the loss goes down; the first update equals tf.train.AdamOptimizer's
+    formula applied to the reference gradients plus gamma * var."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    from pwcnet_amd.train import Trainer
+    N, H, W = 2, 64, 64
+    w = util.model_weights(False, gain=1.1)
+    im0, im1 = util.smooth_images(N, H, W, seed=63, shift=(2, 1))
+    gt = np.zeros((N, H, W, 2), np.float32)
+    gt[..., 0], gt[..., 1] = 2.0, 1.0                       # the true motion of smooth_images(shift=(2, 1))
+    weights = (0.32, 0.08, 0.02, 0.01, 0.005)
+    gamma, lr = 4e-4, 1e-3
+    _, ref_g, _ = _ref_grads(w, im0, im1, gt, weights)
+    tn = Trainer(weights=weights, gamma=gamma, lr=lr)
+    tn.load_weights(w)
+    g0, g1, ggt = gpu(im0), gpu(im1), gpu(gt)
+    losses = [float(tn.step(g0, g1, ggt))]
+    after = tn.state_dict()
+    for k in ("pwcdcnet/context/conv2d_6/kernel", "pwcdcnet/optflow_2/conv2d/kernel", "pwcdcnet/fp_extractor/conv2d_4/bias"):
+        g = ref_g[k] + gamma * t64(w[k], False)
+        exp, _, _ = tr.adam_step(t64(w[k], False), g, torch.zeros_like(g), torch.zeros_like(g), 1, lr)
+        close(after[k], exp, rel=1e-4)
+    for _ in range(7):
+        losses.append(float(tn.step(g0, g1, ggt)))
+    print("losses:", [round(x, 4) for x in losses])
+    assert tn.global_step == 8 and losses[-1] < 0.9 * losses[0]
+
+
+def test_trainer_forward_equals_inference_forward_and_rejects_dc():
+    """The training forward (activations kept, weights from the flat buffer) and PWCDCNet.__call__ are the same
+    function; dense connections are not implemented for training and say so."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    import pwcnet_amd
+    from pwcnet_amd.train import Trainer, piecewise_lr
+    w = util.model_weights(False)
+    im0, im1 = util.smooth_images(2, 64, 128, seed=64)
+    tn = Trainer()
+    tn.load_weights(w)
+    pyr = tn.forward(gpu(im0), gpu(im1))
+    net = pwcnet_amd.PWCDCNet()
+    net.load_weights(w)
+    _, ref = net(gpu(im0), gpu(im1))
+    for a, b in zip(pyr, ref):
+        assert float((a - b).abs().max()) <= 2e-6
+    with pytest.raises(NotImplementedError):
+        Trainer(use_dc=True)
+    with pytest.raises(ValueError, match="missing"):
+        tn.load_weights({})
+    # reference train.py:82-88
+    assert piecewise_lr(1e-4, 0) == 1e-4 and piecewise_lr(1e-4, 200000) == 1e-4 and piecewise_lr(1e-4, 200001) == 5e-5
+    assert piecewise_lr(1e-4, 360000) == 1e-4 / 16 and piecewise_lr(1e-4, 360000, scheduling=False) == 1e-4

@@ -290,6 +290,35 @@ def test_sharded_evaluation_with_an_empty_rank_gloo(tmp_path):
     assert "EMPTY_RANK_OK 2" in out.stdout
 
 
+_ALLREDUCE_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from pwcnet_amd import sharding
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+flat = torch.arange(10, dtype=torch.float32) * (r + 1)       # rank 0: k, rank 1: 2k
+world = sharding.allreduce_sum_(flat, dist)
+assert world == 2 and torch.equal(flat, torch.arange(10, dtype=torch.float32) * 3)
+assert sharding.allreduce_sum_(flat.clone(), None) == 1
+if r == 0:
+    print("ALLREDUCE_OK", w)
+dist.destroy_process_group()
+"""
+
+
+def test_gradient_allreduce_world2_gloo(tmp_path):
+    """the training step's one collective -- the flat gradient buffer summed over the ranks."""
+    script = tmp_path / "allreduce_worker.py"
+    script.write_text(_ALLREDUCE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29620", str(script), ROOT],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "ALLREDUCE_OK 2" in out.stdout
+
+
 # ------------------------------------------------------------------ flow IO (f2)
 def test_flo_round_trip_and_layout(tmp_path):
     from pwcnet_amd import flow_io

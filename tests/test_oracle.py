@@ -209,6 +209,21 @@ def test_assembly_oracle_vs_literal_restatement(use_dc):
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-5 * max(1.0, float(np.abs(b).max())))
 
 
+@pytest.mark.parametrize("use_dc", [False, True])
+def test_torch_reference_forward_matches_the_oracle(use_dc):
+    """oracle/torch_ref.py (float64, differentiable: the reference for the training path's gradients) against
+    the C oracle: a third restatement of the same forward."""
+    from oracle import torch_ref as tr
+    w = util.model_weights(use_dc, gain=1.2)
+    im0, im1 = util.smooth_images(1, 64, 128, seed=31, shift=(3, -2))
+    o_final, o_pyr = orc.OraclePWCDCNet(w, use_dc=use_dc)(im0, im1)
+    wt = {k: torch.tensor(v, dtype=torch.float64) for k, v in w.items()}
+    t_final, t_pyr = tr.TorchPWCDCNet(wt, use_dc=use_dc)(torch.tensor(im0, dtype=torch.float64), torch.tensor(im1, dtype=torch.float64))
+    np.testing.assert_allclose(o_final, t_final.numpy(), rtol=0, atol=2e-4)
+    for a, b in zip(o_pyr, t_pyr):
+        np.testing.assert_allclose(a, b.numpy(), rtol=0, atol=1e-5)
+
+
 def test_literal_assembly_detects_a_wrong_concat_order():
     """Sanity of the test above: a deliberately mis-ordered estimator input (features_0 before
     cv) moves the literal result far outside the comparison tolerance."""
