@@ -262,3 +262,26 @@ def test_trainer_forward_equals_inference_forward_and_rejects_dc():
     # reference train.py:82-88
     assert piecewise_lr(1e-4, 0) == 1e-4 and piecewise_lr(1e-4, 200000) == 1e-4 and piecewise_lr(1e-4, 200001) == 5e-5
     assert piecewise_lr(1e-4, 360000) == 1e-4 / 16 and piecewise_lr(1e-4, 360000, scheduling=False) == 1e-4
+
+
+def test_train_cli_synthetic_epoch_writes_a_restorable_bundle(tmp_path):
+    """train.py (counterpart of the reference's train.py): two short epochs on synthetic translating textures;
+    every epoch prints loss / validation EPE and writes a TF-format bundle that PWCDCNet can restore."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    import os, subprocess, sys
+    import pwcnet_amd
+    from pwcnet_amd import ckpt
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "train.py"), "-d", "synthetic", "--synthetic_pairs", "20",
+                          "-e", "2", "-b", "4", "--crop_shape", "64", "128", "--lr", "3e-4", "--model_dir", str(tmp_path / "model")],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("epoch ")]
+    assert len(lines) == 2 and "EPE/val" in lines[0] and "global_step 8" in lines[1], out.stdout[-1500:]
+    w = ckpt.load_weights(str(tmp_path / "model" / "model_2.ckpt"))
+    net = pwcnet_amd.PWCDCNet()
+    net.load_weights(w)
+    im0, im1 = util.smooth_images(1, 64, 128, seed=65)
+    final, _ = net(gpu(im0), gpu(im1))
+    assert torch.isfinite(final).all()
