@@ -30,6 +30,7 @@
 //   Other tile shapes of the same kernel (WinoGeom): two short sub-lattice images per
 //   workgroup, 4 x 64-pixel blocks; 16 instead of 32 output channels (NT = 1).
 #include "pwc_common.h"
+#include <cstdlib>
 
 #ifndef WINO_BN32_MIN_WG
 #define WINO_BN32_MIN_WG 384
@@ -494,20 +495,31 @@ extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packe
     a.ntiles = (int)nblk;
     // measured (scripts/exp_wino.hip): one LDS stage fetched in three pipelined parts with 2 co-resident
     // workgroups per CU beats a double-buffered whole stage (1 workgroup per CU)
-#define WINO_LAUNCH(NT, GEO)                                                                                \
+#define WINO_LAUNCH_P(NT, GEO, PERS)                                                                        \
     do {                                                                                                    \
         const size_t lds = (size_t)WinoGeom<NT, GEO>::STAGE * sizeof(float);                                \
         static bool attr_done = false;                                                                      \
         if (!attr_done) {                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<0, NT, 1, GEO>),   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<0, NT, 1, GEO, PERS>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
             attr_done = true;                                                                               \
         }                                                                                                   \
-        hipLaunchKernelGGL((conv3x3_wino_kernel<0, NT, 1, GEO>), dim3((unsigned)nblk), dim3(256), lds,      \
+        const long grid = (PERS && nblk > 512) ? 512 : nblk;   /* persistent: 2 workgroups per CU walk the tiles */ \
+        hipLaunchKernelGGL((conv3x3_wino_kernel<0, NT, 1, GEO, PERS>), dim3((unsigned)grid), dim3(256), lds, \
                            (hipStream_t)stream, a);                                                         \
     } while (0)
+#define WINO_LAUNCH(NT, GEO) WINO_LAUNCH_P(NT, GEO, 0)
+    // One- and two-stage launches of the 16-cout variant (the 16 -> 16 and 32 -> 16 layers: Cin_phys <= 32) spend
+    // most of a workgroup's life waiting for its only patch: there the persistent form -- the next tile's first
+    // stage is requested before the current tile's output transform and stores -- pays (64 accumulator registers,
+    // no spill; with 32 couts it spills and loses, see the kernel comment).
+    const char* pe = getenv("PWC_WINO_PERSIST");
+    const bool persist = (pe ? atoi(pe) != 0 : true) && bn == 16 && Cin_phys <= 32 && nblk > 1024;
+    if (persist && geo == 0) { WINO_LAUNCH_P(1, 0, 1); return pwc_launch_status(); }
+    if (persist && geo == 2) { WINO_LAUNCH_P(1, 2, 1); return pwc_launch_status(); }
     if (bn == 32) { if (geo == 1) WINO_LAUNCH(2, 1); else if (geo == 2) WINO_LAUNCH(2, 2); else WINO_LAUNCH(2, 0); }
     else          { if (geo == 1) WINO_LAUNCH(1, 1); else if (geo == 2) WINO_LAUNCH(1, 2); else WINO_LAUNCH(1, 0); }
 #undef WINO_LAUNCH
+#undef WINO_LAUNCH_P
     return pwc_launch_status();
 }

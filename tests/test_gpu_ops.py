@@ -421,6 +421,25 @@ def test_cost_volume_rolling_kernel_full_size(pa):
         np.testing.assert_allclose(out[n:n + 1, ..., :81].cpu().numpy(), orc.cost_volume(f0[n:n + 1], f1[n:n + 1], 4), atol=1e-6)
 
 
+def test_cost_volume_rolling_kernel_stress_no_stale_lds(pa):
+    """The rolling kernel never drains its DMA or its stores: a step's prefetch is waited for with
+    `s_waitcnt vmcnt(#stores issued after it)`, which relies on a wave's memory operations retiring in issue order.
+    If that ever failed, a step would read ring rows of an EARLIER launch or step.  40 launches on alternating,
+    unrelated operand sets (so that stale rows would be plainly wrong), every result against the tile kernel."""
+    from pwcnet_amd.modules import View
+    N, H, W, C = 8, 112, 256, 32
+    sets = [(gpu(rnd((N, H, W, C), 70 + i)), gpu(rnd((N, H, W, C), 80 + i) * (i + 1))) for i in range(3)]
+    refs = [pa.CostVolumeLayer(4)(a, b) for a, b in sets]            # dense output: tile kernel
+    out = torch.zeros((N, H, W, 160), device="cuda")
+    worst = 0.0
+    for it in range(40):
+        a, b = sets[it % 3]
+        pa.CostVolumeLayer(4)._run(View(a.data_ptr(), C, N, H, W, C), View(b.data_ptr(), C, N, H, W, C),
+                                   View(out.data_ptr(), 160, N, H, W, 81))
+        worst = max(worst, float((out[..., :81] - refs[it % 3]).abs().max()) / float(refs[it % 3].abs().max()))
+    assert worst <= 2e-6, worst
+
+
 # ------------------------------------------------------------------ warp
 @pytest.mark.parametrize("wt", ["bilinear", "nearest"])
 @pytest.mark.parametrize("N,H,W,C", [(2, 14, 32, 128), (1, 56, 128, 64), (2, 9, 11, 4), (1, 28, 64, 96)])
