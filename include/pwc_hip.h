@@ -216,6 +216,10 @@ int pwc_add_f32(const float* src, int src_cs, float* dst, int dst_cs, long npix,
 size_t pwc_channel_sums_workspace_floats(long npix, int C);
 int pwc_channel_sums_f32(const float* dy, int dy_cs, long npix, int C, float* workspace,
                          size_t workspace_floats, float* out, int accumulate, pwc_stream_t stream);
+/* The two above in ONE pass over dy: dy *= (y > 0 ? 1 : slope) in place, out[c] (+)= sum_p dy[p,c]. */
+int pwc_lrelu_grad_channel_sums_f32(const float* y, int y_cs, float* dy, int dy_cs, long npix, int C, float slope,
+                                    float* workspace, size_t workspace_floats, float* out, int accumulate,
+                                    pwc_stream_t stream);
 /* Transpose of pwc_resize_bilinear_f32 (tf.image.resize_bilinear legacy, modules.py:283-284) for integer
  * factors OH/H = OW/W in 1..4: dx (+)= mul * R^T dy.  Gather form, deterministic. */
 int pwc_resize_bilinear_grad_f32(const float* dy, int dy_cs, float* dx, int dx_cs, int N, int H, int W, int C,

@@ -50,6 +50,7 @@ SIGNATURES = {
     "pwc_add_f32": (_i, [_vp, _i, _vp, _i, _l, _i, _f, _i, _vp]),
     "pwc_channel_sums_workspace_floats": (_sz, [_l, _i]),
     "pwc_channel_sums_f32": (_i, [_vp, _i, _l, _i, _vp, _sz, _vp, _i, _vp]),
+    "pwc_lrelu_grad_channel_sums_f32": (_i, [_vp, _i, _vp, _i, _l, _i, _f, _vp, _sz, _vp, _i, _vp]),
     "pwc_resize_bilinear_grad_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "pwc_warp_bilinear_grad_f32": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "pwc_cost_volume_grad_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),

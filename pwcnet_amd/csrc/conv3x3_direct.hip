@@ -198,6 +198,62 @@ __global__ __launch_bounds__(256) void conv3x3_head2_c32_kernel(const DirectArgs
     }
 }
 
+// Flow heads on large maps (32 -> 2, stride 1, dilation 1; modules.py:274,324 at pyramid level 4): the kernel above
+// re-reads every input pixel 9 times through L1 (32 us for the 31 MB of the 112 x 256 level = 1 TB/s).  Here a
+// workgroup stages the (8+2) x (32+2)-pixel patch of its 8 x 32-pixel tile in LDS ONCE, quad-major ([channel quad]
+// [pixel]: consecutive lanes = consecutive pixels read consecutive 16-byte slots, plane stride odd in slots so that the
+// 8 quads of a pixel land in different slots when written); thread = output pixel, 72 ds_read_b128 + 576 FMAs, the
+// weights of a (tap, quad) are wave-uniform (scalar loads).
+constexpr int HT_R = 8, HT_C = 32, HT_PW = HT_C + 2, HT_NP = (HT_R + 2) * HT_PW, HT_PLANE = HT_NP * 4 + 4;
+
+__global__ __launch_bounds__(256) void conv3x3_head2_tile_kernel(const DirectArgs a, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float patch[8 * HT_PLANE];
+    const int t = threadIdx.x;
+    int blk = blockIdx.x;
+    const int bx = blk % tiles_x; blk /= tiles_x;
+    const int by = blk % tiles_y;
+    const int n = blk / tiles_y;
+    const int y0 = by * HT_R, x0 = bx * HT_C;
+    const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs;
+    for (int e = t; e < HT_NP * 8; e += 256) {
+        const int p = e >> 3, q = e & 7;
+        const int py = p / HT_PW, px = p - py * HT_PW;
+        const int y = y0 - 1 + py, x = x0 - 1 + px;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+            v = *reinterpret_cast<const f32x4*>(xn + ((size_t)y * a.W + x) * a.x_cs + q * 4);
+        *reinterpret_cast<f32x4*>(patch + q * HT_PLANE + p * 4) = v;
+    }
+    __syncthreads();
+    const int r = t >> 5, c = t & 31;
+    float s0a = 0.f, s0b = 0.f, s1a = 0.f, s1b = 0.f;
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+            const float* pp = patch + ((r + ty) * HT_PW + c + tx) * 4;
+            const float* wt = a.w + (ty * 3 + tx) * 64;                  // [32 ci][2 co] of this tap: wave-uniform
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(pp + q * HT_PLANE);
+                const float* w = wt + q * 8;
+                s0a = fmaf(v[0], w[0], s0a); s1a = fmaf(v[0], w[1], s1a);
+                s0b = fmaf(v[1], w[2], s0b); s1b = fmaf(v[1], w[3], s1b);
+                s0a = fmaf(v[2], w[4], s0a); s1a = fmaf(v[2], w[5], s1a);
+                s0b = fmaf(v[3], w[6], s0b); s1b = fmaf(v[3], w[7], s1b);
+            }
+        }
+    const int oy = y0 + r, ox = x0 + c;
+    if (oy < a.H && ox < a.W) {
+        const size_t m = ((size_t)n * a.H + oy) * a.W + ox;
+        float v0 = (s0a + s0b) + a.bias[0], v1 = (s1a + s1b) + a.bias[1];
+        if (a.apply_act) { v0 = pwc_lrelu(v0, a.slope); v1 = pwc_lrelu(v1, a.slope); }
+        if (a.res) { v0 += a.res[m * a.res_cs]; v1 += a.res[m * a.res_cs + 1]; }
+        a.y[m * a.y_cs] = v0;
+        a.y[m * a.y_cs + 1] = v1;
+    }
+}
+
 extern "C" int pwc_conv3x3_direct_f32(const float* x, int x_cs, const float* w_hwio, const float* bias,
                                       float* y, int y_cs, const float* residual, int res_cs, int N, int H,
                                       int W, int Cin, int Cout, int stride, int dilation, int apply_act,
@@ -223,6 +279,14 @@ extern "C" int pwc_conv3x3_direct_f32(const float* x, int x_cs, const float* w_h
         hipLaunchKernelGGL((conv3x3_smallcin_kernel<3, 16>), dim3((unsigned)blocks), dim3(256),
                            (size_t)27 * Cout * sizeof(float), s, a);
         return pwc_launch_status();
+    }
+    if (Cout == 2 && Cin == 32 && vec4 && stride == 1 && dilation == 1 && (long)H * W >= 16384) {
+        const int tiles_x = (W + HT_C - 1) / HT_C, tiles_y = (H + HT_R - 1) / HT_R;
+        const long nblk = (long)N * tiles_x * tiles_y;
+        if (nblk < (1L << 31)) {
+            hipLaunchKernelGGL(conv3x3_head2_tile_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a, tiles_x, tiles_y);
+            return pwc_launch_status();
+        }
     }
     if (Cout == 2 && Cin == 32 && vec4 && pwc_aligned16(w_hwio) && a.M < (1L << 31) && (long)H * W * x_cs < (1L << 31)) {
         long blocks = (a.M + 31) / 32;            // 32 pixels per 256-thread block iteration

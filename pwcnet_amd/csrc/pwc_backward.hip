@@ -9,6 +9,7 @@
 //
 //   pwc_lrelu_grad_f32          dy *= (y > 0 ? 1 : slope)          tf.nn.leaky_relu's gradient (y = its output)
 //   pwc_channel_sums_f32        s[c] = sum_p dy[p, c]               bias gradient of tf.layers.Conv2D
+//   pwc_lrelu_grad_channel_sums_f32   the two above in one pass over dy
 //   pwc_add_f32                 dst (+)= alpha * src                channel-slice accumulate
 //   pwc_resize_bilinear_grad    transpose of the TF-legacy resize  modules.py:283-284
 //   pwc_warp_bilinear_grad      d/dx and d/dflow of bilinear_warp  modules.py:99-137
@@ -66,46 +67,93 @@ extern "C" int pwc_add_f32(const float* src, int src_cs, float* dst, int dst_cs,
     return pwc_launch_status();
 }
 
-// s[c] = sum over pixels of dy[p, c]: fixed-shape partial sums (deterministic), then one block adds them.
+// s[c] = sum over pixels of dy[p, c]: fixed-shape partial sums (deterministic), then a second kernel adds them.
+// Block = 256 threads = (256 / CP) pixel lanes x CP channel lanes (CP = channels rounded up to a power of two <= 256:
+// consecutive threads read consecutive channels of a pixel -- coalesced); every block walks a fixed pixel range, the
+// pixel lanes are summed through LDS.  With Y != nullptr the kernel first applies the leaky-relu mask to dy IN PLACE
+// (dy *= y > 0 ? 1 : slope) -- bias gradient and activation gradient in one pass over dy.
 // partial: [nparts][C]
-__global__ __launch_bounds__(256) void channel_sums_partial_kernel(const float* __restrict__ dy, int dy_cs, long npix, int C,
+__global__ __launch_bounds__(256) void channel_sums_partial_kernel(const float* __restrict__ y, int y_cs, float slope,
+                                                                   float* __restrict__ dy, int dy_cs, long npix, int C, int CP,
                                                                    float* __restrict__ partial) {
-    // thread = channel (coalesced over c), block walks a pixel range
+    __shared__ float red[256];
+    const int c = threadIdx.x & (CP - 1), pl = threadIdx.x / CP, npl = 256 / CP;
     const long per = (npix + gridDim.x - 1) / gridDim.x;
     const long p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int cb = 0; cb < C; cb += CP) {                 // (C > 256: channel blocks of 256)
+        const int cc = cb + c;
         float s = 0.f;
-        for (long p = p0; p < p1; ++p) s += dy[p * dy_cs + c];
-        partial[(long)blockIdx.x * C + c] = s;
+        if (cc < C) {
+            for (long p = p0 + pl; p < p1; p += npl) {
+                float g = dy[p * dy_cs + cc];
+                if (y) {
+                    g = y[p * y_cs + cc] > 0.f ? g : g * slope;
+                    dy[p * dy_cs + cc] = g;
+                }
+                s += g;
+            }
+        }
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int k = npl >> 1; k > 0; k >>= 1) {         // fixed-order tree over the pixel lanes
+            if (pl < k) red[threadIdx.x] += red[threadIdx.x + k * CP];
+            __syncthreads();
+        }
+        if (pl == 0 && cc < C) partial[(long)blockIdx.x * C + cc] = red[c];
+        __syncthreads();
     }
 }
-__global__ void channel_sums_final_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ out,
-                                          int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[c] (+)= sum_i partial[i][c]: block = 64 channels x 4 part lanes
+__global__ __launch_bounds__(256) void channel_sums_final_kernel(const float* __restrict__ partial, int nparts, int C,
+                                                                 float* __restrict__ out, int accumulate) {
+    __shared__ float red[256];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int i = 0; i < nparts; ++i) s += partial[(long)i * C + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < C)
+        for (int i = pl; i < nparts; i += 4) s += partial[(long)i * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        const float t = (red[cl] + red[64 + cl]) + (red[128 + cl] + red[192 + cl]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 extern "C" size_t pwc_channel_sums_workspace_floats(long npix, int C) {
     if (npix <= 0 || C <= 0) return 0;
-    long parts = (npix + 127) / 128;
-    if (parts > 512) parts = 512;
+    long parts = (npix + 511) / 512;
+    if (parts > 1024) parts = 1024;
     return (size_t)parts * C;
+}
+
+static int channel_sums_launch(const float* y, int y_cs, float slope, float* dy, int dy_cs, long npix, int C, float* workspace,
+                               size_t workspace_floats, float* out, int accumulate, pwc_stream_t stream) {
+    const size_t need = pwc_channel_sums_workspace_floats(npix, C);
+    if (workspace_floats < need) return PWC_EINVAL;
+    const int parts = (int)(need / C);
+    int cp = 1;
+    while (cp < C && cp < 256) cp <<= 1;
+    hipLaunchKernelGGL(channel_sums_partial_kernel, dim3((unsigned)parts), dim3(256), 0, (hipStream_t)stream, y, y_cs, slope, dy,
+                       dy_cs, npix, C, cp, workspace);
+    hipLaunchKernelGGL(channel_sums_final_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, parts, C, out, accumulate);
+    return pwc_launch_status();
 }
 
 extern "C" int pwc_channel_sums_f32(const float* dy, int dy_cs, long npix, int C, float* workspace, size_t workspace_floats,
                                     float* out, int accumulate, pwc_stream_t stream) {
     if (!dy || !workspace || !out || npix <= 0 || C <= 0 || dy_cs < C) return PWC_EINVAL;
-    const size_t need = pwc_channel_sums_workspace_floats(npix, C);
-    if (workspace_floats < need) return PWC_EINVAL;
-    const int parts = (int)(need / C);
-    hipLaunchKernelGGL(channel_sums_partial_kernel, dim3((unsigned)parts), dim3(256), 0, (hipStream_t)stream, dy, dy_cs, npix, C,
-                       workspace);
-    hipLaunchKernelGGL(channel_sums_final_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
-                       (const float*)workspace, parts, C, out, accumulate);
-    return pwc_launch_status();
+    return channel_sums_launch(nullptr, 0, 0.f, const_cast<float*>(dy), dy_cs, npix, C, workspace, workspace_floats, out,
+                               accumulate, stream);
+}
+
+// leaky-relu gradient (in place on dy) + bias gradient in one pass: dy *= (y > 0 ? 1 : slope); out[c] (+)= sum_p dy[p, c]
+extern "C" int pwc_lrelu_grad_channel_sums_f32(const float* y, int y_cs, float* dy, int dy_cs, long npix, int C, float slope,
+                                               float* workspace, size_t workspace_floats, float* out, int accumulate,
+                                               pwc_stream_t stream) {
+    if (!y || !dy || !workspace || !out || npix <= 0 || C <= 0 || dy_cs < C || y_cs < C) return PWC_EINVAL;
+    return channel_sums_launch(y, y_cs, slope, dy, dy_cs, npix, C, workspace, workspace_floats, out, accumulate, stream);
 }
 
 // ------------------------------------------------------------------ resize (legacy bilinear) backward

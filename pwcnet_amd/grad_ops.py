@@ -59,6 +59,16 @@ def channel_sums(dy, out, device, accumulate=False):
                                       1 if accumulate else 0, _s()), "channel_sums")
 
 
+def lrelu_grad_channel_sums_(y, dy, out, device, slope=0.1, accumulate=False):
+    """dy *= (y > 0 ? 1 : slope) in place and out[c] (+)= sum over pixels of the masked dy: one pass over dy."""
+    L = _L()
+    npix = dy.N * dy.H * dy.W
+    ws = _ws(device, L.pwc_channel_sums_workspace_floats(npix, dy.C))
+    _lib.check(L.pwc_lrelu_grad_channel_sums_f32(_p(y.ptr), y.cs, _p(dy.ptr), dy.cs, npix, dy.C, float(slope),
+                                                 _p(ws.data_ptr()), ws.numel(), _p(out.data_ptr()), 1 if accumulate else 0,
+                                                 _s()), "lrelu_grad_channel_sums")
+
+
 def resize_grad(dy, dx, mul=1.0, accumulate=False):
     """dx (+)= mul * R^T dy for the TF-legacy bilinear resize of dx's grid to dy's (integer factor)."""
     assert dy.C == dx.C and dy.N == dx.N

@@ -228,11 +228,9 @@ class Trainer:
         dev = self.device
         dy = View(dy_t.data_ptr(), c.cout, c.y.N, c.y.H, c.y.W, c.cout)
         if c.act:
-            if c.cout % 4 == 0:
-                G.lrelu_grad_(c.y, dy)
-            else:
-                raise AssertionError("activated convs have Cout % 4 == 0")
-        G.channel_sums(dy, c.dbias, dev)
+            G.lrelu_grad_channel_sums_(c.y, dy, c.dbias, dev)      # activation mask + bias gradient in one pass over dy
+        else:
+            G.channel_sums(dy, c.dbias, dev)
         G.conv3x3_wgrad(c.x, dy, c.dkernel, c.cin, c.stride, c.dilation, cin_map=c.cin_map)
         if not need_dx:
             return None

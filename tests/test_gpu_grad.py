@@ -54,6 +54,15 @@ def test_lrelu_grad_and_channel_sums(go):
     out = torch.zeros(16, device="cuda")
     go.channel_sums(V(gdy), out, gdy.device)
     close(out, gdy.cpu().numpy().reshape(-1, 16).sum(0), rel=1e-5)
+    # fused form, awkward channel counts and pixel counts
+    for (n, h, w, c) in [(2, 33, 47, 96), (1, 7, 16, 192), (3, 20, 31, 2), (1, 64, 64, 300)]:
+        y2, d2 = rnd((n, h, w, c), 3 + c), rnd((n, h, w, c), 4 + c)
+        g2y, g2d = gpu(y2), gpu(d2)
+        o2 = torch.zeros(c, device="cuda")
+        go.lrelu_grad_channel_sums_(V(g2y), V(g2d), o2, g2d.device)
+        exp = d2 * np.where(y2 > 0, 1.0, 0.1)
+        close(g2d, exp)
+        close(o2, exp.reshape(-1, c).astype(np.float64).sum(0), rel=2e-5)
 
 
 @pytest.mark.parametrize("k", [2, 4])

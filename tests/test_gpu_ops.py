@@ -310,6 +310,17 @@ def test_conv_direct_residual_flow_head(pa):
     close(run_conv_direct(x, k, b, 1, 1, None, residual=res), orc.conv3x3(x, k, b, 1, 1, None, residual=res))
 
 
+@pytest.mark.parametrize("N,H,W,res", [(1, 128, 128, True), (2, 131, 150, False), (1, 112, 256, True)])
+def test_conv_flow_head_tiled_kernel(pa, N, H, W, res):
+    """32 -> 2 heads on maps of >= 16384 pixels take the LDS-tiled kernel (8 x 32-pixel tiles, ragged edges here)."""
+    x = rnd((N, H, W, 32), 117)
+    k = rnd((3, 3, 32, 2), 118) * 0.05
+    b = rnd((2,), 119) * 0.1
+    r = rnd((N, H, W, 2), 120) if res else None
+    close(run_conv_direct(x, k, b, 1, 1, None, residual=r), orc.conv3x3(x, k, b, 1, 1, None, residual=r))
+    close(run_conv_direct(x, k, b, 1, 1, 0.1), orc.conv3x3(x, k, b, 1, 1, 0.1))
+
+
 def test_conv_direct_equals_mfma(pa):
     x = rnd((1, 21, 30, 64), 21)
     k = rnd((3, 3, 64, 32), 22) * 0.05
