@@ -106,6 +106,19 @@ def multiscale_loss(flows_gt, flows_pyramid, weights):
     return loss
 
 
+def L1loss(x, y):
+    return torch.linalg.vector_norm(x - y, ord=1, dim=3).sum(dim=(1, 2)).mean()
+
+
+def multirobust_loss(flows_gt, flows_pyramid, weights, epsilon=0.01, q=0.4):
+    """reference losses.py:34-48 as intended (its loop body names an undefined `loss_level`; `_l` is meant)."""
+    gt = flows_gt / 20.0
+    loss = 0.0
+    for w, fs in zip(weights, flows_pyramid):
+        loss = loss + w * (L1loss(resize_nearest(gt, fs.shape[1:3]), fs) + epsilon) ** q
+    return loss
+
+
 class TorchPWCDCNet:
     """reference model.py:74-134 on the functions above; weights: {name: tensor(requires_grad)}."""
     FILTERS_FP = [16, 32, 64, 96, 128, 192]

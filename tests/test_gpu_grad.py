@@ -178,27 +178,31 @@ def test_adam_step(go):
 
 
 # ------------------------------------------------------------------ assembled training step
-def _ref_grads(w, im0, im1, gt, weights):
+def _ref_grads(w, im0, im1, gt, weights, use_dc=False, loss="multiscale"):
     wt = {k: t64(v) for k, v in w.items()}
-    _, pyr = tr.TorchPWCDCNet(wt)(t64(im0, False), t64(im1, False))
-    loss = tr.multiscale_loss(t64(gt, False), pyr, weights)
+    _, pyr = tr.TorchPWCDCNet(wt, use_dc=use_dc)(t64(im0, False), t64(im1, False))
+    if loss == "multiscale":
+        loss = tr.multiscale_loss(t64(gt, False), pyr, weights)
+    else:
+        loss = tr.multirobust_loss(t64(gt, False), pyr, weights, epsilon=0.02, q=0.4)
     loss.backward()
     return float(loss.detach()), {k: v.grad for k, v in wt.items()}, [p.detach() for p in pyr]
 
 
-def test_train_step_gradients_vs_autograd():
-    """Whole backward (loss gradient, context, 5 estimators, cost volumes, warps, resizes, shared-weight
-    extractor) against torch.autograd on the float64 restatement: every variable's gradient."""
+@pytest.mark.parametrize("use_dc,loss", [(False, "multiscale"), (True, "multiscale"), (False, "robust"), (True, "robust")])
+def test_train_step_gradients_vs_autograd(use_dc, loss):
+    """Whole backward (loss gradient, context, 5 estimators -- plain and densely connected --, cost volumes, warps,
+    resizes, shared-weight extractor) against torch.autograd on the float64 restatement: every variable's gradient."""
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a GPU")
     from pwcnet_amd.train import Trainer
     N, H, W = 2, 64, 128
-    w = util.model_weights(False, gain=1.25)
+    w = util.model_weights(use_dc, gain=1.25)
     im0, im1 = util.smooth_images(N, H, W, seed=61, shift=(3, -2))
     gt = (util.flow_field(N, H, W, seed=62, sigma=2.0, outliers=False)).astype(np.float32)
     weights = (0.32, 0.08, 0.02, 0.01, 0.005)
-    ref_loss, ref_g, ref_pyr = _ref_grads(w, im0, im1, gt, weights)
-    tn = Trainer(weights=weights, gamma=0.0, lr=1e-4)
+    ref_loss, ref_g, ref_pyr = _ref_grads(w, im0, im1, gt, weights, use_dc, loss)
+    tn = Trainer(weights=weights, gamma=0.0, lr=1e-4, use_dc=use_dc, loss=loss, epsilon=0.02, q=0.4)
     tn.load_weights(w)
     pyr = tn.forward(gpu(im0), gpu(im1))
     for a, b in zip(pyr, ref_pyr):
@@ -247,25 +251,24 @@ def test_train_step_reduces_the_loss_and_matches_adam():
     assert tn.global_step == 8 and losses[-1] < 0.9 * losses[0]
 
 
-def test_trainer_forward_equals_inference_forward_and_rejects_dc():
+@pytest.mark.parametrize("use_dc", [False, True])
+def test_trainer_forward_equals_inference_forward(use_dc):
     """The training forward (activations kept, weights from the flat buffer) and PWCDCNet.__call__ are the same
-    function; dense connections are not implemented for training and say so."""
+    function, with and without dense connections."""
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a GPU")
     import pwcnet_amd
     from pwcnet_amd.train import Trainer, piecewise_lr
-    w = util.model_weights(False)
+    w = util.model_weights(use_dc)
     im0, im1 = util.smooth_images(2, 64, 128, seed=64)
-    tn = Trainer()
+    tn = Trainer(use_dc=use_dc)
     tn.load_weights(w)
     pyr = tn.forward(gpu(im0), gpu(im1))
-    net = pwcnet_amd.PWCDCNet()
+    net = pwcnet_amd.PWCDCNet(use_dc=use_dc)
     net.load_weights(w)
     _, ref = net(gpu(im0), gpu(im1))
     for a, b in zip(pyr, ref):
-        assert float((a - b).abs().max()) <= 2e-6
-    with pytest.raises(NotImplementedError):
-        Trainer(use_dc=True)
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
     with pytest.raises(ValueError, match="missing"):
         tn.load_weights({})
     # reference train.py:82-88
@@ -273,7 +276,8 @@ def test_trainer_forward_equals_inference_forward_and_rejects_dc():
     assert piecewise_lr(1e-4, 360000) == 1e-4 / 16 and piecewise_lr(1e-4, 360000, scheduling=False) == 1e-4
 
 
-def test_train_cli_synthetic_epoch_writes_a_restorable_bundle(tmp_path):
+@pytest.mark.parametrize("extra,use_dc", [((), False), (("--use-dc", "--loss", "robust"), True)])
+def test_train_cli_synthetic_epoch_writes_a_restorable_bundle(tmp_path, extra, use_dc):
     """train.py (counterpart of the reference's train.py): two short epochs on synthetic translating textures;
     every epoch prints loss / validation EPE and writes a TF-format bundle that PWCDCNet can restore."""
     if not torch.cuda.is_available():
@@ -283,13 +287,13 @@ def test_train_cli_synthetic_epoch_writes_a_restorable_bundle(tmp_path):
     from pwcnet_amd import ckpt
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "train.py"), "-d", "synthetic", "--synthetic_pairs", "20",
-                          "-e", "2", "-b", "4", "--crop_shape", "64", "128", "--lr", "3e-4", "--model_dir", str(tmp_path / "model")],
+                          "-e", "2", "-b", "4", "--crop_shape", "64", "128", "--lr", "3e-4", "--model_dir", str(tmp_path / "model"), *extra],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("epoch ")]
     assert len(lines) == 2 and "EPE/val" in lines[0] and "global_step 8" in lines[1], out.stdout[-1500:]
     w = ckpt.load_weights(str(tmp_path / "model" / "model_2.ckpt"))
-    net = pwcnet_amd.PWCDCNet()
+    net = pwcnet_amd.PWCDCNet(use_dc=use_dc)
     net.load_weights(w)
     im0, im1 = util.smooth_images(1, 64, 128, seed=65)
     final, _ = net(gpu(im0), gpu(im1))

@@ -13,7 +13,7 @@ GPU prompt (one process per GPU, LOCAL_RANK picks the device; gradients are aver
 Dataset: the reference's loaders live in its empty `datahandler` submodule; here a directory is scanned for
 MPI-Sintel-style pairs  <dir>/<pass>/<seq>/frame_NNNN.png  with  <dir>/flow/<seq>/frame_NNNN.flo , or, with
 `--dataset synthetic`, random translating textures with known flow are generated (no files needed).
-Only use_dc=False and the multiscale loss are implemented (Trainer docstring).
+Both use_dc settings and both losses (multiscale, robust) are implemented (Trainer docstring).
 """
 import argparse
 import glob
@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--lr_scheduling", dest="lr_scheduling", action="store_true")
     ap.add_argument("--no-lr_scheduling", dest="lr_scheduling", action="store_false")
     ap.set_defaults(lr_scheduling=True)
+    ap.add_argument("--epsilon", type=float, default=0.02, help="robust loss epsilon [0.02]")
+    ap.add_argument("--q", type=float, default=0.4, help="robust loss exponent [0.4]")
     ap.add_argument("--weights", nargs="+", type=float, default=[0.32, 0.08, 0.02, 0.01, 0.005])
     ap.add_argument("--gamma", type=float, default=0.0004, help="Coefficient for weight decay [4e-4]")
     ap.add_argument("-r", "--resume", type=str, default=None, help="Learned parameter checkpoint prefix [None]")
@@ -112,8 +114,6 @@ def main():
     ap.add_argument("--val_fraction", type=float, default=0.1)
     ap.add_argument("--model_dir", type=str, default="./model")
     args = ap.parse_args()
-    if args.loss != "multiscale":
-        raise SystemExit("train.py: only --loss multiscale is implemented on the HIP path")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -146,7 +146,8 @@ def main():
 
     trainer = Trainer(num_levels=args.num_levels, search_range=args.search_range, warp_type=args.warp_type,
                       use_dc=args.use_dc, output_level=args.output_level, weights=args.weights, gamma=args.gamma,
-                      lr=args.lr, lr_scheduling=args.lr_scheduling, device=f"cuda:{local_rank}", dist=dist)
+                      lr=args.lr, lr_scheduling=args.lr_scheduling, device=f"cuda:{local_rank}", dist=dist,
+                      loss=args.loss, epsilon=args.epsilon, q=args.q)
     if args.resume is not None:
         print(f"Loading learned model from checkpoint {args.resume}")
         trainer.load_weights(ckpt.load_weights(args.resume))
