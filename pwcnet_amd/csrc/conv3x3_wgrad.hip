@@ -14,6 +14,7 @@
 // over `ksplit` workgroups; partial tiles are summed in a fixed order (deterministic) by the reduce kernel,
 // which also maps physical input channels back to the TensorFlow variable's logical order (cin_map).
 #include "pwc_common.h"
+#include <cstdlib>
 
 struct WgradArgs {
     const float* x;
@@ -71,22 +72,46 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < VB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Lane (m, k) walks pixels p_begin + 4*wave + k, + 16, ...: (n, oy, ox) are advanced incrementally (the divisions of
+    // a per-iteration decomposition cost about as many VALU cycles as the 16 MFMAs of the widest tile), and the operands
+    // of the next pixel group are requested before the MFMAs of the current one are issued.
     const int hw = a.Ho * a.Wo;
-    for (long p0 = p_begin + 4 * wave; p0 < p_end; p0 += 16) {
-        const long p = p0 + k;
+    long p = p_begin + 4 * wave + k;
+    int n, oy, ox;
+    {
+        const long pc = min(p, a.npix - 1);
+        n = (int)(pc / hw);
+        const int rem = (int)(pc - (long)n * hw);
+        oy = rem / a.Wo;
+        ox = rem - oy * a.Wo;
+    }
+    const int ty_off = ty * a.dil - a.pt, tx_off = tx * a.dil - a.pl;
+    float av[VA], bv[VB];
+    auto fetch = [&](float (&fa)[VA], float (&fb)[VB]) {
         const bool pv = p < p_end;
-        const int n = (int)(p / hw);
-        const int rem = (int)(p - (long)n * hw);
-        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-        const int iy = oy * a.stride + ty * a.dil - a.pt, ix = ox * a.stride + tx * a.dil - a.pl;
+        const int iy = oy * a.stride + ty_off, ix = ox * a.stride + tx_off;
         const bool in = pv && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        float av[VA], bv[VB];
-        wg_load<VA>(a.x + (((long)n * a.H + iy) * a.W + ix) * a.x_cs + ci, in && ci_ok, av);
-        wg_load<VB>(a.dy + p * a.dy_cs + co, pv && co_ok, bv);
+        wg_load<VA>(a.x + (((long)n * a.H + iy) * a.W + ix) * a.x_cs + ci, in && ci_ok, fa);
+        wg_load<VB>(a.dy + p * a.dy_cs + co, pv && co_ok, fb);
+        p += 16;
+        ox += 16;
+        while (ox >= a.Wo) {
+            ox -= a.Wo;
+            if (++oy == a.Ho) { oy = 0; ++n; }
+        }
+    };
+    fetch(av, bv);
+    for (long p0 = p_begin + 4 * wave; p0 < p_end; p0 += 16) {
+        float an[VA], bn[VB];
+        fetch(an, bn);                                    // (past the end: all-false predicates, zeros)
 #pragma unroll
         for (int i = 0; i < VA; ++i)
 #pragma unroll
             for (int j = 0; j < VB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < VA; ++i) av[i] = an[i];
+#pragma unroll
+        for (int j = 0; j < VB; ++j) bv[j] = bn[j];
     }
 
     // ---- sum the 4 waves' tiles (fixed order), write the partial tile
@@ -118,22 +143,314 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
     }
 }
 
-// dW[tap][ci_log][co] = sum_ks partial[ks][tap][ci_phys][co]   (fixed order), dW zero-filled first by the caller's pass below
+// ---------------------------------------------------------------- stride 1, LDS-staged (the large layers)
+// The kernel above streams both operands from L2 once per (tap, 64x64 channel tile): a 128 -> 128 layer moves
+// 18 KB per pixel through the vector memory path and is bound there (measured 17 TB/s, 43 % of the MFMA peak).
+// conv3x3_wgrad_lds_kernel stages a tile of output pixels ONCE per channel tile for all 9 taps:
+//
+//   workgroup = 512 threads = 8 waves = NCI x NCO x NPX: a (32 NCI) ci x (32 NCO) co x 9 taps tile of dW, a chunk of
+//               pixel tiles (k-split as above).  (NCI, NCO) is chosen per layer so that the channel counts fill the
+//               tile: 128 -> 96 runs as (4, 1), 96 -> 64 as (1, 2), 32 -> 32 as (1, 1) with 8 pixel waves;
+//   tile      = TH x TW = P = 4 G NPX output pixels of one dilation sub-lattice (y mod d, x mod d) of one image --
+//               with dilation d the taps of a sub-lattice pixel are its sub-lattice neighbours, so every dilation is
+//               the d = 1 problem on d*d sub-images -- TW in {64, ..., 8} by the sub-image width;
+//   LDS       = the (TH+2) x (TW+2) input patch and the TH x TW dY tile as 32-channel planes [plane][pixel][32 ch]
+//               (pixel stride 128 B: a wave's ds_read_b64 of 4 pixels x 16 channel pairs is 512 contiguous bytes),
+//               two images: tile s is computed from one while the registers holding tile s+1 (buffer loads issued a
+//               tile earlier; out-of-image pixels and padding channels are out-of-range offsets = zeros) are written
+//               to the other -- one barrier per tile;
+//   wave      = (ci block, co block, pixel part): a 32 x 32 tile x 9 taps = 36 accumulator tiles; per 4-pixel group one
+//               dY read and 9 shifted X reads (ds_read_b64, fetched one group ahead) feed 36 MFMAs.  The pixel parts
+//               are summed through LDS at the end (fixed order), partial tiles go to the same workspace / reduce
+//               kernel as above.
+struct WgLdsArgs {
+    const float* x;
+    const float* dy;
+    float* partial;          // [ksplit][9][Cin_phys][Cout]
+    int x_cs, dy_cs;
+    int N, H, W;
+    int Cin_phys, Cout;
+    int dil;
+    int th, tw, tw_log;      // tile shape (th * tw == P)
+    int tiles_y, tiles_x;    // tiles per sub-lattice image
+    int ksplit, ci_tiles, co_tiles;
+    int ntiles, chunk;       // tiles in total (N * d * d * tiles_y * tiles_x) / per workgroup
+};
+
+constexpr int wl_max_patch(int P) { return P >= 64 ? (P / 64 + 2) * 66 : 3 * (P + 2); }   // widest shape: TW = min(P, 64)
+
+template <int NCI, int NCO, int G> struct WgLdsGeom {
+    static constexpr int NPX = 8 / (NCI * NCO);               // pixel parts (waves)
+    static constexpr int P = 4 * G * NPX;                     // output pixels per tile
+    static constexpr int QX = 8 * NCI, QY = 8 * NCO;          // channel quads per pixel
+    static constexpr int NX = (wl_max_patch(P) * QX + 511) / 512;   // b128 pieces per thread: patch
+    static constexpr int ND = (P * QY + 511) / 512;                 //                         dY tile
+    static constexpr int XPIX = NX * 512 / QX, DPIX = ND * 512 / QY;   // LDS pixels per plane (>= patch / tile pixels)
+    static constexpr int XS = NCI * XPIX * 32, DS = NCO * DPIX * 32;   // floats
+    static constexpr int IMG = XS + DS;
+    static constexpr int RED = (NPX - 1) * NCI * NCO * 12 * 256;       // floats of the final pixel-part reduction
+    static constexpr int LDS_BYTES = (2 * IMG > RED ? 2 * IMG : RED) * 4;
+    static_assert(NCI * NCO * NPX == 8 && LDS_BYTES <= 160 * 1024, "wave split / LDS budget");
+};
+
+template <int NCI, int NCO, int G>
+__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_lds_kernel(const WgLdsArgs a) {
+    typedef WgLdsGeom<NCI, NCO, G> Geo;
+    constexpr int NPX = Geo::NPX, NX = Geo::NX, ND = Geo::ND, QX = Geo::QX, QY = Geo::QY;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int m = lane & 15, k = lane >> 4;
+    const int wci = wave % NCI, wco = (wave / NCI) % NCO, wpx = wave / (NCI * NCO);
+    // XCD-aware order (workgroup b runs on XCD b % 8): the channel tiles of one pixel chunk share an XCD's L2, so every
+    // X / dY tile leaves HBM once.  The grid is rounded up to 8 * ceil(ksplit / 8) chunks; the surplus exits.
+    const int npairs = a.ci_tiles * a.co_tiles;
+    const int idx = blockIdx.x >> 3;
+    const int ks = (blockIdx.x & 7) + 8 * (idx / npairs);
+    if (ks >= a.ksplit) return;
+    const int pair = idx % npairs;
+    const int cot = pair % a.co_tiles, cit = pair / a.co_tiles;
+    const int t_begin = ks * a.chunk, t_end = min(a.ntiles, t_begin + a.chunk);
+    const int pw = a.tw + 2, npatch = (a.th + 2) * pw;
+    const int d = a.dil;
+
+    // ---- this thread's staging pieces (same for every tile).  Piece q = t + 512 * j covers channel quad q % QX of
+    // patch pixel q / QX (j < NX; pixels past the patch are out-of-range loads = zeros into unused LDS pixels) or quad
+    // q % QY of dY tile pixel q / QY (j < ND): no predicates anywhere, LDS slots advance by a constant per piece.
+    const int xquad = t & (QX - 1), xpp0 = t / QX;
+    const int dquad = t & (QY - 1), dpp0 = t / QY;
+    int pc_py[NX], pc_px[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const int pp = xpp0 + (512 / QX) * j;
+        pc_py[j] = pp < npatch ? pp / pw : (1 << 20);         // far outside every image
+        pc_px[j] = pp < npatch ? pp - pc_py[j] * pw : 0;
+    }
+    const int xslot = ((xquad >> 3) * Geo::XPIX + xpp0) * 8 + (xquad & 7);            // 16-byte units; + (512 / QX) * 8 per piece
+    const int dslot = Geo::XS / 4 + ((dquad >> 3) * Geo::DPIX + dpp0) * 8 + (dquad & 7);
+    constexpr unsigned WL_OOB = 0x7FFF0000u;
+    f32x4 stx[NX], std_[ND];
+    const bool xch_ok = cit * 32 * NCI + xquad * 4 < a.Cin_phys, dch_ok = cot * 32 * NCO + dquad * 4 < a.Cout;
+    auto issue = [&](int tile) {
+        int r = tile;
+        const int bx = r % a.tiles_x; r /= a.tiles_x;
+        const int by = r % a.tiles_y; r /= a.tiles_y;
+        const int rx = r % d; r /= d;
+        const int ry = r % d;
+        const int n = r / d;
+        const int sy0 = by * a.th, sx0 = bx * a.tw;          // tile origin in sub-lattice coordinates
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.x + (size_t)n * a.H * a.W * a.x_cs + cit * 32 * NCI), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.dy + (size_t)n * a.H * a.W * a.dy_cs + cot * 32 * NCO), 0, a.H * a.W * a.dy_cs * 4, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int iy = ry + d * (sy0 + pc_py[j] - 1), ix = rx + d * (sx0 + pc_px[j] - 1);
+            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && xch_ok;
+            const unsigned off = ok ? (unsigned)(((iy * a.W + ix) * a.x_cs + xquad * 4) * 4) : WL_OOB;
+            stx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int pix = dpp0 + (512 / QY) * j;
+            const int oy = ry + d * (sy0 + (pix >> a.tw_log)), ox = rx + d * (sx0 + (pix & (a.tw - 1)));
+            const bool ok = pix < Geo::P && oy < a.H && ox < a.W && dch_ok;
+            const unsigned off = ok ? (unsigned)(((oy * a.W + ox) * a.dy_cs + dquad * 4) * 4) : WL_OOB;
+            std_[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dr, (int)off, 0, 0));
+        }
+    };
+    auto stash = [&](float* img) {
+        f32x4* v = reinterpret_cast<f32x4*>(img);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) v[xslot + (512 / QX) * 8 * j] = stx[j];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) v[dslot + (512 / QY) * 8 * j] = std_[j];
+    };
+
+    f32x4 acc[9][2][2];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[tp][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int xa_off = wci * Geo::XPIX * 16 + m;               // in float pairs; + pixel * 16
+    const int db_off = Geo::XS / 2 + wco * Geo::DPIX * 16 + m;
+    if (t_begin < t_end) {
+        issue(t_begin);
+        stash(smem);
+        if (t_begin + 1 < t_end) issue(t_begin + 1);
+    }
+    __syncthreads();
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const float* img = smem + ((tile - t_begin) & 1) * Geo::IMG;
+        float* nxt = smem + (((tile - t_begin) & 1) ^ 1) * Geo::IMG;
+        if (tile + 1 < t_end) {
+            stash(nxt);
+            if (tile + 2 < t_end) issue(tile + 2);
+        }
+        // operands of group g+1 are read from LDS before the MFMAs of group g are issued
+        const f32x2* img2 = reinterpret_cast<const f32x2*>(img);
+        f32x2 bv, av[9];
+        auto fetch = [&](int g, f32x2& fb, f32x2 (&fa)[9]) {
+            const int pix = (wpx * G + g) * 4;              // first tile pixel of the group (one tile row: tw % 4 == 0)
+            const int r = pix >> a.tw_log, c0 = pix & (a.tw - 1);
+            fb = img2[db_off + (pix + k) * 16];
+            const f32x2* xg = img2 + xa_off + (r * pw + c0 + k) * 16;
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) fa[ty * 3 + tx] = xg[(ty * pw + tx) * 16];
+        };
+        fetch(0, bv, av);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            f32x2 bn, an[9];
+            if (g + 1 < G) fetch(g + 1, bn, an);
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tp][i], bv[j], acc[tp][i][j], 0, 0, 0);
+            if (g + 1 < G) {
+                bv = bn;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) av[tp] = an[tp];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- sum the pixel parts through LDS (3 taps at a time: 12 tiles x 1 KB per wave), write the partial tile
+    float* out = a.partial + (long)ks * 9 * a.Cin_phys * a.Cout;
+    const int wch = wave % (NCI * NCO);
+#pragma unroll
+    for (int tr = 0; tr < 3; ++tr) {
+        if (NPX > 1) {
+            if (tr > 0) __syncthreads();
+            if (wpx > 0) {
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            reinterpret_cast<f32x4*>(smem)[((((wpx - 1) * NCI * NCO + wch) * 3 + tx) * 4 + i * 2 + j) * 64 + lane] =
+                                acc[tr * 3 + tx][i][j];
+            }
+            __syncthreads();
+        }
+        if (wpx == 0) {
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4 s = acc[tr * 3 + tx][i][j];
+#pragma unroll
+                        for (int w = 1; w < NPX; ++w)
+                            s += reinterpret_cast<const f32x4*>(smem)[((((w - 1) * NCI * NCO + wch) * 3 + tx) * 4 + i * 2 + j) * 64 + lane];
+                        // D rows 4*k + r' (input channel 2 * row + i), column m (output channel 2 * m + j)
+                        const int oc = (cot * NCO + wco) * 32 + 2 * m + j;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int ic = (cit * NCI + wci) * 32 + (4 * k + rr) * 2 + i;
+                            if (ic < a.Cin_phys && oc < a.Cout)
+                                out[((long)(tr * 3 + tx) * a.Cin_phys + ic) * a.Cout + oc] = s[rr];
+                        }
+                    }
+        }
+    }
+}
+
+// (NCI, NCO, G) configurations instantiated; the plan picks the one with the least padded channel area
+struct WgLdsCfg { int nci, nco, g; };
+static const WgLdsCfg WL_CFGS[] = {{2, 2, 8}, {4, 1, 4}, {2, 1, 4}, {1, 2, 4}, {1, 1, 4}};
+
+// the LDS-staged kernel pays from 32 channels on either side and enough tiles to give every workgroup a few
+static bool wgrad_lds_plan(int N, int H, int W, int Cin_phys, int Cout, int stride, int dil, WgLdsArgs* a, int* cfg_out) {
+    if (stride != 1 || Cin_phys < 32 || Cout < 32 || (Cin_phys & 3) || (Cout & 3)) return false;
+    int best = -1;
+    long best_area = 0;
+    for (int c = 0; c < (int)(sizeof(WL_CFGS) / sizeof(WL_CFGS[0])); ++c) {
+        const int tci = 32 * WL_CFGS[c].nci, tco = 32 * WL_CFGS[c].nco;
+        const long area = (long)((Cin_phys + tci - 1) / tci) * tci * ((Cout + tco - 1) / tco) * tco;
+        if (best < 0 || area < best_area) { best = c; best_area = area; }       // earlier configurations win ties
+    }
+    const WgLdsCfg cf = WL_CFGS[best];
+    const int P = 4 * cf.g * (8 / (cf.nci * cf.nco));
+    const int hs = (H + dil - 1) / dil, ws = (W + dil - 1) / dil;     // sub-lattice image (largest)
+    int tw = P < 64 ? P : 64;
+    while (tw > 8 && tw / 2 >= ws) tw >>= 1;                           // smallest TW that covers the width
+    int tw_log = 0;
+    while ((1 << tw_log) < tw) ++tw_log;
+    const int th = P / tw;
+    const int tiles_x = (ws + tw - 1) / tw, tiles_y = (hs + th - 1) / th;
+    const long ntiles = (long)N * dil * dil * tiles_y * tiles_x;
+    const int ci_tiles = (Cin_phys + 32 * cf.nci - 1) / (32 * cf.nci), co_tiles = (Cout + 32 * cf.nco - 1) / (32 * cf.nco);
+    // one workgroup per CU, and the channel tiles of a chunk on ONE XCD (32 CUs): chunks per XCD = 32 / tile pairs
+    long ks = 8 * (32 / (ci_tiles * co_tiles));
+    if (ks > ntiles / 3) ks = ntiles / 3 / 8 * 8;                       // at least 3 tiles per workgroup
+    if (ks < 8 || ks * ci_tiles * co_tiles < 128 || ntiles >= (1L << 30)) return false;
+    if ((long)H * W * (Cin_phys > Cout ? Cin_phys : Cout) >= (1L << 28)) return false;   // 32-bit byte offsets per image
+    const int chunk = (int)((ntiles + ks - 1) / ks);
+    if (a) {
+        a->th = th; a->tw = tw; a->tw_log = tw_log; a->tiles_x = tiles_x; a->tiles_y = tiles_y;
+        a->ci_tiles = ci_tiles; a->co_tiles = co_tiles; a->ntiles = (int)ntiles; a->chunk = chunk;
+        a->ksplit = (int)((ntiles + chunk - 1) / chunk);
+    }
+    if (cfg_out) *cfg_out = best;
+    return true;
+}
+
+template <int NCI, int NCO, int G>
+static void wgrad_lds_launch(const WgLdsArgs& l, hipStream_t stream) {
+    typedef WgLdsGeom<NCI, NCO, G> Geo;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_lds_kernel<NCI, NCO, G>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_wgrad_lds_kernel<NCI, NCO, G>), dim3((unsigned)((l.ksplit + 7) / 8 * 8 * l.ci_tiles * l.co_tiles)), dim3(512),
+                       Geo::LDS_BYTES, stream, l);
+}
+
+// dW[tap][ci_log][co] (+)= sum_ks partial[ks][tap][ci_phys][co] in a fixed order: block = 64 elements x 4 k-lanes, lane q
+// adds the partials ks = q, q + 4, ... (two running sums), the lanes are combined through LDS as ((0 + 1) + (2 + 3)).
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* __restrict__ partial, const int32_t* __restrict__ cin_map,
                                                                   int ksplit, int Cin_phys, int Cin, int Cout, float* __restrict__ dw,
                                                                   int accumulate) {
+    __shared__ float red[256];
     const long total = 9L * Cin_phys * Cout;
-    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long e = blockIdx.x * 64L + el;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < total) {
+        int ks = q;
+        for (; ks + 4 < ksplit; ks += 8) {
+            s0 += partial[(long)ks * total + e];
+            s1 += partial[(long)(ks + 4) * total + e];
+        }
+        if (ks < ksplit) s0 += partial[(long)ks * total + e];
+    }
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (q == 0 && e < total) {
         const int co = (int)(e % Cout);
-        long r = e / Cout;
+        const long r = e / Cout;
         const int cp = (int)(r % Cin_phys);
         const int tap = (int)(r / Cin_phys);
         const int cl = cin_map ? cin_map[cp] : (cp < Cin ? cp : -1);
-        if (cl < 0 || cl >= Cin) continue;
-        float s = 0.f;
-        for (int ks = 0; ks < ksplit; ++ks) s += partial[(long)ks * total + e];
-        float* d = dw + ((long)tap * Cin + cl) * Cout + co;
-        *d = accumulate ? *d + s : s;
+        if (cl >= 0 && cl < Cin) {
+            const float s = (red[el] + red[64 + el]) + (red[128 + el] + red[192 + el]);
+            float* d = dw + ((long)tap * Cin + cl) * Cout + co;
+            *d = accumulate ? *d + s : s;
+        }
     }
 }
 
@@ -159,6 +476,8 @@ extern "C" size_t pwc_conv3x3_wgrad_workspace_floats(int N, int H, int W, int Ci
     int va, vb, ks;
     long chunk;
     wgrad_plan(N, (H + stride - 1) / stride, (W + stride - 1) / stride, Cin_phys, Cout, &va, &vb, &ks, &chunk);
+    // (the LDS-staged plan depends on the dilation, which this query does not take: its k-split is at most 256)
+    if (stride == 1 && Cin_phys >= 32 && Cout >= 32 && ks < 256) ks = 256;
     return (size_t)ks * 9 * Cin_phys * Cout;
 }
 
@@ -175,6 +494,28 @@ extern "C" int pwc_conv3x3_wgrad_f32(const float* x, int x_cs, const float* dy, 
     pwc_same_pad(H, stride, dilation, &a.Ho, &a.pt);
     pwc_same_pad(W, stride, dilation, &a.Wo, &a.pl);
     a.npix = (long)N * a.Ho * a.Wo;
+    {
+        WgLdsArgs l;
+        int cfg = 0;
+        const bool al = !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(dy) & 15) && !(x_cs & 3) && !(dy_cs & 3);
+        if (al && (long)H * W * (x_cs > dy_cs ? x_cs : dy_cs) < (1L << 29) &&
+            wgrad_lds_plan(N, H, W, Cin_phys, Cout, stride, dilation, &l, &cfg) &&
+            (size_t)l.ksplit * 9 * Cin_phys * Cout <= workspace_floats) {
+            l.x = x; l.dy = dy; l.partial = workspace; l.x_cs = x_cs; l.dy_cs = dy_cs;
+            l.N = N; l.H = H; l.W = W; l.Cin_phys = Cin_phys; l.Cout = Cout; l.dil = dilation;
+            switch (cfg) {
+                case 0: wgrad_lds_launch<2, 2, 8>(l, (hipStream_t)stream); break;
+                case 1: wgrad_lds_launch<4, 1, 4>(l, (hipStream_t)stream); break;
+                case 2: wgrad_lds_launch<2, 1, 4>(l, (hipStream_t)stream); break;
+                case 3: wgrad_lds_launch<1, 2, 4>(l, (hipStream_t)stream); break;
+                default: wgrad_lds_launch<1, 1, 4>(l, (hipStream_t)stream); break;
+            }
+            const long rb = (9L * Cin_phys * Cout + 63) / 64;
+            hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream,
+                               (const float*)workspace, cin_map, l.ksplit, Cin_phys, Cin, Cout, dw_hwio, accumulate);
+            return pwc_launch_status();
+        }
+    }
     int va, vb;
     wgrad_plan(N, a.Ho, a.Wo, Cin_phys, Cout, &va, &vb, &a.ksplit, &a.chunk);
     // vector loads need aligned pointers / strides
@@ -197,8 +538,7 @@ extern "C" int pwc_conv3x3_wgrad_f32(const float* x, int x_cs, const float* dy, 
     else if (va == 1 && vb == 2) WG_LAUNCH(1, 2);
     else WG_LAUNCH(1, 1);
 #undef WG_LAUNCH
-    long rb = (9L * Cin_phys * Cout + 255) / 256;
-    if (rb > 4096) rb = 4096;
+    const long rb = (9L * Cin_phys * Cout + 63) / 64;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, cin_map, a.ksplit, Cin_phys, Cin, Cout, dw_hwio, accumulate);
     return pwc_launch_status();

@@ -17,6 +17,7 @@
 //   pwc_flow_norm_grad_f32      gradient of L1loss / L2loss terms  losses.py:4-8,20-29
 //   pwc_adam_step_f32           tf.train.AdamOptimizer update + the weights' L2 term  train.py:75,90
 #include "pwc_common.h"
+#include <cstdint>
 
 // ------------------------------------------------------------------ elementwise
 __global__ __launch_bounds__(256) void lrelu_grad_kernel(const float* __restrict__ y, int y_cs, float* __restrict__ dy,
@@ -73,24 +74,46 @@ extern "C" int pwc_add_f32(const float* src, int src_cs, float* dst, int dst_cs,
 // pixel lanes are summed through LDS.  With Y != nullptr the kernel first applies the leaky-relu mask to dy IN PLACE
 // (dy *= y > 0 ? 1 : slope) -- bias gradient and activation gradient in one pass over dy.
 // partial: [nparts][C]
+// VEC = 4: channels in float4 lanes (C, strides and pointers multiples of 4 floats), CP = lanes per pixel (power of two).
+template <int VEC>
 __global__ __launch_bounds__(256) void channel_sums_partial_kernel(const float* __restrict__ y, int y_cs, float slope,
                                                                    float* __restrict__ dy, int dy_cs, long npix, int C, int CP,
                                                                    float* __restrict__ partial) {
-    __shared__ float red[256];
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    __shared__ vec_t red[256];
     const int c = threadIdx.x & (CP - 1), pl = threadIdx.x / CP, npl = 256 / CP;
     const long per = (npix + gridDim.x - 1) / gridDim.x;
     const long p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
-    for (int cb = 0; cb < C; cb += CP) {                 // (C > 256: channel blocks of 256)
-        const int cc = cb + c;
-        float s = 0.f;
+    for (int cb = 0; cb < C; cb += CP * VEC) {           // (more than 256 lanes of channels: blocks of them)
+        const int cc = cb + c * VEC;
+        vec_t s = 0.f;
         if (cc < C) {
-            for (long p = p0 + pl; p < p1; p += npl) {
-                float g = dy[p * dy_cs + cc];
+            long p = p0 + pl;
+            for (; p + npl < p1; p += 2 * npl) {          // two pixels in flight per lane
+                vec_t g0 = *(const vec_t*)(dy + p * dy_cs + cc);
+                vec_t g1 = *(const vec_t*)(dy + (p + npl) * dy_cs + cc);
                 if (y) {
-                    g = y[p * y_cs + cc] > 0.f ? g : g * slope;
-                    dy[p * dy_cs + cc] = g;
+                    const vec_t y0 = *(const vec_t*)(y + p * y_cs + cc), y1 = *(const vec_t*)(y + (p + npl) * y_cs + cc);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        g0[e] = y0[e] > 0.f ? g0[e] : g0[e] * slope;
+                        g1[e] = y1[e] > 0.f ? g1[e] : g1[e] * slope;
+                    }
+                    *(vec_t*)(dy + p * dy_cs + cc) = g0;
+                    *(vec_t*)(dy + (p + npl) * dy_cs + cc) = g1;
                 }
-                s += g;
+                s += g0;
+                s += g1;
+            }
+            if (p < p1) {
+                vec_t g0 = *(const vec_t*)(dy + p * dy_cs + cc);
+                if (y) {
+                    const vec_t y0 = *(const vec_t*)(y + p * y_cs + cc);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) g0[e] = y0[e] > 0.f ? g0[e] : g0[e] * slope;
+                    *(vec_t*)(dy + p * dy_cs + cc) = g0;
+                }
+                s += g0;
             }
         }
         red[threadIdx.x] = s;
@@ -99,31 +122,32 @@ __global__ __launch_bounds__(256) void channel_sums_partial_kernel(const float* 
             if (pl < k) red[threadIdx.x] += red[threadIdx.x + k * CP];
             __syncthreads();
         }
-        if (pl == 0 && cc < C) partial[(long)blockIdx.x * C + cc] = red[c];
+        if (pl == 0 && cc < C) *(vec_t*)(partial + (long)blockIdx.x * C + cc) = red[c];
         __syncthreads();
     }
 }
-// out[c] (+)= sum_i partial[i][c]: block = 64 channels x 4 part lanes
+// out[c] (+)= sum_i partial[i][c]: block = 16 channels x 16 part lanes
 __global__ __launch_bounds__(256) void channel_sums_final_kernel(const float* __restrict__ partial, int nparts, int C,
                                                                  float* __restrict__ out, int accumulate) {
     __shared__ float red[256];
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
     if (c < C)
-        for (int i = pl; i < nparts; i += 4) s += partial[(long)i * C + c];
+        for (int i = pl; i < nparts; i += 16) s += partial[(long)i * C + c];
     red[threadIdx.x] = s;
     __syncthreads();
-    if (pl == 0 && c < C) {
-        const float t = (red[cl] + red[64 + cl]) + (red[128 + cl] + red[192 + cl]);
-        out[c] = accumulate ? out[c] + t : t;
+    for (int k = 8; k > 0; k >>= 1) {
+        if (pl < k) red[threadIdx.x] += red[threadIdx.x + k * 16];
+        __syncthreads();
     }
+    if (pl == 0 && c < C) out[c] = accumulate ? out[c] + red[cl] : red[cl];
 }
 
 extern "C" size_t pwc_channel_sums_workspace_floats(long npix, int C) {
     if (npix <= 0 || C <= 0) return 0;
-    long parts = (npix + 511) / 512;
-    if (parts > 1024) parts = 1024;
+    long parts = (npix + 255) / 256;
+    if (parts > 2048) parts = 2048;
     return (size_t)parts * C;
 }
 
@@ -132,11 +156,18 @@ static int channel_sums_launch(const float* y, int y_cs, float slope, float* dy,
     const size_t need = pwc_channel_sums_workspace_floats(npix, C);
     if (workspace_floats < need) return PWC_EINVAL;
     const int parts = (int)(need / C);
+    const bool vec4 = C % 4 == 0 && dy_cs % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)workspace & 15) == 0 &&
+                      (!y || (y_cs % 4 == 0 && ((uintptr_t)y & 15) == 0));
+    const int lanes = vec4 ? C / 4 : C;
     int cp = 1;
-    while (cp < C && cp < 256) cp <<= 1;
-    hipLaunchKernelGGL(channel_sums_partial_kernel, dim3((unsigned)parts), dim3(256), 0, (hipStream_t)stream, y, y_cs, slope, dy,
-                       dy_cs, npix, C, cp, workspace);
-    hipLaunchKernelGGL(channel_sums_final_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+    while (cp < lanes && cp < 256) cp <<= 1;
+    if (vec4)
+        hipLaunchKernelGGL(channel_sums_partial_kernel<4>, dim3((unsigned)parts), dim3(256), 0, (hipStream_t)stream, y, y_cs,
+                           slope, dy, dy_cs, npix, C, cp, workspace);
+    else
+        hipLaunchKernelGGL(channel_sums_partial_kernel<1>, dim3((unsigned)parts), dim3(256), 0, (hipStream_t)stream, y, y_cs,
+                           slope, dy, dy_cs, npix, C, cp, workspace);
+    hipLaunchKernelGGL(channel_sums_final_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, parts, C, out, accumulate);
     return pwc_launch_status();
 }

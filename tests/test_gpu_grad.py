@@ -41,6 +41,11 @@ def close(got, exp, rel=2e-5):
     assert err <= tol, f"max abs err {err:.3e} > tol {tol:.3e} (max |ref| {float(np.abs(exp).max()):.3e})"
 
 
+def View(*a):
+    from pwcnet_amd.modules import View as _V
+    return _V(*a)
+
+
 def V(t):
     from pwcnet_amd.modules import as_view
     return as_view(t)[0]
@@ -144,6 +149,31 @@ def test_conv_wgrad_and_dgrad(go, stride, dil, H, W, cin, cout):
         go.conv3x3_dgrad(V(gdy), gk, V(dx), stride, dil, keep=keep, dy_tensor=gdy)
         torch.cuda.synchronize()
         close(dx, xt.grad, rel=3e-5)
+
+
+@pytest.mark.parametrize("N,dil,H,W,cin,cout", [
+    (2, 1, 64, 128, 128, 128), (2, 4, 64, 128, 96, 64), (4, 1, 50, 70, 40, 36), (1, 16, 112, 256, 96, 64),
+    (2, 2, 33, 47, 64, 100), (3, 1, 28, 64, 160, 32), (8, 8, 24, 20, 32, 32)])
+def test_conv_wgrad_lds_staged_kernel(go, N, dil, H, W, cin, cout):
+    """Shapes the LDS-staged weight-gradient kernel takes (stride 1, >= 32 channels, enough 64-pixel tiles): full and
+    ragged tiles, every tile shape (64x1 ... 8x8), dilation sub-lattices that do not divide the image."""
+    x, dy = rnd((N, H, W, cin), 23), rnd((N, H, W, cout), 24)
+    xt = t64(x, False)
+    kt = torch.zeros((3, 3, cin, cout), dtype=torch.float64, requires_grad=True)
+    (tr.conv3x3_same(xt, kt, torch.zeros(cout, dtype=torch.float64), 1, dil) * t64(dy, False)).sum().backward()
+    gx, gdy = gpu(x), gpu(dy)
+    dw = torch.full((3, 3, cin, cout), 7.0, device="cuda")
+    go.conv3x3_wgrad(V(gx), V(gdy), dw, cin, 1, dil)
+    close(dw, kt.grad, rel=3e-5)
+    # strided views (the dense-connection buffers): x and dy as channel slices of wider tensors
+    if cin % 8 == 0:
+        wide_x = torch.zeros((N, H, W, cin + 16), device="cuda"); wide_x[..., 8:8 + cin] = gx
+        wide_d = torch.zeros((N, H, W, cout + 8), device="cuda"); wide_d[..., 4:4 + cout] = gdy
+        vx = View(wide_x.data_ptr() + 32, cin + 16, N, H, W, cin)
+        vd = View(wide_d.data_ptr() + 16, cout + 8, N, H, W, cout)
+        dw2 = torch.zeros((3, 3, cin, cout), device="cuda")
+        go.conv3x3_wgrad(vx, vd, dw2, cin, 1, dil)
+        close(dw2, kt.grad, rel=3e-5)
 
 
 def test_conv_wgrad_with_channel_map(go):
