@@ -76,6 +76,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget")
     ap.add_argument("--no-op-timing", action="store_true", help="skip the per-launch HIP events")
     ap.add_argument("--no-op-leg", action="store_true", help="skip the op-level correlation/warp leg")
+    ap.add_argument("--mode", choices=("infer", "train"), default="infer",
+                    help="train: one optimisation step per bench step (pwcnet_amd.train.Trainer: forward, backward, "
+                         "one RCCL all-reduce of the gradients, Adam) -- SURVEY.md 8 f4, not the headline metric")
+    ap.add_argument("--loss", choices=("multiscale", "robust"), default="multiscale", help="--mode train")
     ap.add_argument("--persistent-outputs", action="store_true",
                     help="PWCDCNet(persistent_outputs=True): replays write into the plan's own output tensors")
     args = ap.parse_args(argv)
@@ -119,6 +123,59 @@ def spawn(args):
 SAMPLE_EVERY = 8
 
 
+def train_mode(args, dist, dev, rank, world):
+    """--mode train: K optimisation steps of the training path on this rank's batch (synthetic pairs and flows,
+    seeded glorot-uniform weights).  Data-parallel: every rank steps on its own pairs, gradients are summed with one
+    all-reduce per step.  Same timing bracket as the inference mode."""
+    from pwcnet_amd.sharding import gather_stats
+    from pwcnet_amd.train import Trainer
+    B, H, Wd = args.batch, args.height, args.width
+    tn = Trainer(use_dc=args.use_dc, loss=args.loss, device=str(dev), dist=dist)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321 + rank)
+    im0 = torch.rand((B, H, Wd, 3), generator=g, device=dev, dtype=torch.float32)
+    im1 = torch.rand((B, H, Wd, 3), generator=g, device=dev, dtype=torch.float32)
+    gt = torch.randn((B, H, Wd, 2), generator=g, device=dev, dtype=torch.float32) * 3.0
+    loss0 = None
+    for _ in range(max(args.warmup, 1)):
+        v = float(tn.step(im0, im1, gt))
+        loss0 = v if loss0 is None else loss0
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    torch.cuda.reset_peak_memory_stats()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tn.step(im0, im1, gt)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    stats = gather_stats(dict(pairs=float(B * args.steps), seconds=elapsed), dist, dev)
+    if rank == 0:
+        mx = max(s["seconds"] for s in stats)
+        print(json.dumps({
+            "metric": f"training_image_pairs_per_sec_{H}x{Wd}",
+            "value": sum(s["pairs"] for s in stats) / mx, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": max(args.warmup, 1), "ms_per_step": 1e3 * mx / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (uniform[0,1) images, N(0, 3^2) px flows, seeded glorot-uniform weights)",
+            "config": {"workload": f"training step (forward + backward + Adam), batch={B} pairs per GPU, {H}x{Wd}, "
+                                   f"PWCDCNet use_dc={args.use_dc}, {args.loss} loss, on {world}xMI355X",
+                       "global_batch": B * world, "per_gpu_batch": B, "height": H, "width": Wd,
+                       "parallelism": f"dp{world}: pairs sharded across ranks"
+                                      + ("" if dist is None else "; one RCCL all-reduce of the 20 MB gradient buffer per step")},
+            "loss_first_step": loss0, "loss_last_step": float(loss),
+            "peak_memory_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
+        }))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
@@ -152,6 +209,9 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+
+    if args.mode == "train":
+        return train_mode(args, dist, dev, rank, world)
 
     import pwcnet_amd
     from pwcnet_amd import weights as W

@@ -191,6 +191,19 @@ def test_bench_spawns_its_ranks_with_rccl(pa):
     assert d["parity"]["max_abs_flows_final"] <= d["parity"]["tolerance"]
 
 
+def test_bench_train_mode_through_the_rccl_launch(pa):
+    """`bench.py --mode train --gpus 1 --spawn`: training steps under torch.distributed.run -- the gradient all-reduce
+    runs on the nccl (= RCCL) process group (world 1), the loss falls on the repeated batch."""
+    out = _run_bench(["--gpus", "1", "--spawn", "--mode", "train", "--steps", "4"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("training_image_pairs_per_sec") and d["n_gpus"] == 1 and d["value"] > 0
+    assert "all-reduce" in d["config"]["parallelism"]
+    assert d["loss_last_step"] < d["loss_first_step"]
+
+
 def test_bench_rejects_a_world_size_that_contradicts_gpus(pa):
     """--gpus must never be silently ignored."""
     more = torch.cuda.device_count() + 1
