@@ -179,23 +179,30 @@ struct WgLdsArgs {
 
 constexpr int wl_max_patch(int P) { return P >= 64 ? (P / 64 + 2) * 66 : 3 * (P + 2); }   // widest shape: TW = min(P, 64)
 
-template <int NCI, int NCO, int G> struct WgLdsGeom {
+typedef float f32x1 __attribute__((ext_vector_type(1)));
+template <int V> __device__ __forceinline__ float wl_elem(f32x1 v, int) { return v[0]; }
+template <int V> __device__ __forceinline__ float wl_elem(f32x2 v, int i) { return v[i]; }
+
+template <int NCI, int NCO, int G, int V = 2> struct WgLdsGeom {
+    static constexpr int CPP = 16 * V, QPP = 4 * V;           // channels / 16-byte quads per plane (a wave tile is CPP wide)
     static constexpr int NPX = 8 / (NCI * NCO);               // pixel parts (waves)
     static constexpr int P = 4 * G * NPX;                     // output pixels per tile
-    static constexpr int QX = 8 * NCI, QY = 8 * NCO;          // channel quads per pixel
+    static constexpr int QX = QPP * NCI, QY = QPP * NCO;      // channel quads per pixel
     static constexpr int NX = (wl_max_patch(P) * QX + 511) / 512;   // b128 pieces per thread: patch
     static constexpr int ND = (P * QY + 511) / 512;                 //                         dY tile
     static constexpr int XPIX = NX * 512 / QX, DPIX = ND * 512 / QY;   // LDS pixels per plane (>= patch / tile pixels)
-    static constexpr int XS = NCI * XPIX * 32, DS = NCO * DPIX * 32;   // floats
+    static constexpr int XS = NCI * XPIX * CPP, DS = NCO * DPIX * CPP;   // floats
     static constexpr int IMG = XS + DS;
-    static constexpr int RED = (NPX - 1) * NCI * NCO * 12 * 256;       // floats of the final pixel-part reduction
+    static constexpr int RED = (NPX - 1) * NCI * NCO * 3 * V * V * 256;   // floats of the final pixel-part reduction
     static constexpr int LDS_BYTES = (2 * IMG > RED ? 2 * IMG : RED) * 4;
     static_assert(NCI * NCO * NPX == 8 && LDS_BYTES <= 160 * 1024, "wave split / LDS budget");
 };
 
-template <int NCI, int NCO, int G>
+template <int NCI, int NCO, int G, int V>
 __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_lds_kernel(const WgLdsArgs a) {
-    typedef WgLdsGeom<NCI, NCO, G> Geo;
+    typedef WgLdsGeom<NCI, NCO, G, V> Geo;
+    constexpr int CPP = Geo::CPP, QPP = Geo::QPP;
+    typedef float vec_t __attribute__((ext_vector_type(V)));
     constexpr int NPX = Geo::NPX, NX = Geo::NX, ND = Geo::ND, QX = Geo::QX, QY = Geo::QY;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63;
@@ -226,11 +233,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_lds_kernel(const WgLdsAr
         pc_py[j] = pp < npatch ? pp / pw : (1 << 20);         // far outside every image
         pc_px[j] = pp < npatch ? pp - pc_py[j] * pw : 0;
     }
-    const int xslot = ((xquad >> 3) * Geo::XPIX + xpp0) * 8 + (xquad & 7);            // 16-byte units; + (512 / QX) * 8 per piece
-    const int dslot = Geo::XS / 4 + ((dquad >> 3) * Geo::DPIX + dpp0) * 8 + (dquad & 7);
+    const int xslot = ((xquad / QPP) * Geo::XPIX + xpp0) * QPP + (xquad % QPP);      // 16-byte units; + (512 / QX) * QPP per piece
+    const int dslot = Geo::XS / 4 + ((dquad / QPP) * Geo::DPIX + dpp0) * QPP + (dquad % QPP);
     constexpr unsigned WL_OOB = 0x7FFF0000u;
     f32x4 stx[NX], std_[ND];
-    const bool xch_ok = cit * 32 * NCI + xquad * 4 < a.Cin_phys, dch_ok = cot * 32 * NCO + dquad * 4 < a.Cout;
+    const bool xch_ok = cit * CPP * NCI + xquad * 4 < a.Cin_phys, dch_ok = cot * CPP * NCO + dquad * 4 < a.Cout;
     auto issue = [&](int tile) {
         int r = tile;
         const int bx = r % a.tiles_x; r /= a.tiles_x;
@@ -240,9 +247,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_lds_kernel(const WgLdsAr
         const int n = r / d;
         const int sy0 = by * a.th, sx0 = bx * a.tw;          // tile origin in sub-lattice coordinates
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.x + (size_t)n * a.H * a.W * a.x_cs + cit * 32 * NCI), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
+            (void*)(a.x + (size_t)n * a.H * a.W * a.x_cs + cit * CPP * NCI), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.dy + (size_t)n * a.H * a.W * a.dy_cs + cot * 32 * NCO), 0, a.H * a.W * a.dy_cs * 4, 0x00020000);
+            (void*)(a.dy + (size_t)n * a.H * a.W * a.dy_cs + cot * CPP * NCO), 0, a.H * a.W * a.dy_cs * 4, 0x00020000);
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
             const int iy = ry + d * (sy0 + pc_py[j] - 1), ix = rx + d * (sx0 + pc_px[j] - 1);
@@ -262,21 +269,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_lds_kernel(const WgLdsAr
     auto stash = [&](float* img) {
         f32x4* v = reinterpret_cast<f32x4*>(img);
 #pragma unroll
-        for (int j = 0; j < NX; ++j) v[xslot + (512 / QX) * 8 * j] = stx[j];
+        for (int j = 0; j < NX; ++j) v[xslot + (512 / QX) * QPP * j] = stx[j];
 #pragma unroll
-        for (int j = 0; j < ND; ++j) v[dslot + (512 / QY) * 8 * j] = std_[j];
+        for (int j = 0; j < ND; ++j) v[dslot + (512 / QY) * QPP * j] = std_[j];
     };
 
-    f32x4 acc[9][2][2];
+    f32x4 acc[9][V][V];
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < V; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[tp][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < V; ++j) acc[tp][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int xa_off = wci * Geo::XPIX * 16 + m;               // in float pairs; + pixel * 16
-    const int db_off = Geo::XS / 2 + wco * Geo::DPIX * 16 + m;
+    const int xa_off = wci * Geo::XPIX * 16 + m;               // in V-float vectors; + pixel * 16
+    const int db_off = Geo::XS / V + wco * Geo::DPIX * 16 + m;
     if (t_begin < t_end) {
         issue(t_begin);
         stash(smem);
@@ -291,13 +298,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_lds_kernel(const WgLdsAr
             if (tile + 2 < t_end) issue(tile + 2);
         }
         // operands of group g+1 are read from LDS before the MFMAs of group g are issued
-        const f32x2* img2 = reinterpret_cast<const f32x2*>(img);
-        f32x2 bv, av[9];
-        auto fetch = [&](int g, f32x2& fb, f32x2 (&fa)[9]) {
+        const vec_t* img2 = reinterpret_cast<const vec_t*>(img);
+        vec_t bv, av[9];
+        auto fetch = [&](int g, vec_t& fb, vec_t (&fa)[9]) {
             const int pix = (wpx * G + g) * 4;              // first tile pixel of the group (one tile row: tw % 4 == 0)
             const int r = pix >> a.tw_log, c0 = pix & (a.tw - 1);
             fb = img2[db_off + (pix + k) * 16];
-            const f32x2* xg = img2 + xa_off + (r * pw + c0 + k) * 16;
+            const vec_t* xg = img2 + xa_off + (r * pw + c0 + k) * 16;
 #pragma unroll
             for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
@@ -306,15 +313,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_lds_kernel(const WgLdsAr
         fetch(0, bv, av);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            f32x2 bn, an[9];
+            vec_t bn, an[9];
             if (g + 1 < G) fetch(g + 1, bn, an);
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < V; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tp][i], bv[j], acc[tp][i][j], 0, 0, 0);
+                    for (int j = 0; j < V; ++j)
+                        acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl_elem<V>(av[tp], i), wl_elem<V>(bv, j), acc[tp][i][j], 0, 0, 0);
             if (g + 1 < G) {
                 bv = bn;
 #pragma unroll
@@ -335,10 +342,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_lds_kernel(const WgLdsAr
 #pragma unroll
                 for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < V; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            reinterpret_cast<f32x4*>(smem)[((((wpx - 1) * NCI * NCO + wch) * 3 + tx) * 4 + i * 2 + j) * 64 + lane] =
+                        for (int j = 0; j < V; ++j)
+                            reinterpret_cast<f32x4*>(smem)[((((wpx - 1) * NCI * NCO + wch) * 3 + tx) * V * V + i * V + j) * 64 + lane] =
                                 acc[tr * 3 + tx][i][j];
             }
             __syncthreads();
@@ -347,18 +354,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_lds_kernel(const WgLdsAr
 #pragma unroll
             for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < V; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < V; ++j) {
                         f32x4 s = acc[tr * 3 + tx][i][j];
 #pragma unroll
                         for (int w = 1; w < NPX; ++w)
-                            s += reinterpret_cast<const f32x4*>(smem)[((((w - 1) * NCI * NCO + wch) * 3 + tx) * 4 + i * 2 + j) * 64 + lane];
-                        // D rows 4*k + r' (input channel 2 * row + i), column m (output channel 2 * m + j)
-                        const int oc = (cot * NCO + wco) * 32 + 2 * m + j;
+                            s += reinterpret_cast<const f32x4*>(smem)[((((w - 1) * NCI * NCO + wch) * 3 + tx) * V * V + i * V + j) * 64 + lane];
+                        // D rows 4*k + r' (input channel V * row + i), column m (output channel V * m + j)
+                        const int oc = (cot * NCO + wco) * CPP + V * m + j;
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
-                            const int ic = (cit * NCI + wci) * 32 + (4 * k + rr) * 2 + i;
+                            const int ic = (cit * NCI + wci) * CPP + (4 * k + rr) * V + i;
                             if (ic < a.Cin_phys && oc < a.Cout)
                                 out[((long)(tr * 3 + tx) * a.Cin_phys + ic) * a.Cout + oc] = s[rr];
                         }
@@ -368,16 +375,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_lds_kernel(const WgLdsAr
 }
 
 // (NCI, NCO, G) configurations instantiated; the plan picks the one with the least padded channel area
-struct WgLdsCfg { int nci, nco, g; };
-static const WgLdsCfg WL_CFGS[] = {{2, 2, 8}, {4, 1, 4}, {2, 1, 4}, {1, 2, 4}, {1, 1, 4}};
+struct WgLdsCfg { int nci, nco, g, v; };
+static const WgLdsCfg WL_CFGS[] = {{2, 2, 8, 2}, {4, 1, 4, 2}, {2, 1, 4, 2}, {1, 2, 4, 2}, {1, 1, 4, 2}, {1, 1, 16, 1}};
 
 // the LDS-staged kernel pays from 32 channels on either side and enough tiles to give every workgroup a few
 static bool wgrad_lds_plan(int N, int H, int W, int Cin_phys, int Cout, int stride, int dil, WgLdsArgs* a, int* cfg_out) {
-    if (stride != 1 || Cin_phys < 32 || Cout < 32 || (Cin_phys & 3) || (Cout & 3)) return false;
+    if (stride != 1 || Cin_phys < 16 || Cout < 16 || (Cin_phys & 3) || (Cout & 3)) return false;
     int best = -1;
     long best_area = 0;
+    const bool narrow = Cin_phys <= 16 && Cout <= 16;                  // 16-wide wave tiles only for the 16 -> 16 layers
+    if (!narrow && (Cin_phys < 32 || Cout < 32)) return false;
     for (int c = 0; c < (int)(sizeof(WL_CFGS) / sizeof(WL_CFGS[0])); ++c) {
-        const int tci = 32 * WL_CFGS[c].nci, tco = 32 * WL_CFGS[c].nco;
+        if ((WL_CFGS[c].v == 1) != narrow) continue;
+        const int tci = 16 * WL_CFGS[c].v * WL_CFGS[c].nci, tco = 16 * WL_CFGS[c].v * WL_CFGS[c].nco;
         const long area = (long)((Cin_phys + tci - 1) / tci) * tci * ((Cout + tco - 1) / tco) * tco;
         if (best < 0 || area < best_area) { best = c; best_area = area; }       // earlier configurations win ties
     }
@@ -391,7 +401,8 @@ static bool wgrad_lds_plan(int N, int H, int W, int Cin_phys, int Cout, int stri
     const int th = P / tw;
     const int tiles_x = (ws + tw - 1) / tw, tiles_y = (hs + th - 1) / th;
     const long ntiles = (long)N * dil * dil * tiles_y * tiles_x;
-    const int ci_tiles = (Cin_phys + 32 * cf.nci - 1) / (32 * cf.nci), co_tiles = (Cout + 32 * cf.nco - 1) / (32 * cf.nco);
+    const int tci = 16 * cf.v * cf.nci, tco = 16 * cf.v * cf.nco;
+    const int ci_tiles = (Cin_phys + tci - 1) / tci, co_tiles = (Cout + tco - 1) / tco;
     // one workgroup per CU, and the channel tiles of a chunk on ONE XCD (32 CUs): chunks per XCD = 32 / tile pairs
     long ks = 8 * (32 / (ci_tiles * co_tiles));
     if (ks > ntiles / 3) ks = ntiles / 3 / 8 * 8;                       // at least 3 tiles per workgroup
@@ -407,16 +418,16 @@ static bool wgrad_lds_plan(int N, int H, int W, int Cin_phys, int Cout, int stri
     return true;
 }
 
-template <int NCI, int NCO, int G>
+template <int NCI, int NCO, int G, int V>
 static void wgrad_lds_launch(const WgLdsArgs& l, hipStream_t stream) {
-    typedef WgLdsGeom<NCI, NCO, G> Geo;
+    typedef WgLdsGeom<NCI, NCO, G, V> Geo;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_lds_kernel<NCI, NCO, G>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_lds_kernel<NCI, NCO, G, V>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_wgrad_lds_kernel<NCI, NCO, G>), dim3((unsigned)((l.ksplit + 7) / 8 * 8 * l.ci_tiles * l.co_tiles)), dim3(512),
+    hipLaunchKernelGGL((conv3x3_wgrad_lds_kernel<NCI, NCO, G, V>), dim3((unsigned)((l.ksplit + 7) / 8 * 8 * l.ci_tiles * l.co_tiles)), dim3(512),
                        Geo::LDS_BYTES, stream, l);
 }
 
@@ -477,7 +488,7 @@ extern "C" size_t pwc_conv3x3_wgrad_workspace_floats(int N, int H, int W, int Ci
     long chunk;
     wgrad_plan(N, (H + stride - 1) / stride, (W + stride - 1) / stride, Cin_phys, Cout, &va, &vb, &ks, &chunk);
     // (the LDS-staged plan depends on the dilation, which this query does not take: its k-split is at most 256)
-    if (stride == 1 && Cin_phys >= 32 && Cout >= 32 && ks < 256) ks = 256;
+    if (stride == 1 && Cin_phys >= 16 && Cout >= 16 && ks < 256) ks = 256;
     return (size_t)ks * 9 * Cin_phys * Cout;
 }
 
@@ -504,11 +515,12 @@ extern "C" int pwc_conv3x3_wgrad_f32(const float* x, int x_cs, const float* dy, 
             l.x = x; l.dy = dy; l.partial = workspace; l.x_cs = x_cs; l.dy_cs = dy_cs;
             l.N = N; l.H = H; l.W = W; l.Cin_phys = Cin_phys; l.Cout = Cout; l.dil = dilation;
             switch (cfg) {
-                case 0: wgrad_lds_launch<2, 2, 8>(l, (hipStream_t)stream); break;
-                case 1: wgrad_lds_launch<4, 1, 4>(l, (hipStream_t)stream); break;
-                case 2: wgrad_lds_launch<2, 1, 4>(l, (hipStream_t)stream); break;
-                case 3: wgrad_lds_launch<1, 2, 4>(l, (hipStream_t)stream); break;
-                default: wgrad_lds_launch<1, 1, 4>(l, (hipStream_t)stream); break;
+                case 0: wgrad_lds_launch<2, 2, 8, 2>(l, (hipStream_t)stream); break;
+                case 1: wgrad_lds_launch<4, 1, 4, 2>(l, (hipStream_t)stream); break;
+                case 2: wgrad_lds_launch<2, 1, 4, 2>(l, (hipStream_t)stream); break;
+                case 3: wgrad_lds_launch<1, 2, 4, 2>(l, (hipStream_t)stream); break;
+                case 4: wgrad_lds_launch<1, 1, 4, 2>(l, (hipStream_t)stream); break;
+                default: wgrad_lds_launch<1, 1, 16, 1>(l, (hipStream_t)stream); break;
             }
             const long rb = (9L * Cin_phys * Cout + 63) / 64;
             hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream,
