@@ -119,8 +119,8 @@ def spawn(args):
 
 
 # HIP events bracket the instrumented kernels in every SAMPLE_EVERY-th step of the timed region only:
-# an event pair serialises the launches around it (45 instrumented launches cost 9 % of a step)
-SAMPLE_EVERY = 8
+# an event pair serialises the launches around it (45 instrumented launches cost 9 % of such a step)
+SAMPLE_EVERY = 10
 
 
 def train_mode(args, dist, dev, rank, world):
@@ -273,9 +273,13 @@ def main():
     stats = gather_stats(dict(pairs=float(B * args.steps), seconds=elapsed), dist, dev)
     max_elapsed = max(s["seconds"] for s in stats)
     total_pairs = sum(s["pairs"] for s in stats)
+    used_rccl = dist is not None
+    if dist is not None:
+        # every rank leaves the process group together, before rank 0's single-GPU legs (op-level leg, CPU baseline)
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
         return
 
     cfg_idx = None
@@ -305,7 +309,7 @@ def main():
             "height": H,
             "width": Wd,
             "parallelism": f"dp{world}: pairs sharded across ranks, no data-path collective"
-                           + ("" if dist is None else "; RCCL all-gather of per-rank stats"),
+                           + ("; RCCL all-gather of per-rank stats" if used_rccl else ""),
             "outputs": "persistent (plan-owned)" if args.persistent_outputs else "fresh tensors per call",
         },
     }
@@ -386,8 +390,6 @@ def main():
 
     print(json.dumps(line))
     sys.stdout.flush()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 def corr_warp_op_leg(net, B, H, Wd, dev, reps=12):
