@@ -31,7 +31,8 @@ Extra objects in the line:
   cpu_baseline   the CPU oracle (oracle/, a port -- the TF reference cannot run) timed on
                  the host cores on whole pairs of the bench shape, N=1 / rank 0 only;
   parity         max-abs / EPE of flows_final between the HIP path and the oracle on the
-                 cpu_baseline pair.
+                 cpu_baseline pair; parity_moving: the same with every conv kernel scaled up so
+                 that the flows, and with them the warps, are several pixels.
 """
 import argparse
 import json
@@ -506,6 +507,17 @@ def cpu_baseline_and_parity(net, wts, args, dev):
     a, b, e_final = first
     final, _ = net(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev))
     got = final.cpu().numpy()
+    # Random-init weights give flows of a fraction of a pixel: the warps barely move anything.  Second check with every
+    # kernel scaled up (flows of several pixels at every level, as in tests/test_gpu_model.py::test_e2e_large_flows):
+    # same pair, same bound.
+    import pwcnet_amd
+    gain = 1.25 if args.use_dc else 1.35
+    w2 = {k: (v * gain).astype(np.float32) if k.endswith("/kernel") else v for k, v in wts.items()}
+    net2 = pwcnet_amd.PWCDCNet(use_dc=args.use_dc)
+    net2.load_weights(w2)
+    e2, _ = orc.OraclePWCDCNet(w2, use_dc=args.use_dc)(a, b)
+    g2 = net2(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev))[0].cpu().numpy()
+    del net2
     return {
         "cpu_baseline": {"value": n_done / t_cpu, "unit": "pairs/s", "cores": orc.num_threads(), "kind": "port",
                          "host_cpu_count": os.cpu_count(), "cpus_in_affinity_mask": len(usable),
@@ -516,6 +528,10 @@ def cpu_baseline_and_parity(net, wts, args, dev):
         "parity": {"max_abs_flows_final": float(np.abs(got - e_final).max()),
                    "epe": orc.epe(e_final, got), "tolerance": 1e-3,
                    "max_abs_flow_value": float(np.abs(e_final).max())},
+        "parity_moving": {"max_abs_flows_final": float(np.abs(g2 - e2).max()), "epe": orc.epe(e2, g2), "tolerance": 1e-3,
+                          "max_abs_flow_value": float(np.abs(e2).max()), "kernel_gain": gain,
+                          "note": "same pair, every conv kernel scaled by kernel_gain so that the flows (and the warps) "
+                                  "are several pixels"},
     }
 
 
