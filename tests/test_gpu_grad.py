@@ -165,6 +165,11 @@ def test_conv_wgrad_lds_staged_kernel(go, N, dil, H, W, cin, cout):
     dw = torch.full((3, 3, cin, cout), 7.0, device="cuda")
     go.conv3x3_wgrad(V(gx), V(gdy), dw, cin, 1, dil)
     close(dw, kt.grad, rel=3e-5)
+    # fixed summation order (k-split partials, pixel parts): bit-identical on every run
+    for _ in range(3):
+        again = torch.full((3, 3, cin, cout), -3.0, device="cuda")
+        go.conv3x3_wgrad(V(gx), V(gdy), again, cin, 1, dil)
+        assert torch.equal(again, dw)
     # strided views (the dense-connection buffers): x and dy as channel slices of wider tensors
     if cin % 8 == 0:
         wide_x = torch.zeros((N, H, W, cin + 16), device="cuda"); wide_x[..., 8:8 + cin] = gx
