@@ -254,6 +254,80 @@ __global__ __launch_bounds__(256) void conv3x3_head2_tile_kernel(const DirectArg
     }
 }
 
+// Flow heads of the dense-connection estimators (modules.py:269-274 with use_dc: Cin = 725 ... 3169 -> 2): the same
+// tile decomposition with a loop over 32-channel chunks.  The generic kernel below reads every input value 9 times
+// with one thread per pixel walking all channels (3.1 ms average, 10 ms at level 4: a third of the use_dc forward);
+// here the next chunk's patch is fetched into registers while the current one is reduced from LDS.
+__global__ __launch_bounds__(256) void conv3x3_head2_wide_kernel(const DirectArgs a, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float patch[8 * HT_PLANE];
+    constexpr int NLD = (HT_NP * 8 + 255) / 256;             // b128 pieces per thread and chunk (11)
+    const int t = threadIdx.x;
+    int blk = blockIdx.x;
+    const int bx = blk % tiles_x; blk /= tiles_x;
+    const int by = blk % tiles_y;
+    const int n = blk / tiles_y;
+    const int y0 = by * HT_R, x0 = bx * HT_C;
+    const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs;
+    // this thread's pieces: patch pixel and channel quad (fixed over the chunks), global offset or -1
+    long goff[NLD];
+    int lslot[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int e = t + 256 * j;
+        const int p = e >> 3, q = e & 7;
+        const int py = p / HT_PW, px = p - py * HT_PW;
+        const int y = y0 - 1 + py, x = x0 - 1 + px;
+        const bool ok = e < HT_NP * 8 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        goff[j] = ok ? ((long)y * a.W + x) * a.x_cs + q * 4 : -1;
+        lslot[j] = e < HT_NP * 8 ? q * HT_PLANE + p * 4 : -1;
+    }
+    f32x4 st[NLD];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (goff[j] >= 0 && c0 + ((t + 256 * j) & 7) * 4 < a.Cin) v = *reinterpret_cast<const f32x4*>(xn + goff[j] + c0);
+            st[j] = v;
+        }
+    };
+    const int r = t >> 5, c = t & 31;
+    float s0a = 0.f, s0b = 0.f, s1a = 0.f, s1b = 0.f;
+    fetch(0);
+    for (int c0 = 0; c0 < a.Cin; c0 += 32) {
+        __syncthreads();                                      // the previous chunk has been read
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+            if (lslot[j] >= 0) *reinterpret_cast<f32x4*>(patch + lslot[j]) = st[j];
+        __syncthreads();
+        if (c0 + 32 < a.Cin) fetch(c0 + 32);
+        const int nq = min(8, (a.Cin - c0) >> 2);             // channel quads of this chunk (Cin % 4 == 0)
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const float* pp = patch + ((r + ty) * HT_PW + c + tx) * 4;
+                const float* wt = a.w + ((size_t)(ty * 3 + tx) * a.Cin + c0) * 2;      // [ci][2 co] of this tap: wave-uniform
+                for (int q = 0; q < nq; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(pp + q * HT_PLANE);
+                    const float* w = wt + q * 8;
+                    s0a = fmaf(v[0], w[0], s0a); s1a = fmaf(v[0], w[1], s1a);
+                    s0b = fmaf(v[1], w[2], s0b); s1b = fmaf(v[1], w[3], s1b);
+                    s0a = fmaf(v[2], w[4], s0a); s1a = fmaf(v[2], w[5], s1a);
+                    s0b = fmaf(v[3], w[6], s0b); s1b = fmaf(v[3], w[7], s1b);
+                }
+            }
+    }
+    const int oy = y0 + r, ox = x0 + c;
+    if (oy < a.H && ox < a.W) {
+        const size_t m = ((size_t)n * a.H + oy) * a.W + ox;
+        float v0 = (s0a + s0b) + a.bias[0], v1 = (s1a + s1b) + a.bias[1];
+        if (a.apply_act) { v0 = pwc_lrelu(v0, a.slope); v1 = pwc_lrelu(v1, a.slope); }
+        if (a.res) { v0 += a.res[m * a.res_cs]; v1 += a.res[m * a.res_cs + 1]; }
+        a.y[m * a.y_cs] = v0;
+        a.y[m * a.y_cs + 1] = v1;
+    }
+}
+
 extern "C" int pwc_conv3x3_direct_f32(const float* x, int x_cs, const float* w_hwio, const float* bias,
                                       float* y, int y_cs, const float* residual, int res_cs, int N, int H,
                                       int W, int Cin, int Cout, int stride, int dilation, int apply_act,
@@ -285,6 +359,14 @@ extern "C" int pwc_conv3x3_direct_f32(const float* x, int x_cs, const float* w_h
         const long nblk = (long)N * tiles_x * tiles_y;
         if (nblk < (1L << 31)) {
             hipLaunchKernelGGL(conv3x3_head2_tile_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a, tiles_x, tiles_y);
+            return pwc_launch_status();
+        }
+    }
+    if (Cout == 2 && Cin >= 64 && vec4 && stride == 1 && dilation == 1) {
+        const int tiles_x = (W + HT_C - 1) / HT_C, tiles_y = (H + HT_R - 1) / HT_R;
+        const long nblk = (long)N * tiles_x * tiles_y;
+        if (nblk < (1L << 31)) {
+            hipLaunchKernelGGL(conv3x3_head2_wide_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a, tiles_x, tiles_y);
             return pwc_launch_status();
         }
     }

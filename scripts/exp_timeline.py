@@ -1,5 +1,5 @@
 """Per-launch timeline of one forward (batch 8, 448x1024): every launch bracketed by HIP events,
-printed in issue order with its label.  Run on the GPU box: python scripts/exp_timeline.py"""
+printed in issue order with its label.  Run on the GPU box: python scripts/exp_timeline.py [batch] [dc]"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,8 +7,9 @@ sys.path.insert(0, ROOT)
 import pwcnet_amd
 from pwcnet_amd import modules as M, weights as W
 
-net = pwcnet_amd.PWCDCNet(use_plans=False)
-net.load_weights(W.init_weights(W.conv_specs(use_dc=False), seed=0))
+DC = len(sys.argv) > 2 and sys.argv[2] == "dc"
+net = pwcnet_amd.PWCDCNet(use_plans=False, use_dc=DC)
+net.load_weights(W.init_weights(W.conv_specs(use_dc=DC), seed=0))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 im0 = torch.rand((B, 448, 1024, 3), device="cuda"); im1 = torch.rand((B, 448, 1024, 3), device="cuda")
 for _ in range(3):

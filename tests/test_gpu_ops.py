@@ -321,6 +321,19 @@ def test_conv_flow_head_tiled_kernel(pa, N, H, W, res):
     close(run_conv_direct(x, k, b, 1, 1, 0.1), orc.conv3x3(x, k, b, 1, 1, 0.1))
 
 
+@pytest.mark.parametrize("N,H,W,cin,res", [(2, 7, 16, 724, False), (1, 30, 45, 100, True), (1, 64, 96, 1384, True),
+                                           (2, 9, 70, 64, False), (1, 17, 33, 92, True)])
+def test_conv_flow_head_wide_kernel(pa, N, H, W, cin, res):
+    """Cin >= 64 -> 2 heads (the dense-connection estimators' flow heads: Cin = 725 ... 3169 logical channels): tiles with
+    a loop over 32-channel chunks, ragged tiles and a last chunk of fewer than 32 channels."""
+    x = rnd((N, H, W, cin), 121)
+    k = rnd((3, 3, cin, 2), 122) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((2,), 123) * 0.1
+    r = rnd((N, H, W, 2), 124) if res else None
+    close(run_conv_direct(x, k, b, 1, 1, None, residual=r), orc.conv3x3(x, k, b, 1, 1, None, residual=r))
+    close(run_conv_direct(x, k, b, 1, 1, 0.1), orc.conv3x3(x, k, b, 1, 1, 0.1))
+
+
 def test_conv_direct_equals_mfma(pa):
     x = rnd((1, 21, 30, 64), 21)
     k = rnd((3, 3, 64, 32), 22) * 0.05
