@@ -405,6 +405,7 @@ static bool wgrad_lds_plan(int N, int H, int W, int Cin_phys, int Cout, int stri
     const int ci_tiles = (Cin_phys + tci - 1) / tci, co_tiles = (Cout + tco - 1) / tco;
     // one workgroup per CU, and the channel tiles of a chunk on ONE XCD (32 CUs): chunks per XCD = 32 / tile pairs
     long ks = 8 * (32 / (ci_tiles * co_tiles));
+    if (ks < 8) ks = 8;                                                 // many channel tiles: one chunk per XCD, several rounds
     if (ks > ntiles / 3) ks = ntiles / 3 / 8 * 8;                       // at least 3 tiles per workgroup
     if (ks < 8 || ks * ci_tiles * co_tiles < 128 || ntiles >= (1L << 30)) return false;
     if ((long)H * W * (Cin_phys > Cout ? Cin_phys : Cout) >= (1L << 28)) return false;   // 32-bit byte offsets per image
@@ -487,8 +488,18 @@ extern "C" size_t pwc_conv3x3_wgrad_workspace_floats(int N, int H, int W, int Ci
     int va, vb, ks;
     long chunk;
     wgrad_plan(N, (H + stride - 1) / stride, (W + stride - 1) / stride, Cin_phys, Cout, &va, &vb, &ks, &chunk);
-    // (the LDS-staged plan depends on the dilation, which this query does not take: its k-split is at most 256)
-    if (stride == 1 && Cin_phys >= 16 && Cout >= 16 && ks < 256) ks = 256;
+    // the LDS-staged plan's k-split depends on the dilation (through the tile count), which this query does not take:
+    // bound it by its largest value for these channel counts (the smallest channel tiles give the most chunks)
+    if (stride == 1 && Cin_phys >= 16 && Cout >= 16) {
+        long bound = 8;
+        for (int c = 0; c < (int)(sizeof(WL_CFGS) / sizeof(WL_CFGS[0])); ++c) {
+            const int tci = 16 * WL_CFGS[c].v * WL_CFGS[c].nci, tco = 16 * WL_CFGS[c].v * WL_CFGS[c].nco;
+            const long pairs = (long)((Cin_phys + tci - 1) / tci) * ((Cout + tco - 1) / tco);
+            const long k = 8 * (32 / pairs) < 8 ? 8 : 8 * (32 / pairs);
+            if (k > bound) bound = k;
+        }
+        if (ks < bound) ks = (int)bound;
+    }
     return (size_t)ks * 9 * Cin_phys * Cout;
 }
 

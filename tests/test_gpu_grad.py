@@ -153,7 +153,7 @@ def test_conv_wgrad_and_dgrad(go, stride, dil, H, W, cin, cout):
 
 @pytest.mark.parametrize("N,dil,H,W,cin,cout", [
     (2, 1, 64, 128, 128, 128), (2, 4, 64, 128, 96, 64), (4, 1, 50, 70, 40, 36), (1, 16, 112, 256, 96, 64),
-    (2, 2, 33, 47, 64, 100), (3, 1, 28, 64, 160, 32), (8, 8, 24, 20, 32, 32), (2, 1, 96, 160, 16, 16), (1, 1, 130, 77, 16, 16)])
+    (2, 2, 33, 47, 64, 100), (3, 1, 28, 64, 160, 32), (8, 8, 24, 20, 32, 32), (2, 1, 96, 160, 16, 16), (1, 1, 130, 77, 16, 16), (1, 1, 32, 64, 2112, 64)])
 def test_conv_wgrad_lds_staged_kernel(go, N, dil, H, W, cin, cout):
     """Shapes the LDS-staged weight-gradient kernel takes (stride 1, >= 32 channels, enough 64-pixel tiles): full and
     ragged tiles, every tile shape (64x1 ... 8x8), dilation sub-lattices that do not divide the image."""
