@@ -162,6 +162,17 @@ int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packed_u, const 
                          float* y, int y_cs, int N, int H, int W, int Cin_phys, int Cout,
                          int dilation, int apply_act, float slope, pwc_stream_t stream);
 long pwc_conv3x3_wino_workgroups(int N, int H, int W, int Cout, int dilation);
+/* The same convolution with the input-channel stages dealt to `csplit` workgroups per tile (launches that would leave
+ * most of the GPU's workgroup slots empty: the 14x32 / 28x64 pyramid levels).  Partial outputs go to `workspace`
+ * (pwc_conv3x3_wino_split_workspace_floats floats, 16-byte aligned) and are summed in a fixed order, with the bias and the
+ * activation, by a second kernel: deterministic, within fp32 rounding of pwc_conv3x3_wino_f32.
+ * pwc_conv3x3_wino_split_plan gives the csplit to use for a shape (1 = do not split; then no workspace is needed). */
+int pwc_conv3x3_wino_split_plan(int N, int H, int W, int Cin_phys, int Cout, int dilation);
+size_t pwc_conv3x3_wino_split_workspace_floats(int N, int H, int W, int Cout, int csplit);
+int pwc_conv3x3_wino_split_f32(const float* x, int x_cs, const float* packed_u, const float* bias,
+                               float* y, int y_cs, int N, int H, int W, int Cin_phys, int Cout,
+                               int dilation, int apply_act, float slope, int csplit, float* workspace,
+                               size_t workspace_floats, pwc_stream_t stream);
 
 /* Same convolution straight from the HWIO variable, any Cin/Cout, plus the optional
  * residual add of modules.py:275-277 (`flows += flows_up_prev`) and modules.py:326

@@ -43,6 +43,9 @@ SIGNATURES = {
     "pwc_conv3x3_wino_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pwc_conv3x3_wino_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_conv3x3_wino_workgroups": (_l, [_i, _i, _i, _i, _i]),
+    "pwc_conv3x3_wino_split_plan": (_i, [_i, _i, _i, _i, _i, _i]),
+    "pwc_conv3x3_wino_split_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),
+    "pwc_conv3x3_wino_split_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "pwc_conv3x3_direct_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_resize_bilinear_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_copy_channels_f32": (_i, [_vp, _i, _vp, _i, _l, _i, _vp]),

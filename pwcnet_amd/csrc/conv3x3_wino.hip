@@ -49,7 +49,9 @@ struct WinoArgs {
     int tiles_x, tiles_y, ncb;   // 16x16-pixel blocks per (sub-)image, cout blocks of 32
     int y_vec4;
     int dil;                     // dilation d: the conv splits into d*d ordinary convs on the pixel sub-lattices
-    int ntiles;                  // (pixel block, cout block) tiles of the launch (= gridDim.x unless PERSIST)
+    int ntiles;                  // (pixel block, cout block[, channel split]) tiles of the launch (= gridDim.x unless PERSIST)
+    int csplit;                  // > 1: the input channel stages are split over `csplit` workgroups per tile; each writes its
+    long slab;                   //      raw partial outputs (no bias, no activation) to y + z * slab (floats), see wino_split
 };
 
 __device__ __forceinline__ int wswz(int row) { return (4 - ((row >> 2) & 3)) & 3; }   // weight rows
@@ -150,11 +152,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
     // (SGPR) -- no vector instruction per fetch -- and the buffer range check gives the zeros of
     // the SAME padding: out-of-image lanes carry the offset WN_OOB.
     int n, n0, y0, x0, ry_g[2], rx_g[2];
+    int zsplit = 0, c_begin = 0, c_end = nc16;     // this workgroup's share of the channel stages
     __amdgpu_buffer_rsrc_t xrsrc;
     unsigned p_voff[PPW];
     unsigned u_voff;
     auto setup = [&](int tile) {
-        const int lb = pwc_xcd_remap(tile, a.ntiles);
+        int lb = pwc_xcd_remap(tile, a.ntiles);
+        zsplit = lb % a.csplit;                    // (csplit = 1: 0)
+        lb /= a.csplit;
+        {
+            const int base = nc16 / a.csplit, rem = nc16 - base * a.csplit;
+            c_begin = zsplit * base + min(zsplit, rem);
+            c_end = c_begin + base + (zsplit < rem ? 1 : 0);
+        }
         const int cb = lb % a.ncb;
         int rest = lb / a.ncb;
         const int bx = rest % a.tiles_x;
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
     // one 16-channel stage; FIRST: the accumulators start from the MFMA's zero C operand
     auto stage = [&](auto first, int c16) {
         constexpr bool FIRST = decltype(first)::value;
-        const bool has_next = c16 + 1 < nc16;
+        const bool has_next = c16 + 1 < c_end;
         if (PIPE) {
             WAIT_VM(UH);                             // patch(c) landed (weights A(c) may be in flight)
             __syncthreads();                         // ... for every wave; positions 8-15 of c-1 fully read
@@ -310,13 +320,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
         mfma_half(1);
         if (ABL & 8) __builtin_amdgcn_s_setprio(0);
     };
-    if (PIPE) { issue_patch(0); issue_u(0, 0); }
+    if (PIPE) { issue_patch(c_begin); issue_u(c_begin, 0); }
     for (;;) {
-    stage(WinoBool<true>{}, 0);
-    for (int c16 = 1; c16 < nc16; ++c16) stage(WinoBool<false>{}, c16);
+    stage(WinoBool<true>{}, c_begin);
+    for (int c16 = c_begin + 1; c16 < c_end; ++c16) stage(WinoBool<false>{}, c16);
 
     // the tile's output coordinates, before setup() moves on to the next tile
-    const int on = n, on0 = n0, oy0 = y0, ox0 = x0;
+    const int on = n, on0 = n0, oy0 = y0, ox0 = x0, oz = zsplit;
     const int ory[2] = {ry_g[0], ry_g[1]}, orx[2] = {rx_g[0], rx_g[1]};
     const int next = tile + (int)gridDim.x;
     const bool more = PERSIST && next < a.ntiles;
@@ -324,15 +334,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
         // all waves are past the last stage's patch and positions-0-7 reads (its barriers): those two
         // LDS regions take the next tile's first stage while this tile's outputs are transformed and stored
         setup(next);
-        issue_patch(0);
-        issue_u(0, 0);
+        issue_patch(c_begin);
+        issue_u(c_begin, 0);
     }
 
     // ---- output transform  Y = A^T M A  (A^T = [1 1 1 0; 0 1 -1 -1]), bias, leaky-relu; stores go
     // through a buffer resource of image n so that pixels beyond the image edge are dropped by the
     // range check (no divergent branches)
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.y + (size_t)on * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
+        (void*)(a.y + (size_t)oz * a.slab + (size_t)on * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
     const int og = SPLIT ? tr >> 2 : 0, otr = SPLIT ? tr & 3 : tr;
     const int py0 = ory[og] + d * (oy0 + 2 * otr), px0 = orx[og] + d * (ox0 + 2 * tc);   // real coordinates of output (0,0)
     unsigned y_voff[2][2];
@@ -353,7 +363,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) 
             s[0][j] = acc[0 * 4 + j][nt] + acc[1 * 4 + j][nt] + acc[2 * 4 + j][nt];
             s[1][j] = WSUB(WSUB(acc[1 * 4 + j][nt], acc[2 * 4 + j][nt]), acc[3 * 4 + j][nt]);
         }
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + co);
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};            // (channel split: the reduce kernel adds the bias)
+        if (a.csplit == 1) b4 = *reinterpret_cast<const f32x4*>(a.bias + co);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -468,9 +479,76 @@ extern "C" long pwc_conv3x3_wino_workgroups(int N, int H, int W, int Cout, int d
     return pix_blocks * (Cout / wino_bn(pix_blocks, Cout));
 }
 
+// sum of the channel-split partial outputs (fixed order) + bias + leaky-relu -> y
+__global__ __launch_bounds__(256) void conv3x3_wino_split_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                                        float* __restrict__ y, int y_cs, int y_vec4, long M,
+                                                                        int Cout, int Cout_pad, int nsplit, int apply_act,
+                                                                        float slope) {
+    const int c4n = Cout >> 2;
+    const long total = M * c4n;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c4 = (int)(idx % c4n);
+        const long pix = idx / c4n;
+        f32x4 v = *reinterpret_cast<const f32x4*>(bias + c4 * 4);
+        for (int z = 0; z < nsplit; ++z) v += *reinterpret_cast<const f32x4*>(ws + ((size_t)z * M + pix) * Cout_pad + c4 * 4);
+        if (apply_act) {
+            v[0] = pwc_lrelu(v[0], slope); v[1] = pwc_lrelu(v[1], slope);
+            v[2] = pwc_lrelu(v[2], slope); v[3] = pwc_lrelu(v[3], slope);
+        }
+        float* dst = y + (size_t)pix * y_cs + c4 * 4;
+        if (y_vec4) *reinterpret_cast<f32x4*>(dst) = v;
+        else { dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
+    }
+}
+
+static int wino_run(const float* x, int x_cs, const float* packed_u, const float* bias, float* y, int y_cs, int N, int H,
+                    int W, int Cin_phys, int Cout, int dilation, int apply_act, float slope, int csplit, float* workspace,
+                    size_t workspace_floats, pwc_stream_t stream);
+
+// Channel split for launches that leave most of the 512 workgroup slots (256 CUs x 2) empty -- the 14 x 32 and
+// 28 x 64 pyramid levels: 32 ... 128 workgroups that each walk 6 ... 16 channel stages whose fetch latency nothing
+// hides.  With csplit > 1 the stages are dealt to csplit workgroups per tile, each writes its raw partial outputs to a
+// slab of the caller's workspace, and a reduce kernel adds the slabs in a fixed order, the bias and the activation.
+// pwc_conv3x3_wino_split_plan returns the csplit pwc_conv3x3_wino_split_f32 should be given (1: no split).
+extern "C" int pwc_conv3x3_wino_split_plan(int N, int H, int W, int Cin_phys, int Cout, int dilation) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin_phys < 16 || Cout <= 0 || dilation < 1 || (Cin_phys % 16) || (Cout % 16)) return 1;
+    const long wgs = pwc_conv3x3_wino_workgroups(N, H, W, Cout, dilation);
+    const int nc16 = Cin_phys / 16;
+    // measured (batch 8, levels 14x32 / 28x64): the split pays from a quarter-filled GPU down and from 6 stages up --
+    // 33 -> 21 us for 128 workgroups x 16 stages; at 256 workgroups x 8 stages the reduce launch costs more than it saves
+    if (wgs <= 0 || wgs > 128 || nc16 < 6) return 1;
+    long s = 512 / wgs;
+    if (s > 4) s = 4;
+    if (s > nc16 / 2) s = nc16 / 2;
+    return s < 2 ? 1 : (int)s;
+}
+
+extern "C" size_t pwc_conv3x3_wino_split_workspace_floats(int N, int H, int W, int Cout, int csplit) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || csplit <= 1) return 0;
+    return (size_t)csplit * N * H * W * ((Cout + 15) & ~15);
+}
+
+extern "C" int pwc_conv3x3_wino_split_f32(const float* x, int x_cs, const float* packed_u, const float* bias, float* y,
+                                          int y_cs, int N, int H, int W, int Cin_phys, int Cout, int dilation,
+                                          int apply_act, float slope, int csplit, float* workspace,
+                                          size_t workspace_floats, pwc_stream_t stream) {
+    if (csplit < 1 || (csplit > 1 && (!workspace || !pwc_aligned16(workspace)))) return PWC_EINVAL;
+    if (csplit > 1 && (Cin_phys / 16 < csplit || workspace_floats < pwc_conv3x3_wino_split_workspace_floats(N, H, W, Cout, csplit)))
+        return PWC_EINVAL;
+    return wino_run(x, x_cs, packed_u, bias, y, y_cs, N, H, W, Cin_phys, Cout, dilation, apply_act, slope, csplit, workspace,
+                    workspace_floats, stream);
+}
+
 extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packed_u, const float* bias, float* y,
                                     int y_cs, int N, int H, int W, int Cin_phys, int Cout, int dilation,
                                     int apply_act, float slope, pwc_stream_t stream) {
+    return wino_run(x, x_cs, packed_u, bias, y, y_cs, N, H, W, Cin_phys, Cout, dilation, apply_act, slope, 1, nullptr, 0, stream);
+}
+
+static int wino_run(const float* x, int x_cs, const float* packed_u, const float* bias, float* y, int y_cs, int N, int H,
+                    int W, int Cin_phys, int Cout, int dilation, int apply_act, float slope, int csplit, float* workspace,
+                    size_t workspace_floats, pwc_stream_t stream) {
+    (void)workspace_floats;
     if (!x || !packed_u || !bias || !y) return PWC_EINVAL;
     if (N <= 0 || H <= 0 || W <= 0 || Cin_phys <= 0 || Cout <= 0 || dilation < 1) return PWC_EINVAL;
     if (Cin_phys % 16 || Cout % 16) return PWC_EUNSUPPORTED;
@@ -479,18 +557,27 @@ extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packe
     // per-image slabs are addressed with 32-bit byte offsets through buffer resources
     if ((long)H * W * x_cs * 4 >= (long)WN_OOB || (long)H * W * y_cs * 4 >= (long)WN_OOB) return PWC_ERANGE;
     if ((long)16 * Cin_phys * ((Cout + 15) & ~15) * 4 >= (long)WN_OOB) return PWC_ERANGE;
+    const int Cout_pad = (Cout + 15) & ~15;
+    const long M = (long)N * H * W;
+    if (csplit > 1 && (long)H * W * Cout_pad * 4 >= (long)WN_OOB) return PWC_ERANGE;
     WinoArgs a;
-    a.x = x; a.up = packed_u; a.bias = bias; a.y = y; a.x_cs = x_cs; a.y_cs = y_cs;
+    a.x = x; a.up = packed_u; a.bias = bias; a.x_cs = x_cs;
     a.N = N; a.H = H; a.W = W; a.Cin_phys = Cin_phys; a.Cout = Cout;
-    a.apply_act = apply_act; a.slope = slope;
+    a.slope = slope;
     a.dil = dilation;
+    a.csplit = csplit;
+    if (csplit > 1) {            // partial outputs: dense [z][pixel][Cout_pad] slabs, no bias / activation
+        a.y = workspace; a.y_cs = Cout_pad; a.apply_act = 0; a.slab = M * Cout_pad;
+    } else {
+        a.y = y; a.y_cs = y_cs; a.apply_act = apply_act; a.slab = 0;
+    }
     const int geo = wino_geo(H, W, dilation);
     long pix_blocks;
     wino_grid(N, H, W, dilation, geo, &a.tiles_x, &a.tiles_y, &pix_blocks);
     const int bn = wino_bn(pix_blocks, Cout);
     a.ncb = Cout / bn;
-    a.y_vec4 = ((y_cs & 3) == 0 && pwc_aligned16(y)) ? 1 : 0;
-    const long nblk = pix_blocks * a.ncb;
+    a.y_vec4 = csplit > 1 ? 1 : (((y_cs & 3) == 0 && pwc_aligned16(y)) ? 1 : 0);
+    const long nblk = pix_blocks * a.ncb * csplit;
     if (nblk >= (1L << 31)) return PWC_ERANGE;
     a.ntiles = (int)nblk;
     // measured (scripts/exp_wino.hip): one LDS stage fetched in three pipelined parts with 2 co-resident
@@ -514,12 +601,19 @@ extern "C" int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packe
     // stage is requested before the current tile's output transform and stores -- pays (64 accumulator registers,
     // no spill; with 32 couts it spills and loses, see the kernel comment).
     const char* pe = getenv("PWC_WINO_PERSIST");
-    const bool persist = (pe ? atoi(pe) != 0 : true) && bn == 16 && Cin_phys <= 32 && nblk > 1024;
+    const bool persist = (pe ? atoi(pe) != 0 : true) && bn == 16 && Cin_phys <= 32 && nblk > 1024 && csplit == 1;
     if (persist && geo == 0) { WINO_LAUNCH_P(1, 0, 1); return pwc_launch_status(); }
     if (persist && geo == 2) { WINO_LAUNCH_P(1, 2, 1); return pwc_launch_status(); }
     if (bn == 32) { if (geo == 1) WINO_LAUNCH(2, 1); else if (geo == 2) WINO_LAUNCH(2, 2); else WINO_LAUNCH(2, 0); }
     else          { if (geo == 1) WINO_LAUNCH(1, 1); else if (geo == 2) WINO_LAUNCH(1, 2); else WINO_LAUNCH(1, 0); }
 #undef WINO_LAUNCH
 #undef WINO_LAUNCH_P
+    if (csplit > 1) {
+        long blocks = (M * (Cout >> 2) + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(conv3x3_wino_split_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)workspace, bias, y, y_cs, ((y_cs & 3) == 0 && pwc_aligned16(y)) ? 1 : 0, M, Cout,
+                           Cout_pad, csplit, apply_act, slope);
+    }
     return pwc_launch_status();
 }

@@ -256,9 +256,17 @@ class _ConvRunner:
                                                        cin, x.C, cout, _p(packed.data_ptr()), s), "conv3x3 wino pack")
                 cache[key] = packed
             _keep(packed, y_t)
-            _launch(L.pwc_conv3x3_wino_f32,
+            # launches that would leave most workgroup slots empty deal their channel stages to several workgroups
+            csplit = L.pwc_conv3x3_wino_split_plan(x.N, x.H, x.W, x.C, cout, dilation)
+            if csplit > 1:
+                ws = _workspace(kern.value.device, L.pwc_conv3x3_wino_split_workspace_floats(x.N, x.H, x.W, cout, csplit))
+                _keep(ws)
+                fn, extra = L.pwc_conv3x3_wino_split_f32, (csplit, _p(ws.data_ptr()), ws.numel(), s)
+            else:
+                fn, extra = L.pwc_conv3x3_wino_f32, (s,)
+            _launch(fn,
                     (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
-                     x.N, x.H, x.W, x.C, cout, dilation, act, sl, s),
+                     x.N, x.H, x.W, x.C, cout, dilation, act, sl) + extra,
                     f"conv3x3_wino {name}", "conv3x3_wino_kernel",
                     2.0 * x.N * Ho * Wo * 9 * cin * cout, 4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout),
                     # executed: 16 multiplies per 2x2 output tile, per physical input channel

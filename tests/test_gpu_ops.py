@@ -173,6 +173,46 @@ def test_conv_winograd_dilated_vs_oracle(pa, N, H, W, cin, cout, dil):
     close(run_conv_wino(x, k, b, 0.1, dil=dil), orc.conv3x3(x, k, b, 1, dil, 0.1), rel=2e-5)
 
 
+@pytest.mark.parametrize("N,H,W,cin,cout,dil,csplit", [
+    (2, 14, 32, 256, 128, 1, 4), (1, 28, 64, 224, 96, 1, 2), (2, 14, 32, 112, 48, 1, 3), (1, 28, 64, 64, 32, 1, 2),
+    (1, 20, 36, 128, 64, 2, 4), (8, 14, 32, 128, 128, 1, 0), (1, 16, 16, 80, 16, 1, 5)])
+def test_conv_winograd_channel_split(pa, N, H, W, cin, cout, dil, csplit):
+    """The input-channel stages dealt to csplit workgroups per tile (under-filled launches): partial slabs + the
+    fixed-order reduce with bias and activation; uneven stage counts (7 stages over 3, 5 over 5), strided and
+    unaligned outputs, csplit 0 = whatever pwc_conv3x3_wino_split_plan says for the shape."""
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    x = rnd((N, H, W, cin), 171)
+    k = rnd((3, 3, cin, cout), 172) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 173) * 0.1
+    if csplit == 0:
+        csplit = L.pwc_conv3x3_wino_split_plan(N, H, W, cin, cout, dil)
+        assert csplit > 1, "this shape is meant to be split by the planner"
+    xg, kg, bg = gpu(x), gpu(k), gpu(b)
+    packed = torch.empty(L.pwc_conv3x3_wino_packed_floats(cin, cout), device="cuda")
+    _lib.check(L.pwc_conv3x3_wino_pack_f32(_p(kg), None, cin, cin, cout, _p(packed), None))
+    ws = torch.full((L.pwc_conv3x3_wino_split_workspace_floats(N, H, W, cout, csplit) + 8,), float("nan"), device="cuda")
+    for y_cs, slope in ((cout, 0.1), (cout + 3, None)):
+        y = torch.full((N, H, W, y_cs), -7.0, device="cuda")
+        _lib.check(L.pwc_conv3x3_wino_split_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), y_cs, N, H, W, cin, cout, dil,
+                                                0 if slope is None else 1, 0.0 if slope is None else slope, csplit,
+                                                _p(ws), ws.numel(), None))
+        torch.cuda.synchronize()
+        close(y[..., :cout], orc.conv3x3(x, k, b, 1, dil, slope), rel=2e-5)
+        if y_cs > cout:
+            assert float(y[..., cout:].min()) == -7.0
+        again = torch.full((N, H, W, y_cs), -7.0, device="cuda")
+        _lib.check(L.pwc_conv3x3_wino_split_f32(_p(xg), cin, _p(packed), _p(bg), _p(again), y_cs, N, H, W, cin, cout, dil,
+                                                0 if slope is None else 1, 0.0 if slope is None else slope, csplit,
+                                                _p(ws), ws.numel(), None))
+        assert torch.equal(again, y)
+    # a workspace that is too small, or more parts than stages, is refused
+    assert L.pwc_conv3x3_wino_split_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), y_cs, N, H, W, cin, cout, dil, 0, 0.0,
+                                        csplit, _p(ws), 16, None) != 0
+    assert L.pwc_conv3x3_wino_split_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), y_cs, N, H, W, cin, cout, dil, 0, 0.0,
+                                        cin // 16 + 1, _p(ws), ws.numel(), None) != 0
+
+
 def test_conv_winograd_unaligned_output_stride_and_slopes(pa):
     """channel stride not a multiple of 4 (scalar stores through the buffer resource); slopes > 1
     and < 0 (tf.nn.leaky_relu is max(v, slope*v) whatever the slope)"""
