@@ -208,6 +208,8 @@ constexpr int HT_R = 8, HT_C = 32, HT_PW = HT_C + 2, HT_NP = (HT_R + 2) * HT_PW,
 
 __global__ __launch_bounds__(256) void conv3x3_head2_tile_kernel(const DirectArgs a, int tiles_x, int tiles_y) {
     __shared__ __attribute__((aligned(16))) float patch[8 * HT_PLANE];
+    __shared__ __attribute__((aligned(16))) float wsm[9 * 64];   // [tap][32 ci][2 co]: read as broadcasts (a chain of 72
+                                                                // scalar loads cost more than the arithmetic)
     const int t = threadIdx.x;
     int blk = blockIdx.x;
     const int bx = blk % tiles_x; blk /= tiles_x;
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(256) void conv3x3_head2_tile_kernel(const DirectArg
     const int n = blk / tiles_y;
     const int y0 = by * HT_R, x0 = bx * HT_C;
     const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs;
+    for (int e = t; e < 9 * 64; e += 256) wsm[e] = a.w[e];
     for (int e = t; e < HT_NP * 8; e += 256) {
         const int p = e >> 3, q = e & 7;
         const int py = p / HT_PW, px = p - py * HT_PW;
@@ -232,15 +235,15 @@ __global__ __launch_bounds__(256) void conv3x3_head2_tile_kernel(const DirectArg
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) {
             const float* pp = patch + ((r + ty) * HT_PW + c + tx) * 4;
-            const float* wt = a.w + (ty * 3 + tx) * 64;                  // [32 ci][2 co] of this tap: wave-uniform
+            const float* wt = wsm + (ty * 3 + tx) * 64;                  // [32 ci][2 co] of this tap
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(pp + q * HT_PLANE);
-                const float* w = wt + q * 8;
-                s0a = fmaf(v[0], w[0], s0a); s1a = fmaf(v[0], w[1], s1a);
-                s0b = fmaf(v[1], w[2], s0b); s1b = fmaf(v[1], w[3], s1b);
-                s0a = fmaf(v[2], w[4], s0a); s1a = fmaf(v[2], w[5], s1a);
-                s0b = fmaf(v[3], w[6], s0b); s1b = fmaf(v[3], w[7], s1b);
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(wt + q * 8), wb = *reinterpret_cast<const f32x4*>(wt + q * 8 + 4);
+                s0a = fmaf(v[0], wa[0], s0a); s1a = fmaf(v[0], wa[1], s1a);
+                s0b = fmaf(v[1], wa[2], s0b); s1b = fmaf(v[1], wa[3], s1b);
+                s0a = fmaf(v[2], wb[0], s0a); s1a = fmaf(v[2], wb[1], s1a);
+                s0b = fmaf(v[3], wb[2], s0b); s1b = fmaf(v[3], wb[3], s1b);
             }
         }
     const int oy = y0 + r, ox = x0 + c;
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(256) void conv3x3_head2_tile_kernel(const DirectArg
 // here the next chunk's patch is fetched into registers while the current one is reduced from LDS.
 __global__ __launch_bounds__(256) void conv3x3_head2_wide_kernel(const DirectArgs a, int tiles_x, int tiles_y) {
     __shared__ __attribute__((aligned(16))) float patch[8 * HT_PLANE];
+    __shared__ __attribute__((aligned(16))) float wsm[9 * 64];   // this chunk's weights [tap][32 ci][2 co] (broadcast reads)
     constexpr int NLD = (HT_NP * 8 + 255) / 256;             // b128 pieces per thread and chunk (11)
     const int t = threadIdx.x;
     int blk = blockIdx.x;
@@ -282,12 +286,20 @@ __global__ __launch_bounds__(256) void conv3x3_head2_wide_kernel(const DirectArg
         lslot[j] = e < HT_NP * 8 ? q * HT_PLANE + p * 4 : -1;
     }
     f32x4 st[NLD];
+    f32x4 wst = {0.f, 0.f, 0.f, 0.f};                        // threads 0..143: one float4 of the chunk's 9 x 64 weights
+    const int wtap = t >> 4, wq4 = t & 15;                   // tap, float4 within the tap's 64 floats (2 channels x 2 co)
     auto fetch = [&](int c0) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (goff[j] >= 0 && c0 + ((t + 256 * j) & 7) * 4 < a.Cin) v = *reinterpret_cast<const f32x4*>(xn + goff[j] + c0);
             st[j] = v;
+        }
+        if (t < 144) {
+            const float* wp = a.w + ((size_t)wtap * a.Cin + c0) * 2 + wq4 * 4;     // channels c0 + 2*wq4, +1
+            const int ch = c0 + wq4 * 2;
+            wst[0] = ch < a.Cin ? wp[0] : 0.f; wst[1] = ch < a.Cin ? wp[1] : 0.f;
+            wst[2] = ch + 1 < a.Cin ? wp[2] : 0.f; wst[3] = ch + 1 < a.Cin ? wp[3] : 0.f;
         }
     };
     const int r = t >> 5, c = t & 31;
@@ -298,6 +310,7 @@ __global__ __launch_bounds__(256) void conv3x3_head2_wide_kernel(const DirectArg
 #pragma unroll
         for (int j = 0; j < NLD; ++j)
             if (lslot[j] >= 0) *reinterpret_cast<f32x4*>(patch + lslot[j]) = st[j];
+        if (t < 144) *reinterpret_cast<f32x4*>(wsm + wtap * 64 + wq4 * 4) = wst;
         __syncthreads();
         if (c0 + 32 < a.Cin) fetch(c0 + 32);
         const int nq = min(8, (a.Cin - c0) >> 2);             // channel quads of this chunk (Cin % 4 == 0)
@@ -306,14 +319,14 @@ __global__ __launch_bounds__(256) void conv3x3_head2_wide_kernel(const DirectArg
 #pragma unroll
             for (int tx = 0; tx < 3; ++tx) {
                 const float* pp = patch + ((r + ty) * HT_PW + c + tx) * 4;
-                const float* wt = a.w + ((size_t)(ty * 3 + tx) * a.Cin + c0) * 2;      // [ci][2 co] of this tap: wave-uniform
+                const float* wt = wsm + (ty * 3 + tx) * 64;                           // [32 ci][2 co] of this tap and chunk
                 for (int q = 0; q < nq; ++q) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(pp + q * HT_PLANE);
-                    const float* w = wt + q * 8;
-                    s0a = fmaf(v[0], w[0], s0a); s1a = fmaf(v[0], w[1], s1a);
-                    s0b = fmaf(v[1], w[2], s0b); s1b = fmaf(v[1], w[3], s1b);
-                    s0a = fmaf(v[2], w[4], s0a); s1a = fmaf(v[2], w[5], s1a);
-                    s0b = fmaf(v[3], w[6], s0b); s1b = fmaf(v[3], w[7], s1b);
+                    const f32x4 wa = *reinterpret_cast<const f32x4*>(wt + q * 8), wb = *reinterpret_cast<const f32x4*>(wt + q * 8 + 4);
+                    s0a = fmaf(v[0], wa[0], s0a); s1a = fmaf(v[0], wa[1], s1a);
+                    s0b = fmaf(v[1], wa[2], s0b); s1b = fmaf(v[1], wa[3], s1b);
+                    s0a = fmaf(v[2], wb[0], s0a); s1a = fmaf(v[2], wb[1], s1a);
+                    s0b = fmaf(v[3], wb[2], s0b); s1b = fmaf(v[3], wb[3], s1b);
                 }
             }
     }
