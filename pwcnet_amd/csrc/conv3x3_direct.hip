@@ -8,6 +8,7 @@
 // addresses are wave-uniform (scalar loads).  HBM-bound layers: the 9-tap re-reads of
 // x are served by L1/L2.
 #include "pwc_common.h"
+#include <cstdlib>
 
 struct DirectArgs {
     const float* x;
@@ -206,54 +207,78 @@ __global__ __launch_bounds__(256) void conv3x3_head2_c32_kernel(const DirectArgs
 // weights of a (tap, quad) are wave-uniform (scalar loads).
 constexpr int HT_R = 8, HT_C = 32, HT_PW = HT_C + 2, HT_NP = (HT_R + 2) * HT_PW, HT_PLANE = HT_NP * 4 + 4;
 
-__global__ __launch_bounds__(256) void conv3x3_head2_tile_kernel(const DirectArgs a, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) void conv3x3_head2_tile_kernel(const DirectArgs a, int tiles_x, int tiles_y, int ntiles) {
     __shared__ __attribute__((aligned(16))) float patch[8 * HT_PLANE];
-    __shared__ __attribute__((aligned(16))) float wsm[9 * 64];   // [tap][32 ci][2 co]: read as broadcasts (a chain of 72
-                                                                // scalar loads cost more than the arithmetic)
+    __shared__ __attribute__((aligned(16))) float wsm[9 * 64];   // [tap][32 ci][2 co]: read as broadcasts
+    constexpr int NLD = (HT_NP * 8 + 255) / 256;             // b128 pieces per thread and tile (11)
     const int t = threadIdx.x;
-    int blk = blockIdx.x;
-    const int bx = blk % tiles_x; blk /= tiles_x;
-    const int by = blk % tiles_y;
-    const int n = blk / tiles_y;
-    const int y0 = by * HT_R, x0 = bx * HT_C;
-    const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs;
     for (int e = t; e < 9 * 64; e += 256) wsm[e] = a.w[e];
-    for (int e = t; e < HT_NP * 8; e += 256) {
+    // this thread's pieces (same for every tile): patch pixel (py, px), channel quad, LDS slot
+    int ppy[NLD], ppx[NLD], lslot[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int e = t + 256 * j;
         const int p = e >> 3, q = e & 7;
-        const int py = p / HT_PW, px = p - py * HT_PW;
-        const int y = y0 - 1 + py, x = x0 - 1 + px;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
-            v = *reinterpret_cast<const f32x4*>(xn + ((size_t)y * a.W + x) * a.x_cs + q * 4);
-        *reinterpret_cast<f32x4*>(patch + q * HT_PLANE + p * 4) = v;
+        ppy[j] = p / HT_PW;
+        ppx[j] = p - ppy[j] * HT_PW;
+        lslot[j] = e < HT_NP * 8 ? q * HT_PLANE + p * 4 : -1;
     }
-    __syncthreads();
-    const int r = t >> 5, c = t & 31;
-    float s0a = 0.f, s0b = 0.f, s1a = 0.f, s1b = 0.f;
+    // persistent: the workgroup walks tiles blockIdx.x, + gridDim.x, ...; the next tile's patch is fetched into
+    // registers while the current one is reduced from LDS (a workgroup with a single tile spends most of its life
+    // waiting for that one fetch)
+    f32x4 st[NLD];
+    auto fetch = [&](int tile) {
+        const int bx = tile % tiles_x;
+        const int by = (tile / tiles_x) % tiles_y;
+        const int n = tile / (tiles_x * tiles_y);
+        const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs + (t & 7) * 4;
 #pragma unroll
-    for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-        for (int tx = 0; tx < 3; ++tx) {
-            const float* pp = patch + ((r + ty) * HT_PW + c + tx) * 4;
-            const float* wt = wsm + (ty * 3 + tx) * 64;                  // [32 ci][2 co] of this tap
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(pp + q * HT_PLANE);
-                const f32x4 wa = *reinterpret_cast<const f32x4*>(wt + q * 8), wb = *reinterpret_cast<const f32x4*>(wt + q * 8 + 4);
-                s0a = fmaf(v[0], wa[0], s0a); s1a = fmaf(v[0], wa[1], s1a);
-                s0b = fmaf(v[1], wa[2], s0b); s1b = fmaf(v[1], wa[3], s1b);
-                s0a = fmaf(v[2], wb[0], s0a); s1a = fmaf(v[2], wb[1], s1a);
-                s0b = fmaf(v[3], wb[2], s0b); s1b = fmaf(v[3], wb[3], s1b);
-            }
+        for (int j = 0; j < NLD; ++j) {
+            const int y = by * HT_R - 1 + ppy[j], x = bx * HT_C - 1 + ppx[j];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (lslot[j] >= 0 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+                v = *reinterpret_cast<const f32x4*>(xn + ((size_t)y * a.W + x) * a.x_cs);
+            st[j] = v;
         }
-    const int oy = y0 + r, ox = x0 + c;
-    if (oy < a.H && ox < a.W) {
-        const size_t m = ((size_t)n * a.H + oy) * a.W + ox;
-        float v0 = (s0a + s0b) + a.bias[0], v1 = (s1a + s1b) + a.bias[1];
-        if (a.apply_act) { v0 = pwc_lrelu(v0, a.slope); v1 = pwc_lrelu(v1, a.slope); }
-        if (a.res) { v0 += a.res[m * a.res_cs]; v1 += a.res[m * a.res_cs + 1]; }
-        a.y[m * a.y_cs] = v0;
-        a.y[m * a.y_cs + 1] = v1;
+    };
+    const int r = t >> 5, c = t & 31;
+    const float b0 = a.bias[0], b1 = a.bias[1];
+    int tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                      // the previous tile has been read (first pass: wsm written)
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+            if (lslot[j] >= 0) *reinterpret_cast<f32x4*>(patch + lslot[j]) = st[j];
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+        float s0a = 0.f, s0b = 0.f, s1a = 0.f, s1b = 0.f;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const float* pp = patch + ((r + ty) * HT_PW + c + tx) * 4;
+                const float* wt = wsm + (ty * 3 + tx) * 64;                  // [32 ci][2 co] of this tap
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(pp + q * HT_PLANE);
+                    const f32x4 wa = *reinterpret_cast<const f32x4*>(wt + q * 8), wb = *reinterpret_cast<const f32x4*>(wt + q * 8 + 4);
+                    s0a = fmaf(v[0], wa[0], s0a); s1a = fmaf(v[0], wa[1], s1a);
+                    s0b = fmaf(v[1], wa[2], s0b); s1b = fmaf(v[1], wa[3], s1b);
+                    s0a = fmaf(v[2], wb[0], s0a); s1a = fmaf(v[2], wb[1], s1a);
+                    s0b = fmaf(v[3], wb[2], s0b); s1b = fmaf(v[3], wb[3], s1b);
+                }
+            }
+        const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int oy = by * HT_R + r, ox = bx * HT_C + c;
+        if (oy < a.H && ox < a.W) {
+            const size_t m = ((size_t)n * a.H + oy) * a.W + ox;
+            float v0 = (s0a + s0b) + b0, v1 = (s1a + s1b) + b1;
+            if (a.apply_act) { v0 = pwc_lrelu(v0, a.slope); v1 = pwc_lrelu(v1, a.slope); }
+            if (a.res) { v0 += a.res[m * a.res_cs]; v1 += a.res[m * a.res_cs + 1]; }
+            a.y[m * a.y_cs] = v0;
+            a.y[m * a.y_cs + 1] = v1;
+        }
     }
 }
 
@@ -371,7 +396,8 @@ extern "C" int pwc_conv3x3_direct_f32(const float* x, int x_cs, const float* w_h
         const int tiles_x = (W + HT_C - 1) / HT_C, tiles_y = (H + HT_R - 1) / HT_R;
         const long nblk = (long)N * tiles_x * tiles_y;
         if (nblk < (1L << 31)) {
-            hipLaunchKernelGGL(conv3x3_head2_tile_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a, tiles_x, tiles_y);
+            const long grid = nblk < 768 ? nblk : 768;       // 3 workgroups per CU (LDS), each walks its tiles
+            hipLaunchKernelGGL(conv3x3_head2_tile_kernel, dim3((unsigned)grid), dim3(256), 0, s, a, tiles_x, tiles_y, (int)nblk);
             return pwc_launch_status();
         }
     }
