@@ -449,6 +449,10 @@ extern "C" int pwc_conv3x3_wino_pack_f32(const float* w_hwio, const int32_t* cin
 // (256 CUs x 2) empty -- measured on the 28 x 64 level (14 336 pixels): 16 is faster below ~384 workgroups
 static int wino_bn(long pix_blocks, int Cout) {
     if (Cout % 32) return 16;
+    if (const char* e = getenv("PWC_WINO_FORCE_BN")) {          // scripts/tune_wino_split.py only
+        const int v = atoi(e);
+        if (v == 16 || v == 32) return v;
+    }
     return pix_blocks * (Cout / 32) >= WINO_BN32_MIN_WG ? 32 : 16;
 }
 
@@ -512,13 +516,18 @@ static int wino_run(const float* x, int x_cs, const float* packed_u, const float
 // pwc_conv3x3_wino_split_plan returns the csplit pwc_conv3x3_wino_split_f32 should be given (1: no split).
 extern "C" int pwc_conv3x3_wino_split_plan(int N, int H, int W, int Cin_phys, int Cout, int dilation) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin_phys < 16 || Cout <= 0 || dilation < 1 || (Cin_phys % 16) || (Cout % 16)) return 1;
+    if (const char* e = getenv("PWC_WINO_FORCE_SPLIT")) {       // scripts/tune_wino_split.py only
+        const int v = atoi(e);
+        if (v >= 1 && v <= Cin_phys / 16) return v;
+    }
     const long wgs = pwc_conv3x3_wino_workgroups(N, H, W, Cout, dilation);
     const int nc16 = Cin_phys / 16;
     // measured (batch 8, levels 14x32 / 28x64): the split pays from a quarter-filled GPU down and from 6 stages up --
     // 33 -> 21 us for 128 workgroups x 16 stages; at 256 workgroups x 8 stages the reduce launch costs more than it saves
     if (wgs <= 0 || wgs > 128 || nc16 < 6) return 1;
-    long s = 512 / wgs;
-    if (s > 4) s = 4;
+    long s = 256 / wgs;                                        // fill half of the slots (scripts/tune_wino_split.py: at 128
+    if (s > 4) s = 4;                                          // workgroups 2 parts beat 4 by 1-2 us)
+    if (s < 2) s = 2;
     if (s > nc16 / 2) s = nc16 / 2;
     return s < 2 ? 1 : (int)s;
 }
