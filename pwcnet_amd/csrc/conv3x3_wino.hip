@@ -116,7 +116,7 @@ __device__ __forceinline__ float wino_minus_one() {
 // them.  Correct, but the 7 offsets of the next tile live across the epilogue push the kernel over
 // 256 VGPRs (84 B of scratch per lane) and it measures 289 us against 255 us: not used by the library.
 template <int ABL = 0, int NT = 2, int PIPE = 0, int GEO = 0, int PERSIST = 0>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a) {
+__global__ __launch_bounds__(256, NT >= 4 ? 1 : 2) void conv3x3_wino_kernel(const WinoArgs a) {
     static_assert(!PERSIST || PIPE, "the persistent loop is built on the pipelined stage");
     typedef WinoGeom<NT, GEO> Geo;
     constexpr int SPLIT = GEO == 1, WIDE = GEO == 2;

@@ -27,6 +27,7 @@ int main(int argc, char** argv) {
     for (auto& v : h) { r = r * 1664525u + 1013904223u; v = ((r >> 8) & 0xFFFF) / 65536.f - 0.5f; }
     hipMemcpy(x, h.data(), nx * 4, hipMemcpyHostToDevice); hipMemcpy(u, h.data(), nu * 4, hipMemcpyHostToDevice); hipMemset(b, 0, CO * 4);
     WinoArgs a{}; a.x = x; a.up = u; a.bias = b; a.y = y; a.x_cs = C; a.y_cs = CO; a.N = N; a.H = H; a.W = W; a.Cin_phys = C; a.Cout = CO;
+    a.csplit = 1; a.slab = 0;
     a.apply_act = 1; a.slope = 0.1f; a.tiles_x = W / 16; a.tiles_y = H / 16; a.ncb = CO / 32; a.y_vec4 = 1; a.dil = 1;
     const long nblk = (long)N * a.tiles_x * a.tiles_y * a.ncb;
     a.ntiles = (int)nblk;
@@ -47,6 +48,16 @@ int main(int argc, char** argv) {
         printf("round %d:", round);
         for (int i = 0; i < 7; ++i) { printf(" %s %.1f |", names[i], t[i]); if (t[i] < best[i]) best[i] = t[i]; }
         printf("\n");
+    }
+    {   // 64 output channels per workgroup (NT = 4): 256 accumulator registers, 1 workgroup per CU
+        WinoArgs a4 = a; a4.ncb = CO / 64;
+        const long nblk4 = (long)N * a.tiles_x * a.tiles_y * a4.ncb; a4.ntiles = (int)nblk4;
+        const size_t L4 = (size_t)WinoGeom<4>::STAGE * 4;
+        float b4 = 1e9f;
+        for (int round = 0; round < 5; ++round) { float t = run(conv3x3_wino_kernel<0, 4, 1>, a4, nblk4, L4, 10); if (t < b4) b4 = t; }
+        hipMemset(y, 0, (size_t)N * H * W * CO * 4);
+        run(conv3x3_wino_kernel<0, 4, 1>, a4, nblk4, L4, 1);
+        printf("NT=4 pipe: %.1f us (%.1f eff TF), checksum %.3f\n", b4, gf / b4 * 1e3, checksum(y, (size_t)N * H * W * CO));
     }
     hipMemset(y, 0, (size_t)N * H * W * CO * 4);
     run(conv3x3_wino_kernel<0, 2, 1, 0, 1>, a, 512, L1, 1);
