@@ -111,6 +111,15 @@ def test_cost_volume_grad(go, N, H, W, C):
     go.cost_volume_grad(V(g0), V(g1), V(gcv), V(gdcv), V(df0), V(df1))
     close(df0, a.grad)
     close(df1, b.grad)
+    # cv / dcv as 16-byte aligned slices of wider buffers (the estimator layouts): the float4 path
+    wcv = torch.zeros((N, H, W, 96), device="cuda"); wcv[..., 4:85] = gcv
+    wd = torch.zeros((N, H, W, 100), device="cuda"); wd[..., 8:89] = gdcv
+    vcv = View(wcv.data_ptr() + 16, 96, N, H, W, 81)
+    vd = View(wd.data_ptr() + 32, 100, N, H, W, 81)
+    df0b = torch.zeros((N, H, W, C), device="cuda")
+    df1b = torch.zeros((N, H, W, C), device="cuda")
+    go.cost_volume_grad(V(g0), V(g1), vcv, vd, V(df0b), V(df1b))
+    assert torch.equal(df0b, df0) and torch.equal(df1b, df1)
 
 
 def test_flow_norm_grad(go):
