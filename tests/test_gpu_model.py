@@ -402,3 +402,25 @@ def test_e2e_large_flows_vs_oracle(pa, gain, use_dc):
     print(f"gain {gain} use_dc {use_dc}: max |flow| {mag:.3f} px, max abs err {err:.3e}")
     assert np.isfinite(mag) and mag >= 2.0, mag
     assert err <= 1e-3
+
+
+def test_channel_split_launches_do_not_change_the_flows(pa, monkeypatch):
+    """The coarse estimator levels run their Winograd convs with the channel loop dealt to several workgroups
+    (pwc_conv3x3_wino_split_f32); with the split disabled the forward must give the same flows up to fp32 summation order."""
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    assert L.pwc_conv3x3_wino_split_plan(8, 14, 32, 256, 128, 1) > 1          # the 14x32 level of a batch of 8
+    assert L.pwc_conv3x3_wino_split_plan(8, 112, 256, 160, 128, 1) == 1       # full launches are left alone
+    w = util.model_weights(False, gain=1.2)
+    im0, im1 = util.smooth_images(8, 448, 1024, seed=91, shift=(2, -3))
+    net = pa.PWCDCNet()
+    net.load_weights(w)
+    final, pyr = net(gpu(im0), gpu(im1))
+    monkeypatch.setenv("PWC_WINO_FORCE_SPLIT", "1")                           # read by the library at plan time
+    ref = pa.PWCDCNet()
+    ref.load_weights(w)
+    rfinal, rpyr = ref(gpu(im0), gpu(im1))
+    monkeypatch.delenv("PWC_WINO_FORCE_SPLIT")
+    assert float((final - rfinal).abs().max()) <= 2e-5 * max(1.0, float(rfinal.abs().max()))
+    for a, b in zip(pyr, rpyr):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
