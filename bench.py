@@ -81,6 +81,9 @@ def parse(argv=None):
                     help="train: one optimisation step per bench step (pwcnet_amd.train.Trainer: forward, backward, "
                          "one RCCL all-reduce of the gradients, Adam) -- SURVEY.md 8 f4, not the headline metric")
     ap.add_argument("--loss", choices=("multiscale", "robust"), default="multiscale", help="--mode train")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="PWCDCNet(streams=K): the batch runs as K sub-batches on side HIP streams (opt-in; kernels of "
+                         "different sub-batches overlap, so the per-kernel roofline legs are switched off)")
     ap.add_argument("--persistent-outputs", action="store_true",
                     help="PWCDCNet(persistent_outputs=True): replays write into the plan's own output tensors")
     args = ap.parse_args(argv)
@@ -223,8 +226,10 @@ def main():
     # identical seeded glorot-uniform weights on every rank
     specs = W.conv_specs(use_dc=args.use_dc)
     wts = W.init_weights(specs, seed=0)
-    net = pwcnet_amd.PWCDCNet(use_dc=args.use_dc, persistent_outputs=args.persistent_outputs)
+    net = pwcnet_amd.PWCDCNet(use_dc=args.use_dc, persistent_outputs=args.persistent_outputs, streams=args.streams)
     net.load_weights(wts)
+    if args.streams > 1:
+        args.no_op_timing = True      # HIP events on the caller's stream do not bracket side-stream kernels
 
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
@@ -315,6 +320,7 @@ def main():
             "parallelism": f"dp{world}: pairs sharded across ranks, no data-path collective"
                            + ("; RCCL all-gather of per-rank stats" if used_rccl else ""),
             "outputs": "persistent (plan-owned)" if args.persistent_outputs else "fresh tensors per call",
+            "streams": args.streams,
         },
     }
 

@@ -29,7 +29,7 @@ from .weights import ChannelLayout, SCALES, conv_specs
 class PWCDCNet(object):
     def __init__(self, num_levels=6, search_range=4, warp_type="bilinear", use_dc=False,
                  output_level=4, name="pwcdcnet", seed=0, fuse_warp=False, use_plans=True, winograd=True,
-                 coarse_cv=True, persistent_outputs=False, max_plans=4):
+                 coarse_cv=True, persistent_outputs=False, max_plans=4, streams=1):
         self.num_levels = num_levels
         self.s_range = search_range
         self.warp_type = warp_type
@@ -68,6 +68,14 @@ class PWCDCNet(object):
         self._plans = collections.OrderedDict()
         self._buffers = {}     # buffer set of the forward being run (a plan's, or the eager one's)
         self._eager_buffers = collections.OrderedDict()   # use_plans=False: (shape, device, stream) -> buffers
+        # streams > 1 (opt-in): a batch divisible by `streams` is run as that many sub-batches on side HIP streams, so
+        # that the latency-bound coarse levels of one overlap the MFMA-bound layers of another (+4-5 % pairs/s at
+        # batch 8, scripts/exp_two_streams.py).  Same results and the same stream semantics for the caller (the side
+        # streams wait for the caller's stream, the caller's stream waits for them); per-kernel timings lose their
+        # meaning while kernels overlap, which is why it is not the default.
+        self.streams = max(1, int(streams))
+        self.max_plans = max(self.max_plans, self.streams)      # one plan per sub-batch stream of a shape
+        self._side_streams = {}
 
     # ------------------------------------------------------------------ variables
     @property
@@ -120,6 +128,38 @@ class PWCDCNet(object):
         """(flows_final, flows_pyramid[, pyramid_0]) as reference model.py:95-134.  The returned
         tensors are new on every call unless the model was built with persistent_outputs=True
         (then they are the launch plan's own tensors, overwritten by the next call of that shape)."""
+        k = self.streams
+        if (k > 1 and self.use_plans and not self.persistent_outputs and not with_features and _m._RECORDER is None
+                and getattr(images_0, "shape", (0,))[0] % k == 0 and images_0.shape[0] >= k):
+            return self._call_on_side_streams(images_0, images_1, k)
+        return self._call_one(images_0, images_1, with_features)
+
+    def _call_on_side_streams(self, images_0, images_1, k):
+        _, images_0 = as_view(images_0, "images_0")
+        _, images_1 = as_view(images_1, "images_1")
+        dev = images_0.device
+        N, H, W, _ = images_0.shape
+        n = N // k
+        streams = self._side_streams.get(str(dev))
+        if streams is None or len(streams) != k:
+            streams = self._side_streams[str(dev)] = [torch.cuda.Stream(device=dev) for _ in range(k)]
+        main = torch.cuda.current_stream(dev)
+        final = torch.empty((N, H, W, 2), dtype=torch.float32, device=dev)
+        pyr = [torch.empty((N, H >> (self.num_levels - l), W >> (self.num_levels - l), 2), dtype=torch.float32, device=dev)
+               for l in range(self.output_level + 1)]
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for i, st in enumerate(streams):
+            sl = slice(i * n, (i + 1) * n)
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                self._call_one(images_0[sl], images_1[sl], False, into=(final[sl], [p[sl] for p in pyr]))
+            done = torch.cuda.Event()
+            done.record(st)
+            main.wait_event(done)
+        return final, pyr
+
+    def _call_one(self, images_0, images_1, with_features=False, into=None):
         iv0, images_0 = as_view(images_0, "images_0")
         iv1, images_1 = as_view(images_1, "images_1")
         assert iv0[2:] == iv1[2:], "image batches must have equal shapes"
@@ -141,7 +181,7 @@ class PWCDCNet(object):
             if self.persistent_outputs:
                 plan.replay(patch)
                 return plan.outputs
-            outputs = self._fresh_outputs(plan, patch)
+            outputs = self._fresh_outputs(plan, patch, into)
             plan.replay(patch)
             if with_features:
                 # pyramid_0 are slices of the extractor's activations (plan-owned): copy them,
@@ -173,13 +213,23 @@ class PWCDCNet(object):
         self._plans[key] = plan
         while len(self._plans) > self.max_plans:
             self._plans.popitem(last=False)          # least recently used; its buffers go with it
+        if into is not None:                         # recording call of a sub-batch: hand the results over
+            into[0].copy_(outputs[0])
+            for dst, src in zip(into[1], outputs[1]):
+                dst.copy_(src)
+            return into
         return outputs
 
-    def _fresh_outputs(self, plan, patch):
-        """New flows_final / flows_pyramid tensors for this replay; their pointers are patched
-        into the recorded launches like the inputs'."""
+    def _fresh_outputs(self, plan, patch, into=None):
+        """New flows_final / flows_pyramid tensors for this replay (or the caller's `into` slices); their
+        pointers are patched into the recorded launches like the inputs'."""
         old = plan.outputs
-        new = [torch.empty_like(t) for t in [old[0]] + list(old[1])]
+        if into is not None:
+            new = [into[0]] + list(into[1])
+            for t, o in zip(new, [old[0]] + list(old[1])):
+                assert tuple(t.shape) == tuple(o.shape) and t.is_contiguous(), (t.shape, o.shape)
+        else:
+            new = [torch.empty_like(t) for t in [old[0]] + list(old[1])]
         for i, t in enumerate(new):
             patch[f"out{i}"] = t.data_ptr()
         return new[0], new[1:]

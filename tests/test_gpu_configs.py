@@ -213,3 +213,29 @@ def test_bench_rejects_a_world_size_that_contradicts_gpus(pa):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
+
+
+def test_sub_batches_on_side_streams_give_the_same_flows(pa):
+    """PWCDCNet(streams=2): the batch runs as two sub-batches on side HIP streams (their kernels overlap).  Same flows as
+    the single-stream model, fresh tensors on every call, correct when calls follow each other without a sync."""
+    w = util.model_weights(False, gain=1.2)
+    im0, im1 = util.smooth_images(4, 128, 192, seed=93, shift=(2, -1))
+    jm0, jm1 = util.smooth_images(4, 128, 192, seed=94, shift=(-3, 2))
+    ref = pa.PWCDCNet()
+    ref.load_weights(w)
+    net = pa.PWCDCNet(streams=2)
+    net.load_weights(w)
+    g0, g1, h0, h1 = gpu(im0), gpu(im1), gpu(jm0), gpu(jm1)
+    ra, rpa = ref(g0, g1)
+    rb, _ = ref(h0, h1)
+    for _ in range(3):                                  # recording call, then replays; back-to-back without syncs
+        a, pyr_a = net(g0, g1)
+        b, _ = net(h0, h1)
+    assert a.data_ptr() != b.data_ptr()
+    assert float((a - ra).abs().max()) <= 2e-5 * max(1.0, float(ra.abs().max()))
+    assert float((b - rb).abs().max()) <= 2e-5 * max(1.0, float(rb.abs().max()))
+    for x, y in zip(pyr_a, rpa):
+        assert x.shape == y.shape and float((x - y).abs().max()) <= 2e-5 * max(1.0, float(y.abs().max()))
+    # an odd batch falls back to the single-stream path
+    c, _ = net(g0[:3], g1[:3])
+    assert float((c - ra[:3]).abs().max()) <= 2e-5 * max(1.0, float(ra.abs().max()))
