@@ -14,8 +14,8 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
   timed region.  Pairs shard across ranks with no data-path collective (weak scaling);
   one RCCL all-gather of per-rank stats per run.  Rank 0 prints ONE JSON line.
   `--config configs3` = PWCDCNet use_dc=True batch 8; `--config configs4` = 960x1920
-  batch 8 per GPU (BASELINE.json configs[4] is that on 2 GPUs: add --gpus 2);
-  `--config configs2` = configs[1] per GPU on 8 GPUs.
+  batch 8 per GPU on 2 GPUs (BASELINE.json configs[4]; an explicit `--gpus 1` runs one
+  rank's share of it); `--config configs2` = configs[1] per GPU on 8 GPUs.
 
 Extra objects in the line:
   roofline       dominant kernel (by summed duration).  For the Winograd kernel `achieved`
@@ -57,7 +57,7 @@ CONFIGS = {
     "configs1": {},
     "configs2": {"gpus": 8},
     "configs3": {"use_dc": True},
-    "configs4": {"height": 960, "width": 1920},
+    "configs4": {"height": 960, "width": 1920, "gpus": 2},
 }
 
 
@@ -71,7 +71,8 @@ def parse(argv=None):
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--use-dc", action="store_true", help="dense-connection estimator (configs[3])")
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
-                    help="preset of BASELINE.json `configs` (overrides height/width/use-dc; configs2 also --gpus)")
+                    help="preset of BASELINE.json `configs` (overrides height/width/use-dc; configs2 / configs4 also imply "
+                         "--gpus 8 / 2 unless --gpus is given)")
     ap.add_argument("--spawn", action="store_true", help="go through torch.distributed.run even for --gpus 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget")
@@ -87,10 +88,12 @@ def parse(argv=None):
     ap.add_argument("--persistent-outputs", action="store_true",
                     help="PWCDCNet(persistent_outputs=True): replays write into the plan's own output tensors")
     args = ap.parse_args(argv)
+    raw = sys.argv[1:] if argv is None else list(argv)
+    args.gpus_given = any(a == "--gpus" or a.startswith("--gpus=") for a in raw)
     if args.config:
         for k, v in CONFIGS[args.config].items():
             if k == "gpus":
-                if args.gpus == 1:
+                if not args.gpus_given:      # an explicit --gpus always wins over the preset
                     args.gpus = v
             else:
                 setattr(args, k, v)
@@ -117,7 +120,7 @@ def spawn(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)]
     cmd += [a for a in sys.argv[1:] if a != "--spawn"]
-    if args.config == "configs2" and "--gpus" not in sys.argv[1:]:
+    if not args.gpus_given:                  # --gpus came from a --config preset: hand it to the ranks
         cmd += ["--gpus", str(args.gpus)]
     return subprocess.call(cmd, env=env)
 
@@ -132,7 +135,7 @@ def train_mode(args, dist, dev, rank, world):
     """--mode train: K optimisation steps of the training path on this rank's batch (synthetic pairs and flows,
     seeded glorot-uniform weights).  Data-parallel: every rank steps on its own pairs, gradients are summed with one
     all-reduce per step.  Same timing bracket as the inference mode."""
-    from pwcnet_amd.sharding import gather_stats
+    from pwcnet_amd.sharding import aggregate_throughput, gather_stats
     from pwcnet_amd.train import Trainer
     B, H, Wd = args.batch, args.height, args.width
     tn = Trainer(use_dc=args.use_dc, loss=args.loss, device=str(dev), dist=dist)
@@ -161,11 +164,11 @@ def train_mode(args, dist, dev, rank, world):
     elapsed = time.perf_counter() - t0
     stats = gather_stats(dict(pairs=float(B * args.steps), seconds=elapsed), dist, dev)
     if rank == 0:
-        mx = max(s["seconds"] for s in stats)
+        value, ms_per_step, _, _ = aggregate_throughput(stats, args.steps)
         print(json.dumps({
             "metric": f"training_image_pairs_per_sec_{H}x{Wd}",
-            "value": sum(s["pairs"] for s in stats) / mx, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": max(args.warmup, 1), "ms_per_step": 1e3 * mx / args.steps, "higher_is_better": True,
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": max(args.warmup, 1), "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (uniform[0,1) images, N(0, 3^2) px flows, seeded glorot-uniform weights)",
             "config": {"workload": f"training step (forward + backward + Adam), batch={B} pairs per GPU, {H}x{Wd}, "
@@ -221,7 +224,7 @@ def main():
     import pwcnet_amd
     from pwcnet_amd import weights as W
     from pwcnet_amd.profiler import OpTimer
-    from pwcnet_amd.sharding import gather_stats
+    from pwcnet_amd.sharding import aggregate_throughput, gather_stats
 
     # identical seeded glorot-uniform weights on every rank
     specs = W.conv_specs(use_dc=args.use_dc)
@@ -280,8 +283,8 @@ def main():
     del out
 
     stats = gather_stats(dict(pairs=float(B * args.steps), seconds=elapsed), dist, dev)
-    max_elapsed = max(s["seconds"] for s in stats)
-    total_pairs = sum(s["pairs"] for s in stats)
+    value, ms_per_step, total_pairs, n_ranks = aggregate_throughput(stats, args.steps)
+    assert n_ranks == world
     used_rccl = dist is not None
     if dist is not None:
         # every rank leaves the process group together, before rank 0's single-GPU legs (op-level leg, CPU baseline)
@@ -298,12 +301,12 @@ def main():
         cfg_idx = 4
     line = {
         "metric": "image_pairs_per_sec_448x1024" if (H, Wd) == (448, 1024) else f"image_pairs_per_sec_{H}x{Wd}",
-        "value": total_pairs / max_elapsed,
+        "value": value,
         "unit": "pairs/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": 1e3 * max_elapsed / args.steps,
+        "ms_per_step": ms_per_step,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

@@ -595,11 +595,10 @@ static int launch_halo(const HaloArgs& a0, hipStream_t s) {
     constexpr int KG = CIN / 16, PW = 34, PH = TH + 2;
     constexpr int PRP = (PH * PW + 15) & ~15;
     const size_t lds = ((size_t)9 * CIN * COUT + (size_t)NB * KG * PRP * 16) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PwcDevOnce attr_once;   // the attribute is per device
+    if (pwc_first_on_device(&attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<CIN, COUT, TH, NB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + TH - 1) / TH;

@@ -422,11 +422,10 @@ static bool wgrad_lds_plan(int N, int H, int W, int Cin_phys, int Cout, int stri
 template <int NCI, int NCO, int G, int V>
 static void wgrad_lds_launch(const WgLdsArgs& l, hipStream_t stream) {
     typedef WgLdsGeom<NCI, NCO, G, V> Geo;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PwcDevOnce attr_once;   // the attribute is per device
+    if (pwc_first_on_device(&attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_lds_kernel<NCI, NCO, G, V>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS_BYTES);
-        attr_set = true;
     }
     hipLaunchKernelGGL((conv3x3_wgrad_lds_kernel<NCI, NCO, G, V>), dim3((unsigned)((l.ksplit + 7) / 8 * 8 * l.ci_tiles * l.co_tiles)), dim3(512),
                        Geo::LDS_BYTES, stream, l);

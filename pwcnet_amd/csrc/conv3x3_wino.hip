@@ -594,11 +594,10 @@ static int wino_run(const float* x, int x_cs, const float* packed_u, const float
 #define WINO_LAUNCH_P(NT, GEO, PERS)                                                                        \
     do {                                                                                                    \
         const size_t lds = (size_t)WinoGeom<NT, GEO>::STAGE * sizeof(float);                                \
-        static bool attr_done = false;                                                                      \
-        if (!attr_done) {                                                                                   \
+        static PwcDevOnce attr_once;                                                                          \
+        if (pwc_first_on_device(&attr_once)) {                                                              \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<0, NT, 1, GEO, PERS>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
-            attr_done = true;                                                                               \
         }                                                                                                   \
         const long grid = (PERS && nblk > 512) ? 512 : nblk;   /* persistent: 2 workgroups per CU walk the tiles */ \
         hipLaunchKernelGGL((conv3x3_wino_kernel<0, NT, 1, GEO, PERS>), dim3((unsigned)grid), dim3(256), lds, \

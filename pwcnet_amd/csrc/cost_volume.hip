@@ -494,11 +494,10 @@ template <int R>
 static int cv_launch_dma(const CvArgs& a, hipStream_t s) {
     using G = CvPGeom<R>;
     const size_t lds = (size_t)2 * G::BUF * sizeof(float);
-    static bool attr_set = false;   // idempotent, benign if raced
-    if (!attr_set) {
+    static PwcDevOnce attr_once;   // the attribute is per device
+    if (pwc_first_on_device(&attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_volume_dma_kernel<R, 0>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const long ntiles = (long)a.tiles_x * a.tiles_y * a.N;
     // one persistent workgroup per CU; smaller LDS footprints (R < 4) may co-reside
@@ -513,11 +512,10 @@ template <int R, bool FUSED>
 static int cv_launch(const CvArgs& a, hipStream_t s) {
     using G = CvGeom<R>;
     const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;   // idempotent, benign if raced
-    if (!attr_set) {
+    static PwcDevOnce attr_once;   // the attribute is per device
+    if (pwc_first_on_device(&attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_volume_kernel<R, FUSED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const unsigned nb = (unsigned)(a.tiles_x * a.tiles_y * a.N);
     hipLaunchKernelGGL((cost_volume_kernel<R, FUSED>), dim3(nb), dim3(G::T), lds, s, a);

@@ -413,11 +413,10 @@ static int cv_roll_launch(const float* f0, int f0_cs, const float* f1, int f1_cs
     const long items = (long)N * a.nstrips * a.nseg;
     if (items >= (1L << 31)) return PWC_ERANGE;
     const size_t lds = (size_t)G::LDS_F * sizeof(float);
-    static bool attr_set = false;   // idempotent, benign if raced
-    if (!attr_set) {
+    static PwcDevOnce attr_once;   // the attribute is per device
+    if (pwc_first_on_device(&attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_volume_roll_kernel<0>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const unsigned nwg = (unsigned)(items < 256 ? items : 256);
     hipLaunchKernelGGL((cost_volume_roll_kernel<0>), dim3(nwg), dim3(G::T), lds, s, a);

@@ -494,11 +494,10 @@ extern "C" int pwc_cost_volume_grad_f32(const float* f0, int f0_cs, const float*
     const long nblk = (long)N * a.tiles_x * a.tiles_y;
     if (nblk >= (1L << 31)) return PWC_ERANGE;
     const size_t lds0 = (size_t)(16 * 16 * 20 + 8 * 8 * 81) * 4, lds1 = (size_t)(16 * 16 * 20 + 16 * 16 * 81) * 4;
-    static bool attr_set = false;   // idempotent, benign if raced
-    if (!attr_set) {
+    static PwcDevOnce attr_once;   // the attribute is per device
+    if (pwc_first_on_device(&attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_volume_grad_kernel<1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-        attr_set = true;
     }
     if (df0) hipLaunchKernelGGL(cost_volume_grad_kernel<0>, dim3((unsigned)nblk), dim3(256), lds0, (hipStream_t)stream, a);
     if (df1w) hipLaunchKernelGGL(cost_volume_grad_kernel<1>, dim3((unsigned)nblk), dim3(256), lds1, (hipStream_t)stream, a);

@@ -15,6 +15,20 @@ static inline int pwc_launch_status() {
     return e == hipSuccess ? PWC_OK : (int)e;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: a launch site keeps one flag per device
+// (a process that uses the library on a second GPU must set it there too).  Idempotent, benign if raced.
+struct PwcDevOnce {
+    unsigned long long done[4] = {0, 0, 0, 0};
+};
+static inline bool pwc_first_on_device(PwcDevOnce* o) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 256) return true;    // unknown: just set it again
+    const unsigned long long bit = 1ull << (d & 63);
+    if (o->done[d >> 6] & bit) return false;
+    o->done[d >> 6] |= bit;
+    return true;
+}
+
 static inline bool pwc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // TF 'SAME' padding of one axis for a 3-tap kernel (see include/pwc_hip.h, conv).

@@ -172,7 +172,7 @@ class PWCDCNet(object):
             self._eager_buffers[bkey] = self._buffers = {} if bufs is None else bufs
             while len(self._eager_buffers) > self.max_plans:
                 self._eager_buffers.popitem(last=False)
-            return self._forward(iv0, iv1, dev, with_features)
+            return self._hand_over(self._forward(iv0, iv1, dev, with_features), into)
         key = (iv0[1:], str(dev), stream, bool(with_features), self.store.version)
         plan = self._plans.get(key)
         if plan is not None:
@@ -214,11 +214,24 @@ class PWCDCNet(object):
         while len(self._plans) > self.max_plans:
             self._plans.popitem(last=False)          # least recently used; its buffers go with it
         if into is not None:                         # recording call of a sub-batch: hand the results over
-            into[0].copy_(outputs[0])
-            for dst, src in zip(into[1], outputs[1]):
-                dst.copy_(src)
-            return into
+            return self._hand_over(outputs, into)
+        if with_features and not self.persistent_outputs:
+            # pyramid_0 are slices of plan-owned extractor activations: the next replay of this shape would
+            # rewrite them under the caller (flows_final / flows_pyramid of the recording call are tensors of
+            # their own; replays are re-pointed at fresh ones)
+            outputs = (outputs[0], outputs[1], [t.clone() for t in outputs[2]])
         return outputs
+
+    @staticmethod
+    def _hand_over(outputs, into):
+        """Copy a forward's own flows into the caller-provided `into` = (final, pyramid) slices (sub-batches on
+        side streams); with into=None the outputs pass through."""
+        if into is None:
+            return outputs
+        into[0].copy_(outputs[0])
+        for dst, src in zip(into[1], outputs[1]):
+            dst.copy_(src)
+        return into
 
     def _fresh_outputs(self, plan, patch, into=None):
         """New flows_final / flows_pyramid tensors for this replay (or the caller's `into` slices); their

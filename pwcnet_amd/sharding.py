@@ -30,6 +30,19 @@ def gather_stats(stats, dist=None, device="cpu"):
     return [dict(zip(keys, t.cpu().tolist())) for t in out]
 
 
+def aggregate_throughput(stats, steps):
+    """The whole-job numbers of a bench run from the gathered per-rank {pairs, seconds} dicts: every rank timed
+    the same K steps, the job took as long as its slowest rank (MAX over ranks), and processed the SUM of the
+    ranks' pairs.  Returns (value in pairs/s, ms per step, total pairs, world size)."""
+    if not stats:
+        raise ValueError("no rank statistics")
+    slowest = max(s["seconds"] for s in stats)
+    total = sum(s["pairs"] for s in stats)
+    if slowest <= 0 or steps <= 0:
+        raise ValueError(f"bad timing: slowest rank {slowest} s over {steps} steps")
+    return total / slowest, 1e3 * slowest / steps, total, len(stats)
+
+
 def allreduce_sum_(flat, dist=None):
     """In-place sum of a flat (gradient) buffer over the ranks -- one collective per training step (RCCL over xGMI
     under `nccl`; gloo in the CPU tests).  Returns the world size (1: nothing done) so that the caller can average."""

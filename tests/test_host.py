@@ -213,6 +213,56 @@ def test_gather_stats_world2_gloo(tmp_path):
     assert "GATHER_OK 2.0 10.0" in out.stdout
 
 
+_WORLD8_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from pwcnet_amd import sharding
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+steps, per_gpu_batch = 20, 8
+# what bench.py hands to the gather on every rank: its pairs and ITS elapsed seconds (rank 5 is the slowest)
+mine = {"pairs": float(per_gpu_batch * steps), "seconds": 0.070 + 0.001 * r + (0.010 if r == 5 else 0.0)}
+stats = sharding.gather_stats(mine, dist, "cpu")
+value, ms_per_step, total, n = sharding.aggregate_throughput(stats, steps)
+assert n == w == 8 and total == 8 * per_gpu_batch * steps
+slowest = 0.070 + 0.005 + 0.010
+assert abs(ms_per_step - 1e3 * slowest / steps) < 1e-9 and abs(value - total / slowest) < 1e-6
+# every rank computes the same aggregate (the gather is an ALL-gather)
+agg = sharding.gather_stats({"value": value}, dist, "cpu")
+assert all(abs(a["value"] - value) < 1e-9 for a in agg)
+if r == 0:
+    print("WORLD8_OK", n, int(total), round(value, 3))
+dist.destroy_process_group()
+"""
+
+
+def test_bench_aggregation_world8_gloo(tmp_path):
+    """The host logic of the 8-GPU bench line (BASELINE configs[2]) on 8 gloo ranks: value = sum of the ranks' pairs /
+    the SLOWEST rank's seconds, ms_per_step from that rank, n_gpus = world -- so that the first real 8-GPU run cannot
+    trip on the aggregation."""
+    script = tmp_path / "world8_worker.py"
+    script.write_text(_WORLD8_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                          "--master-addr", "127.0.0.1", "--master-port", "29621", str(script), ROOT],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "WORLD8_OK 8 1280 15058.824" in out.stdout
+
+
+def test_bench_config_presets_imply_their_gpu_count():
+    """`--config configs2` / `configs4` are BASELINE's 8- and 2-GPU configurations; an explicit --gpus wins."""
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse(["--config", "configs4"])
+    assert (a.gpus, a.height, a.width, a.batch, a.gpus_given) == (2, 960, 1920, 8, False)
+    assert bench.parse(["--config", "configs2"]).gpus == 8
+    a = bench.parse(["--config", "configs4", "--gpus", "1"])
+    assert a.gpus == 1 and a.gpus_given
+    assert bench.parse(["--config", "configs3"]).gpus == 1 and bench.parse(["--config", "configs3"]).use_dc
+
+
 _EVAL_WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1])
