@@ -26,6 +26,7 @@
 //   Tiles are visited in XCD-aware order (neighbouring tiles share halo rows in one L2).
 #include "pwc_common.h"
 #include "cost_volume_roll.hip"   // rolling-window kernel for C = 32 (static: compiled into this unit)
+#include "cost_volume_mfma.hip"   // matrix-pipe kernel with the warp and the concat copy fused in (static: compiled into this unit)
 
 struct CvArgs {
     const float* f0;
