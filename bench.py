@@ -82,9 +82,10 @@ def parse(argv=None):
                     help="train: one optimisation step per bench step (pwcnet_amd.train.Trainer: forward, backward, "
                          "one RCCL all-reduce of the gradients, Adam) -- SURVEY.md 8 f4, not the headline metric")
     ap.add_argument("--loss", choices=("multiscale", "robust"), default="multiscale", help="--mode train")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="PWCDCNet(streams=K): the batch runs as K sub-batches on side HIP streams (opt-in; kernels of "
-                         "different sub-batches overlap, so the per-kernel roofline legs are switched off)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="PWCDCNet(streams=K): the batch runs as K sub-batches on side HIP streams whose kernels overlap; "
+                         "0 = the model's default (2 for even batches >= 4, else 1), 1 = single stream.  The per-kernel "
+                         "roofline legs always come from single-stream passes.")
     ap.add_argument("--persistent-outputs", action="store_true",
                     help="PWCDCNet(persistent_outputs=True): replays write into the plan's own output tensors")
     args = ap.parse_args(argv)
@@ -229,10 +230,13 @@ def main():
     # identical seeded glorot-uniform weights on every rank
     specs = W.conv_specs(use_dc=args.use_dc)
     wts = W.init_weights(specs, seed=0)
-    net = pwcnet_amd.PWCDCNet(use_dc=args.use_dc, persistent_outputs=args.persistent_outputs, streams=args.streams)
+    net = pwcnet_amd.PWCDCNet(use_dc=args.use_dc, persistent_outputs=args.persistent_outputs,
+                              streams=args.streams if args.streams > 0 else None)
     net.load_weights(wts)
-    if args.streams > 1:
-        args.no_op_timing = True      # HIP events on the caller's stream do not bracket side-stream kernels
+    eff_streams = net.streams if net.streams is not None else (2 if (args.batch >= 4 and args.batch % 2 == 0) else 1)
+    if args.persistent_outputs:
+        eff_streams = 1
+    overlapped = eff_streams > 1      # HIP events on the caller's stream do not bracket side-stream kernels
 
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
@@ -258,14 +262,23 @@ def main():
     dominant = None
     full_steps = min(args.steps, 5)
     if not args.no_op_timing and full_steps > 0:
+        keep_streams, net.streams = net.streams, 1      # per-kernel durations: single-stream form of the same forward
+        for _ in range(2):
+            net(im0, im1)
+        torch.cuda.synchronize()
         full = OpTimer()
         with full:
             for _ in range(full_steps):
                 net(im0, im1)
         full_summary = full.summary()
         dominant = max(full_summary.items(), key=lambda kv: kv[1]["ms"])[0]
+        net.streams = keep_streams
+        for _ in range(2):
+            net(im0, im1)
+        torch.cuda.synchronize()
 
-    timer = None if dominant is None else OpTimer(only=(dominant, "cost_volume", "warp_kernel"))
+    # events inside the timed region only when its kernels run one after the other on the caller's stream
+    timer = None if (dominant is None or overlapped) else OpTimer(only=(dominant, "cost_volume", "warp_kernel"))
     # sampled steps: the middle one of every SAMPLE_EVERY (at least one)
     sampled = set(i for i in range(args.steps) if i % SAMPLE_EVERY == SAMPLE_EVERY // 2) or {args.steps - 1}
     sync_all()
@@ -323,13 +336,22 @@ def main():
             "parallelism": f"dp{world}: pairs sharded across ranks, no data-path collective"
                            + ("; RCCL all-gather of per-rank stats" if used_rccl else ""),
             "outputs": "persistent (plan-owned)" if args.persistent_outputs else "fresh tensors per call",
-            "streams": args.streams,
+            "streams": eff_streams,
         },
     }
 
-    if timer is not None:
-        summ = timer.summary()          # events recorded INSIDE the timed region (sampled steps)
-        n_sampled = len(sampled)
+    if dominant is not None:
+        if timer is not None:
+            summ = timer.summary()          # events recorded INSIDE the timed region (sampled steps)
+            n_sampled = len(sampled)
+            where = (f"HIP events around each launch of this kernel in one step of every {SAMPLE_EVERY} of the "
+                     f"timed region ({n_sampled} of {args.steps} steps)")
+        else:
+            summ = full_summary             # overlapped timed region: the untimed single-stream profile pass
+            n_sampled = full_steps
+            where = (f"HIP events around each launch in the UNTIMED single-stream profile pass ({full_steps} forwards of "
+                     f"the whole batch, every launch bracketed); the timed region runs the batch as {eff_streams} "
+                     "sub-batches on side HIP streams whose kernels overlap, so per-kernel durations exist only here")
         dd = summ[dominant]
         alg = dd["flops"] / (dd["ms"] * 1e-3) / 1e12
         exe = dd["exec_flops"] / (dd["ms"] * 1e-3) / 1e12
@@ -341,8 +363,7 @@ def main():
                 "algorithmic_tflops": alg,
                 "algorithmic_flops_per_launch": dd["flops"] / dd["launches"],
                 "algorithmic_over_executed": dd["flops"] / dd["exec_flops"],
-                "measured": f"HIP events around each launch of this kernel in one step of every {SAMPLE_EVERY} of the "
-                            f"timed region ({n_sampled} of {args.steps} steps)",
+                "measured": where,
                 "note": "achieved/frac = multiply-adds the MFMA units execute (Winograd: 16 per 2x2 outputs "
                         "and 36 per 4x4 outputs instead of 9 per output, physical Cin); algorithmic_* = "
                         "2*M*9*Cin*Cout of the direct convolution the launch replaces (SURVEY.md 8d)"}
@@ -372,8 +393,7 @@ def main():
                 "ms_per_step": ms / n_sampled,
                 "per_kernel": {k: {"avg_us": 1e3 * d["ms"] / d["launches"],
                                    "gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9} for k, d in hb},
-                "measured": f"HIP events in one step of every {SAMPLE_EVERY} of the timed region (random-init net: flows "
-                            "~ 0); bytes = N*h*w*(2C+81)*4 (cost volume), N*h*w*(2C+2)*4 (warp), "
+                "measured": where + " (random-init net: flows ~ 0); bytes = N*h*w*(2C+81)*4 (cost volume), N*h*w*(2C+2)*4 (warp), "
                             "N*h*w*(2C+2+81)*4 (fused warp + cost volume), all 5 pyramid levels; the f0 concat "
                             "copy that rides in some launches is NOT counted"}
         # per-kernel table from the untimed, fully instrumented profile pass

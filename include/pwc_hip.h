@@ -98,11 +98,33 @@ int pwc_cost_volume_coarse_f32(const float* f0, int f0_cs, const float* f1, int 
 
 /* ---- a2+a1 fused: model.py:109-112 (warp then cost volume) without materialising
  * the warped feature map.  f1 is the UN-warped second feature map.  Same result as
- * pwc_warp_bilinear_f32 followed by pwc_cost_volume_f32. */
+ * pwc_warp_bilinear_f32 followed by pwc_cost_volume_f32.  Runs the matrix-pipe kernel of
+ * pwc_warp_cost_volume_concat_f32 where that one is supported, the tile kernel with a gathering
+ * loader otherwise. */
 int pwc_warp_cost_volume_f32(const float* f0, int f0_cs, const float* f1, int f1_cs,
                              const float* flow, int flow_cs, float flow_scale,
                              float* out, int out_cs, int N, int H, int W, int C,
                              int search_range, float slope, pwc_stream_t stream);
+
+/* ---- a2+a1 + the `features_0` part of tf.concat (modules.py:264) in ONE launch, correlation on the matrix
+ * pipe (csrc/cost_volume_mfma.hip) -- model.py:105-112 for a pyramid level:
+ *   out      = pwc_cost_volume_f32(f0, bilinear_warp(f1, flow_scale * flow))     (flow == NULL: f1 as is)
+ *   f0_copy  = f0                                                                (f0_copy == NULL: no copy)
+ * without ever writing the warped map.  out_pad_writable != 0 declares channels 81..83 of every `out` record
+ * padding that the callee may overwrite with zeros (the estimator buffers of pwcnet_amd/model.py: segments start
+ * on multiples of 4 channels) -- the record then leaves as 21 full 16-byte stores.
+ * Supported: search_range 4, C in {32, 64, 96}, 16-byte aligned f0 / f1 / out / f0_copy with channel strides
+ * % 4 == 0, flow 4-byte aligned, per-image extents below 2^31 bytes; anything else returns PWC_EUNSUPPORTED /
+ * PWC_EALIGN and the caller uses the separate entry points.  pwc_warp_cost_volume_concat_supported tells in
+ * advance (pointers taken as aligned). */
+int pwc_warp_cost_volume_concat_f32(const float* f0, int f0_cs, const float* f1, int f1_cs,
+                                    const float* flow, int flow_cs, float flow_scale,
+                                    float* out, int out_cs, int out_pad_writable,
+                                    float* f0_copy, int f0_copy_cs,
+                                    int N, int H, int W, int C, int search_range, float slope,
+                                    pwc_stream_t stream);
+int pwc_warp_cost_volume_concat_supported(int H, int W, int C, int search_range, int f0_cs, int f1_cs,
+                                          int flow_cs, int out_cs, int f0_copy_cs);
 
 /* ---- a4/a5/a6: tf.layers.Conv2D(Cout,(3,3),(s,s),'same',dilation_rate=d) [+
  * tf.nn.leaky_relu(slope)] -- modules.py:62-67,267-268,274,306-324 ----

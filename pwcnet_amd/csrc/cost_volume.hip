@@ -770,6 +770,29 @@ extern "C" int pwc_cost_volume_f32(const float* f0, int f0_cs, const float* f1w,
     return cv_dispatch(a, search_range, false, (hipStream_t)stream);
 }
 
+extern "C" int pwc_warp_cost_volume_concat_supported(int H, int W, int C, int search_range, int f0_cs, int f1_cs,
+                                                     int flow_cs, int out_cs, int f0_copy_cs) {
+    const float* al = reinterpret_cast<const float*>(16);
+    return cvm_eligible(al, f0_cs, al, f1_cs, flow_cs ? al : nullptr, flow_cs, al, out_cs, f0_copy_cs ? al : nullptr,
+                        f0_copy_cs, H, W, C, search_range) ? 1 : 0;
+}
+
+extern "C" int pwc_warp_cost_volume_concat_f32(const float* f0, int f0_cs, const float* f1, int f1_cs,
+                                               const float* flow, int flow_cs, float flow_scale, float* out,
+                                               int out_cs, int out_pad_writable, float* f0_copy, int f0_copy_cs,
+                                               int N, int H, int W, int C, int search_range, float slope,
+                                               pwc_stream_t stream) {
+    int rc = cv_check(f0, f0_cs, f1, f1_cs, out, out_cs, N, H, W, C, search_range);
+    if (rc) return rc;
+    if ((flow && flow_cs < 2) || (f0_copy && f0_copy_cs < C)) return PWC_EINVAL;
+    if (out_pad_writable && out_cs < 84) return PWC_EINVAL;
+    if (search_range != 4 || !(C == 32 || C == 64 || C == 96)) return PWC_EUNSUPPORTED;
+    if (!cvm_eligible(f0, f0_cs, f1, f1_cs, flow, flow_cs, out, out_cs, f0_copy, f0_copy_cs, H, W, C, search_range))
+        return ((long)H * W * (long)(out_cs > f0_cs ? out_cs : f0_cs) * 4 >= (1L << 31)) ? PWC_ERANGE : PWC_EALIGN;
+    return cvm_launch(f0, f0_cs, f1, f1_cs, flow, flow_cs, flow_scale, out, out_cs, out_pad_writable ? 1 : 0, f0_copy,
+                      f0_copy_cs, N, H, W, C, slope, (hipStream_t)stream);
+}
+
 extern "C" int pwc_warp_cost_volume_f32(const float* f0, int f0_cs, const float* f1, int f1_cs,
                                         const float* flow, int flow_cs, float flow_scale, float* out,
                                         int out_cs, int N, int H, int W, int C, int search_range, float slope,
@@ -777,6 +800,9 @@ extern "C" int pwc_warp_cost_volume_f32(const float* f0, int f0_cs, const float*
     int rc = cv_check(f0, f0_cs, f1, f1_cs, out, out_cs, N, H, W, C, search_range);
     if (rc) return rc;
     if (!flow || flow_cs < 2) return PWC_EINVAL;
+    if (cvm_eligible(f0, f0_cs, f1, f1_cs, flow, flow_cs, out, out_cs, nullptr, 0, H, W, C, search_range))
+        return cvm_launch(f0, f0_cs, f1, f1_cs, flow, flow_cs, flow_scale, out, out_cs, 0, nullptr, 0, N, H, W, C, slope,
+                          (hipStream_t)stream);
     CvArgs a;
     a.f0 = f0; a.f1 = f1; a.flow = flow; a.out = out;
     a.f0_cs = f0_cs; a.f1_cs = f1_cs; a.flow_cs = flow_cs; a.out_cs = out_cs;

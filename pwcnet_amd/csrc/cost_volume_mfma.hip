@@ -66,7 +66,7 @@ struct CvmGeom {
     static constexpr int ITEMS = CG * NPIX * 4 / T;      // gather items per lane and Q row
     static constexpr int NB = ITEMS / 3;                 // batches of 3 items (48 registers in flight)
     static constexpr int SROW = 84;                      // stage floats per pixel record
-    static constexpr int DUMP = 16 * SROW + 36;          // dump slots: 64 lanes, reached with +-36-float immediates
+    static constexpr int DUMP = 16 * SROW;               // dump slots: 64 lanes, reached with 0 / 36 / 72-float immediates
     static constexpr int WSTG = 16 * SROW + 144;         // stage floats per wave: its 4 x 4 block + the dump area
     static constexpr int TAB = NPIX * 8;                 // dwords per corner table
     static constexpr int LDS_F = 2 * BUF * 4 + NW * WSTG + 2 * TAB;
@@ -82,10 +82,18 @@ struct CvmGeom {
 #endif
 // cache policy bits of the builtins' aux operand (gfx940+): 0 = default, 2 = nt (streaming), 16 = sc1
 #ifndef CVM_STORE_AUX
-#define CVM_STORE_AUX 0
+#define CVM_STORE_AUX 2
 #endif
 #ifndef CVM_F0_AUX
 #define CVM_F0_AUX 0
+#endif
+#ifndef CVM_COPY_AUX
+#define CVM_COPY_AUX 0
+#endif
+// start delay (s_sleep units of 64 cycles) of the workgroups of the second half of the grid: the two workgroups of
+// a CU then alternate their matrix and memory phases instead of meeting in them
+#ifndef CVM_STAGGER
+#define CVM_STAGGER 0
 #endif
 // phase boundaries of a step (scripts/exp_cv3.hip builds a variant without them)
 #ifndef CVM_NO_SCHED_BARRIER
@@ -109,6 +117,15 @@ __device__ __forceinline__ void cvm_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
+// f(std::integral_constant<int, i>{}) for i = 0 .. N-1
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void cvm_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        cvm_for<N, I + 1>(f);
+    }
+}
+
 // ABL (scripts/exp_cv3.hip only; 0 in the library): 1 = no MFMAs, 2 = no gather loads, 4 = no stores
 // PAD: channels 81..83 of every `out` record are the kernel's to zero (estimator buffers: padding channels) -- the
 // record is then 21 full 16-byte quads.
@@ -116,7 +133,7 @@ template <int CG, bool WARP, bool PAD, int ABL = 0>
 __global__ __launch_bounds__(256, CvmGeom<CG>::WGPC) void cost_volume_mfma_kernel(const CvmArgs a) {
     using G = CvmGeom<CG>;
     constexpr int RS = G::RS, PLANE = G::PLANE, BUF = G::BUF, NB = G::NB, ITEMS = G::ITEMS;
-    constexpr bool KEEP = CG <= 4;                                      // per-item constants live in registers
+    constexpr bool KEEP = CG <= 2;                                      // per-item constants live in registers
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* qimg = reinterpret_cast<f32x4*>(smem);                       // 2 Q-row images of BUF slots
     float* stg_all = smem + 2 * BUF * 4;
@@ -136,6 +153,7 @@ __global__ __launch_bounds__(256, CvmGeom<CG>::WGPC) void cost_volume_mfma_kerne
     const int pb0 = sg * a.seg_brows;
     const int pb1 = min(pb0 + a.seg_brows, a.nbrows);
     if (pb0 >= pb1) return;                                             // uniform
+    if (CVM_STAGGER > 0 && blockIdx.x >= 256 && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(CVM_STAGGER);
     const int qa = max(pb0 - 1, 0), qb = min(pb1, a.nbrows - 1);        // Q rows that hold image pixels
 
     const size_t npx = (size_t)a.H * a.W;
@@ -170,9 +188,9 @@ __global__ __launch_bounds__(256, CvmGeom<CG>::WGPC) void cost_volume_mfma_kerne
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool vx = bxi == 0 ? (mcol >= r) : (bxi == 2 ? (mcol <= r) : true);
-            sxa[bxi][r] = stg + (vx ? sbase + r * (G::SROW - 1) + 4 * (bxi - 1) : G::DUMP + lane);
+            sxa[bxi][r] = stg + (vx ? sbase + r * (G::SROW - 1) + 4 * (bxi - 1) - 36 : G::DUMP + lane);
         }
-    const bool vy_m = mrow >= kq, vy_p = mrow <= kq;                    // by = -1 / +1: |dy| <= 4
+    const int vy_m_i = mrow >= kq, vy_p_i = mrow <= kq;                 // by = -1 / +1: |dy| <= 4
 
     // copy-out items: e = i * 64 + lane -> (pixel p = e / 21 of the block, quad e % 21); byte offset relative to
     // the block's first pixel (out-of-range: the strip's columns beyond the image, e >= 336, and -- without PAD --
@@ -190,8 +208,6 @@ __global__ __launch_bounds__(256, CvmGeom<CG>::WGPC) void cost_volume_mfma_kerne
 
     // stage padding channels 81..83 stay zero for the whole launch
     if (lane < 48) stg[(lane / 3) * G::SROW + 81 + (lane % 3)] = 0.f;
-    // both corner tables start out-of-range (the fill steps issue their gathers like every other step)
-    if (WARP && t < 2 * G::NPIX) *reinterpret_cast<cvm_u32x4*>(tabf + t * 8) = cvm_u32x4{CVM_OOB, CVM_OOB, CVM_OOB, CVM_OOB};
 
     // ---- gather items of a Q row: item e = i * 256 + t -> (plane g, pixel, quad t & 3)
     auto item_decode = [&](int i, unsigned& chan, int& tab_d, int& img_s) {
@@ -248,65 +264,66 @@ __global__ __launch_bounds__(256, CvmGeom<CG>::WGPC) void cost_volume_mfma_kerne
         }
     };
 
+    // ---- gather of a Q row, as micro-operations that the step places into the shadows of its MFMAs:
+    //   gi_tab(b, qq)     the three table reads of batch b (one LDS round trip)
+    //   gi_load(b, j)     the 4 (1) corner loads of item j
+    //   gc_item(b, j, qq) blend + ds_write_b128 of item j into Q-row image qq & 1
     f32x4 gv[3][WARP ? 4 : 1];
-    auto gather_issue = [&](int batch, int qq) {                        // Q row qq -> registers
-        unsigned chan[3];
-        cvm_u32x4 off[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {                                   // the three table reads first: one LDS round trip
-            int tab_d, img_s;
-            item(batch * 3 + j, chan[j], tab_d, img_s);
-            if (WARP) off[j] = *reinterpret_cast<const cvm_u32x4*>(tabf + (qq & 1) * G::TAB + tab_d);
-            else off[j][0] = nowarp_off(tab_d, qq);
-        }
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int c = 0; c < (WARP ? 4 : 1); ++c) {
-                const unsigned vo = (ABL & 2) ? CVM_OOB : off[j][c] + chan[j];     // out-of-range + chan stays out of range
-                gv[j][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, (int)vo, 0, 0));
-            }
-    };
-    auto gather_commit = [&](int batch, int qq) {                       // registers -> Q-row image qq & 1
-        if (qq < qa || qq > qb) return;                                 // uniform; rows without pixels are never read
+    unsigned gchan[3];
+    cvm_u32x4 goff[3];
+    auto gi_tab = [&](int batch, int qq) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            unsigned chan;
             int tab_d, img_s;
-            item(batch * 3 + j, chan, tab_d, img_s);
-            f32x4 v;
-            if (WARP) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(tabf + (qq & 1) * G::TAB + tab_d + 4);
-                // modules.py:132-135: c00*x00 + c01*x01 + c10*x10 + c11*x11, summed left to right (the weights carry
-                // the 1/C of the mean: exact for C = 32, 64)
-                v = w[0] * gv[j][0];
-                v = __builtin_elementwise_fma(f32x4{w[1], w[1], w[1], w[1]}, gv[j][1], v);
-                v = __builtin_elementwise_fma(f32x4{w[2], w[2], w[2], w[2]}, gv[j][2], v);
-                v = __builtin_elementwise_fma(f32x4{w[3], w[3], w[3], w[3]}, gv[j][3], v);
-            } else {
-                v = gv[j][0] * a.inv_c;
-            }
-            qimg[(qq & 1) * BUF + img_s] = v;
+            item(batch * 3 + j, gchan[j], tab_d, img_s);
+            if (WARP) goff[j] = *reinterpret_cast<const cvm_u32x4*>(tabf + (qq & 1) * G::TAB + tab_d);
+            else goff[j][0] = nowarp_off(tab_d, qq);
         }
+    };
+    auto gi_load = [&](int j) {
+#pragma unroll
+        for (int c = 0; c < (WARP ? 4 : 1); ++c) {
+            const unsigned vo = (ABL & 2) ? CVM_OOB : goff[j][c] + gchan[j];       // out-of-range + chan stays out of range
+            gv[j][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, (int)vo, 0, 0));
+        }
+    };
+    auto gc_item = [&](int batch, int j, int qq) {
+        unsigned chan;
+        int tab_d, img_s;
+        item(batch * 3 + j, chan, tab_d, img_s);
+        f32x4 v;
+        if (WARP) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(tabf + (qq & 1) * G::TAB + tab_d + 4);
+            // modules.py:132-135: c00*x00 + c01*x01 + c10*x10 + c11*x11, summed left to right (the weights carry the
+            // 1/C of the mean: exact for C = 32, 64)
+            v = w[0] * gv[j][0];
+            v = __builtin_elementwise_fma(f32x4{w[1], w[1], w[1], w[1]}, gv[j][1], v);
+            v = __builtin_elementwise_fma(f32x4{w[2], w[2], w[2], w[2]}, gv[j][2], v);
+            v = __builtin_elementwise_fma(f32x4{w[3], w[3], w[3], w[3]}, gv[j][3], v);
+        } else {
+            v = gv[j][0] * a.inv_c;
+        }
+        // rows without pixels are never read: their (out-of-range, zero) items may land anywhere in the image
+        qimg[(qq & 1) * BUF + img_s] = v;
     };
 
     // ---- corner table of a Q row (WARP): 96 lanes, one pixel each
     float fl0 = 0.f, fl1 = 0.f;
     const int t_r = (t * 2731) >> 16, t_xi = t - t_r * 24;              // this lane's table pixel (t < 96)
-    auto flow_issue = [&](int qq) {
+    auto flow_issue = [&](int qq, float& f0v, float& f1v) {
         const int gy = 4 * qq + t_r, gx = x0 - 4 + t_xi;
         const bool ok = t < G::NPIX && qq >= qa && qq <= qb && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
         const unsigned vo = ok ? (unsigned)((gy * a.W + gx) * a.flow_cs) * 4u : CVM_OOB;
-        fl0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, (int)vo, 0, 0));
-        fl1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, (int)vo, 4, 0));
+        f0v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, (int)vo, 0, 0));
+        f1v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, (int)vo, 4, 0));
     };
-    auto table_write = [&](int qq) {
+    auto table_write = [&](int qq, float f0v, float f1v) {
         if (t < G::NPIX) {
             const int gy = 4 * qq + t_r, gx = x0 - 4 + t_xi;
             const bool ok = qq >= qa && qq <= qb && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
             // bilinear_warp, modules.py:107-137: the product flow * scale is rounded first (model.py:109 is an op of
             // its own), weights from the un-clipped floors, the four corner indices clipped independently
-            const float fx = pwc_mul_rounded(fl0, a.flow_scale), fy = pwc_mul_rounded(fl1, a.flow_scale);
+            const float fx = pwc_mul_rounded(f0v, a.flow_scale), fy = pwc_mul_rounded(f1v, a.flow_scale);
             const float fx0 = floorf(fx), fy0 = floorf(fy);
             const float fx1 = fx0 + 1.f, fy1 = fy0 + 1.f;
             const float hl = (float)(a.H - 1), wl = (float)(a.W - 1);
@@ -334,85 +351,107 @@ __global__ __launch_bounds__(256, CvmGeom<CG>::WGPC) void cost_volume_mfma_kerne
             dst[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r0, (int)(ok ? vo : CVM_OOB), g * 64, CVM_F0_AUX));
     };
 
-    // ---- one vertical block offset of a step: the P row in slot `sl` against Q row image `img`; its three tiles
-    // start from zero here (every tile row of a P row is first touched by exactly one group)
-    auto mfma_group = [&](auto sl_c, auto byi_c, const f32x4* img, bool on) {
-        constexpr int sl = decltype(sl_c)::value, byi = decltype(byi_c)::value;
-        if (!on || (ABL & 1)) {                                         // uniform
+    // ---- epilogue of a complete P row (slot sl), as micro-operations:
+    //   e1(i)   value i = (byi, bxi, r) of the 36 the lane holds: leaky-relu -> stage (|dx| > 4: dump area through
+    //           the address, |dy| > 4: dump area by select)
+    //   e2(i)   i < 6: one 16-byte store instruction of the copy-out; 6: the concat copy from the f0 registers;
+    //           7: channel 80 when the padding channels are not the kernel's to write (!PAD)
+    // Always executed (rows outside the segment store nothing: out-of-range offsets) -- the compiler counts vmcnt along
+    // every path, and a branch around these stores would make each wait for a gathered corner wait for the stores too.
+    // e1(t): tile t = (byi, bxi) of the 9 the lane holds -> stage, raw sums (the activation is applied to the 16-byte
+    //        quads of the copy-out: 24 values per lane there against 36 here).  |dx| > 4: dump area through the
+    //        address; |dy| > 4: the lane sits the tile out.
+    auto e1 = [&](auto sl_c, auto t_c) {
+        constexpr int sl = decltype(sl_c)::value, tile = decltype(t_c)::value;
+        constexpr int byi = tile / 3, bxi = tile % 3;
+        if (byi == 1 || (byi == 0 ? vy_m_i : vy_p_i)) {
 #pragma unroll
-            for (int bx = 0; bx < 3; ++bx) acc[sl][byi][bx] = f32x4{0.f, 0.f, 0.f, 0.f};
-            return;
-        }
-#pragma unroll
-        for (int g = 0; g < CG; ++g) {
-            f32x4 B[3];
-#pragma unroll
-            for (int bx = 0; bx < 3; ++bx) B[bx] = img[g * PLANE + bslot + (bx - 1) * 16];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int bx = 0; bx < 3; ++bx) {
-                    const f32x4 c = (g == 0 && k == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[sl][byi][bx];
-                    acc[sl][byi][bx] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[sl][g][k], B[bx][k], c, 0, 0, 0);
-                }
+            for (int r = 0; r < 4; ++r) sxa[bxi][r][36 * byi] = acc[sl][byi][bxi][r];
         }
     };
-
-    // ---- P row pb (slot sl) is complete: activation -> stage -> stores; f0 registers -> concat copy.  Always
-    // executed (rows outside the segment store nothing: out-of-range offsets) -- the compiler counts vmcnt along every
-    // path, and a branch around these stores would make each wait for a gathered corner wait for the stores too.
-    auto epilogue = [&](auto sl_c, int pb) {
-        constexpr int sl = decltype(sl_c)::value;
-        cvm_wave_sync();                                                // the previous copy-out has read the stage
-#pragma unroll
-        for (int byi = 0; byi < 3; ++byi) {
-            if (byi == 1 || (byi == 0 ? vy_m : vy_p)) {
-#pragma unroll
-                for (int bxi = 0; bxi < 3; ++bxi)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        // leaky-relu max(x, slope * x): ONE v_max_f32 (fmaxf costs a second one that quiets a
-                        // possible signalling NaN first; fmed3 with +inf is folded back into fmaxf).  The v_mul_f32
-                        // in front is compiler-visible and reads the same MFMA result, so the MFMA -> VALU wait
-                        // states are in place when the asm statement issues.
-                        const float x = acc[sl][byi][bxi][r];
-                        const float sx = x * a.slope;
-                        float y;
-                        asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(sx));
-                        sxa[bxi][r][36 * (byi - 1)] = y;
-                    }
-            }
-        }
-        cvm_wave_sync();
+    auto e2 = [&](auto sl_c, auto i_c, int pb) {
+        constexpr int sl = decltype(sl_c)::value, i = decltype(i_c)::value;
         const bool pv = pb >= pb0;                                      // uniform (pb < pb1 always)
         const int ylim = pv ? a.H - 4 * pb : 0;                         // rows of this block inside the image
         const unsigned base = (unsigned)((4 * pb * a.W + x0 + 4 * wave) * a.out_cs) * 4u;
+        if constexpr (i < 6) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(stg + (i * 64 + lane < 16 * 21 ? (i * 64 + lane) * 4 : 0));
+            // leaky-relu max(x, slope * x): ONE v_max_f32 per value (fmaxf costs a second one that quiets a possible
+            // signalling NaN first; fmed3 with +inf is folded back into fmaxf).  The multiply in front is
+            // compiler-visible and reads the same registers.
+            const f32x4 sv = v * a.slope;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (i * 64 + lane < 16 * 21 ? (i * 64 + lane) * 4 : 0));
+            for (int k = 0; k < 4; ++k) {
+                float y;
+                asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(v[k]), "v"(sv[k]));
+                v[k] = y;
+            }
             const bool ok = i * 64 + lane < 84 * ylim && !(ABL & 4);    // 84 items per block row
             const unsigned vo = ok ? base + co_rel[i] : CVM_OOB;        // out-of-range + base stays out of range
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cvm_u32x4, v), ro, (int)vo, 0, CVM_STORE_AUX);
-        }
-        if (!PAD) {
-            const float v = stg[(lane & 15) * G::SROW + 80];
-            const bool ok = (lane >> 2) < ylim && !(ABL & 4);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, (int)(ok ? base + c80_rel : CVM_OOB), 0, CVM_STORE_AUX);
-        }
-        {
+        } else if constexpr (i == 6) {
             const bool ok = a_in && pv && mrow < ylim && !(ABL & 4);
             const unsigned vo = ok ? (a_rel + (unsigned)(4 * pb * a.W)) * (unsigned)(a.f0_copy_cs * 4) + (unsigned)(kq * 16) : CVM_OOB;
 #pragma unroll
             for (int g = 0; g < CG; ++g)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cvm_u32x4, A[sl][g]), rc, (int)(ok ? vo : CVM_OOB), g * 64, CVM_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cvm_u32x4, A[sl][g]), rc, (int)(ok ? vo : CVM_OOB), g * 64, CVM_COPY_AUX);
+        } else if constexpr (!PAD) {
+            const float x = stg[(lane & 15) * G::SROW + 80];
+            const float v = pwc_lrelu(x, a.slope);
+            const bool ok = (lane >> 2) < ylim && !(ABL & 4);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, (int)(ok ? base + c80_rel : CVM_OOB), 0, CVM_STORE_AUX);
         }
     };
 
+    // ---- one vertical block offset of a step: 4 CG chunks of 3 MFMAs (P row in slot `sl` against Q-row image
+    // `img`; its three tiles start from zero: every tile row of a P row is first touched by exactly one group), and
+    // after each chunk the share [c n / NCH, (c+1) n / NCH) of the group's n side micro-operations -- they issue
+    // while the matrix pipe works (an MFMA occupies it for 32 cycles, the issuing wave for 4).  sched_barrier pins
+    // the interleave: the compiler would otherwise cluster the MFMAs.
+    auto group = [&](auto sl_c, auto byi_c, const f32x4* img, bool on, auto nside_c, auto&& side) {
+        constexpr int sl = decltype(sl_c)::value, byi = decltype(byi_c)::value, NS = decltype(nside_c)::value;
+        constexpr int NCH = 4 * CG;
+        const bool run = on && !(ABL & 1);                              // uniform
+        if (!run) {
+            // Q row without pixels / P row outside the segment (fill and tail steps): zero tiles, side work only
+#pragma unroll
+            for (int bx = 0; bx < 3; ++bx) acc[sl][byi][bx] = f32x4{0.f, 0.f, 0.f, 0.f};
+            cvm_for<NS>(side);
+            return;
+        }
+        f32x4 B[3], Bn[3];
+#pragma unroll
+        for (int bx = 0; bx < 3; ++bx) B[bx] = img[bslot + (bx - 1) * 16];
+        cvm_for<NCH>([&](auto c_c) {
+            constexpr int c = decltype(c_c)::value, g = c / 4, k = c % 4;
+            if (k == 0 && g + 1 < CG) {
+#pragma unroll
+                for (int bx = 0; bx < 3; ++bx) Bn[bx] = img[(g + 1) * PLANE + bslot + (bx - 1) * 16];
+            }
+#pragma unroll
+            for (int bx = 0; bx < 3; ++bx) {
+                const f32x4 cin = c == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[sl][byi][bx];
+                acc[sl][byi][bx] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[sl][g][k], B[bx][k], cin, 0, 0, 0);
+            }
+            if (k == 3 && g + 1 < CG) {
+#pragma unroll
+                for (int bx = 0; bx < 3; ++bx) B[bx] = Bn[bx];
+            }
+            cvm_for<(c + 1) * NS / NCH - c * NS / NCH>([&](auto i_c) {
+                side(std::integral_constant<int, c * NS / NCH + decltype(i_c)::value>{});
+            });
+            CVM_SCHED_BARRIER();
+        });
+    };
+
     // ---- the walk.  Step q: Q row q (image q & 1) is multiplied; Q row q+1 is gathered into the other image; the
-    // corner table of Q row q+2 is built.  Two (WARP) / one fill steps come first.  S0 / S1 / S2 = slots of the P
-    // rows q-1 / q / q+1 (static: the loop is unrolled three steps deep, nothing rotates)
+    // corner table of Q row q+2 is built.  One fill step comes first (its tables are built in front of it).  S0 / S1 /
+    // S2 = slots of the P rows q-1 / q / q+1 (static: the loop is unrolled three steps deep, nothing rotates)
     auto step = [&](auto s0_c, int q) {
         constexpr int S0 = decltype(s0_c)::value, S1 = (S0 + 1) % 3, S2 = (S0 + 2) % 3;
+        using IS0 = std::integral_constant<int, S0>;
+        using IS1 = std::integral_constant<int, S1>;
+        using IS2 = std::integral_constant<int, S2>;
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
@@ -420,40 +459,68 @@ __global__ __launch_bounds__(256, CvmGeom<CG>::WGPC) void cost_volume_mfma_kerne
         const f32x4* img = qimg + (q & 1) * BUF;
         stamp();
         load_A(A[S2], q + 1);
-        if (WARP) flow_issue(q + 2);
-        gather_issue(0, q + 1);
+        if (WARP) flow_issue(q + 2, fl0, fl1);
         CVM_SCHED_BARRIER();
         stamp();
 
-        mfma_group(std::integral_constant<int, S0>{}, I2{}, img, mm && q - 1 >= pb0);     // by = +1
-        if (NB >= 2) {
-            gather_commit(0, q + 1);
-            gather_issue(1, q + 1);
-        }
-        CVM_SCHED_BARRIER();
+        // The P row q-1 (slot S0) leaves in three parts: its by = -1 and by = 0 tiles have been complete since the
+        // previous steps and go to the stage WHILE the by = +1 group runs (24 registers free before the gather's 48
+        // are taken), the by = +1 tiles follow in the next group, the copy-out in the last.
+        // by = +1 (completes the P row q-1)  ||  activation -> stage, tiles 0..5  [NB >= 2: + batch 0 loads]
+        cvm_wave_sync();                                                // the previous copy-out has read the stage
+        group(IS0{}, I2{}, img, mm && q - 1 >= pb0, std::integral_constant<int, 6 + (NB >= 2 ? 4 : 0)>{}, [&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            if constexpr (i < 6) e1(IS0{}, i_c);
+            else if constexpr (i == 6) gi_tab(0, q + 1);
+            else gi_load(i - 7);
+        });
         stamp();
-        epilogue(std::integral_constant<int, S0>{}, q - 1);
-        CVM_SCHED_BARRIER();
+        // by = 0  ||  tiles 6..8, then the gather traffic of this phase
+        //   NB = 1: batch 0 loads;  NB >= 2: batch 0 -> image, batch 1 loads
+        group(IS1{}, I1{}, img, mm && q >= pb0 && q < pb1, std::integral_constant<int, 3 + (NB >= 2 ? 7 : 4)>{}, [&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            if constexpr (i < 3) e1(IS0{}, std::integral_constant<int, 6 + i>{});
+            else if constexpr (NB == 1) {
+                if constexpr (i == 3) gi_tab(0, q + 1);
+                else gi_load(i - 4);
+            } else {
+                if constexpr (i < 6) gc_item(0, i - 3, q + 1);
+                else if constexpr (i == 6) gi_tab(1, q + 1);
+                else gi_load(i - 7);
+            }
+        });
         stamp();
-
-        mfma_group(std::integral_constant<int, S1>{}, I1{}, img, mm && q >= pb0 && q < pb1);   // by = 0
+        // by = -1  ||  [NB = 3: batch 1 -> image, batch 2 loads, then] the copy-out of the P row q-1
+        cvm_wave_sync();
+        group(IS2{}, I0{}, img, mm && q + 1 < pb1, std::integral_constant<int, 8 + (NB == 3 ? 7 : 0)>{}, [&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            constexpr int E0 = NB == 3 ? 7 : 0;
+            if constexpr (i < E0) {
+                if constexpr (i < 3) gc_item(1, i, q + 1);
+                else if constexpr (i == 3) gi_tab(2, q + 1);
+                else gi_load(i - 4);
+            } else {
+                e2(IS0{}, std::integral_constant<int, i - E0>{}, q - 1);
+            }
+        });
         stamp();
-        if (NB == 1) gather_commit(0, q + 1);
-        if (NB >= 2) gather_commit(1, q + 1);
-        if (NB == 3) gather_issue(2, q + 1);
-        CVM_SCHED_BARRIER();
-        stamp();
-
-        mfma_group(std::integral_constant<int, S2>{}, I0{}, img, mm && q + 1 < pb1);      // by = -1
-        stamp();
-        if (NB == 3) gather_commit(2, q + 1);
-        if (WARP) table_write(q + 2);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gc_item(NB - 1, j, q + 1);
+        if (WARP) table_write(q + 2, fl0, fl1);
         stamp();
         cvm_barrier();
     };
-    cvm_barrier();                                                      // table initialisation
+    if (WARP) {
+        // tables of the first two Q rows
+        float g0, g1;
+        flow_issue(qa, fl0, fl1);
+        flow_issue(qa + 1, g0, g1);
+        table_write(qa, fl0, fl1);
+        table_write(qa + 1, g0, g1);
+    }
+    cvm_barrier();
     {
-        int q = qa - (WARP ? 2 : 1);
+        int q = qa - 1;
         for (;;) {
             step(std::integral_constant<int, 0>{}, q);
             if (++q > pb1) break;

@@ -10,9 +10,11 @@ TF graph.  Inside ``__call__`` the modules' zero-copy ``_run`` forms are compose
     [cv | f0 | flow_up | feat_up] (+ the dense-connection conv outputs when use_dc);
     the cost-volume kernel, the x2 resizes of the previous level and the convs write
     straight into its channel slices, so no tf.concat copy exists;
-  * the `flows_up * scales[l]` multiply (model.py:109) is folded into the warp kernel's
-    flow read; `fuse_warp=True` instead gathers the warp inside the cost-volume kernel
-    (measured slower on MI355X than the streaming warp kernel + LDS-DMA cost volume).
+  * warp + cost volume + the f0 part of the concat are ONE launch per level
+    (pwc_warp_cost_volume_concat_f32, correlation on the matrix pipe; the warped map is never written;
+    the `flows_up * scales[l]` multiply of model.py:109 is folded into the flow read).  The two
+    coarsest levels use the latency-oriented coarse kernel; `concat_cv=False` restores the separate
+    warp + cost-volume launches of rounds 1-2.
 """
 import collections
 
@@ -29,7 +31,7 @@ from .weights import ChannelLayout, SCALES, conv_specs
 class PWCDCNet(object):
     def __init__(self, num_levels=6, search_range=4, warp_type="bilinear", use_dc=False,
                  output_level=4, name="pwcdcnet", seed=0, fuse_warp=False, use_plans=True, winograd=True,
-                 coarse_cv=True, persistent_outputs=False, max_plans=4, streams=1):
+                 coarse_cv=True, persistent_outputs=False, max_plans=4, streams=None, concat_cv=True):
         self.num_levels = num_levels
         self.s_range = search_range
         self.warp_type = warp_type
@@ -39,6 +41,7 @@ class PWCDCNet(object):
         self.name = name
         self.fuse_warp = fuse_warp
         self.coarse_cv = coarse_cv
+        self.concat_cv = concat_cv     # levels with C in {32, 64, 96}: pwc_warp_cost_volume_concat_f32
 
         self.fp_extractor = FeaturePyramidExtractor_custom(self.num_levels)
         self.warp_layer = WarpingLayer(self.warp_type)
@@ -68,13 +71,14 @@ class PWCDCNet(object):
         self._plans = collections.OrderedDict()
         self._buffers = {}     # buffer set of the forward being run (a plan's, or the eager one's)
         self._eager_buffers = collections.OrderedDict()   # use_plans=False: (shape, device, stream) -> buffers
-        # streams > 1 (opt-in): a batch divisible by `streams` is run as that many sub-batches on side HIP streams, so
-        # that the latency-bound coarse levels of one overlap the MFMA-bound layers of another (+4-5 % pairs/s at
-        # batch 8, scripts/exp_two_streams.py).  Same results and the same stream semantics for the caller (the side
-        # streams wait for the caller's stream, the caller's stream waits for them); per-kernel timings lose their
-        # meaning while kernels overlap, which is why it is not the default.
-        self.streams = max(1, int(streams))
-        self.max_plans = max(self.max_plans, self.streams)      # one plan per sub-batch stream of a shape
+        # streams = K > 1: a batch divisible by K is run as K sub-batches on side HIP streams, so that the
+        # latency-bound coarse levels of one overlap the MFMA-bound layers of another (+4-5 % pairs/s at batch 8,
+        # scripts/exp_two_streams.py, profiles/r02_bench_streams2.json).  Same results and the same stream semantics
+        # for the caller (the side streams wait for the caller's stream, the caller's stream waits for them).
+        # streams=None (default): 2 for even batches of at least 4 pairs, 1 otherwise; streams=1 switches it off
+        # (per-kernel timings -- profilers, HIP events on the caller's stream -- need the single-stream form).
+        self.streams = None if streams is None else max(1, int(streams))
+        self.max_plans = max(self.max_plans, 2 * (self.streams or 2))   # a plan per sub-batch stream + the whole-batch one
         self._side_streams = {}
 
     # ------------------------------------------------------------------ variables
@@ -128,7 +132,8 @@ class PWCDCNet(object):
         """(flows_final, flows_pyramid[, pyramid_0]) as reference model.py:95-134.  The returned
         tensors are new on every call unless the model was built with persistent_outputs=True
         (then they are the launch plan's own tensors, overwritten by the next call of that shape)."""
-        k = self.streams
+        n_batch = getattr(images_0, "shape", (0,))[0]
+        k = self.streams if self.streams is not None else (2 if (n_batch >= 4 and n_batch % 2 == 0) else 1)
         if (k > 1 and self.use_plans and not self.persistent_outputs and not with_features and _m._RECORDER is None
                 and getattr(images_0, "shape", (0,))[0] % k == 0 and images_0.shape[0] >= k):
             return self._call_on_side_streams(images_0, images_1, k)
@@ -334,6 +339,14 @@ class PWCDCNet(object):
             # coarse levels: warp + cost volume + the f0 part of the concat in ONE launch
             self.cv_layer._run(f0, f1, cv_out, flow=flow_v, flow_scale=self.scales[l] if l > 0 else 1.0,
                                f0_copy=f0_dst, coarse=True)
+            return
+        if self.concat_cv and (l == 0 or self.warp_type == "bilinear") and \
+                self.cv_layer.concat_ok(f0, f1, cv_out, flow=flow_v, f0_copy=f0_dst):
+            # warp + cost volume + the f0 part of the concat in ONE launch on the matrix pipe; the warped map is
+            # never written.  Channels 81..83 behind the cost volume are layout padding (ChannelLayout starts every
+            # segment on a multiple of 4 channels): the kernel may zero them.
+            self.cv_layer._run(f0, f1, cv_out, flow=flow_v, flow_scale=self.scales[l] if l > 0 else 1.0,
+                               f0_copy=f0_dst, concat=True, out_pad_writable=True)
             return
         copied = False
         if l == 0:

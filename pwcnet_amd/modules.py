@@ -522,15 +522,40 @@ class CostVolumeLayer(_Module):
     def coarse_ok(self, f0):
         return self.s_range == 4 and f0.N * f0.H * f0.W <= self.COARSE_MAX_PIXELS
 
-    def _run(self, f0, f1, out, flow=None, flow_scale=1.0, f0_copy=None, coarse=False):
+    def concat_ok(self, f0, f1, out, flow=None, f0_copy=None):
+        """True if pwc_warp_cost_volume_concat_f32 (matrix-pipe kernel: warp + cost volume + f0 concat copy in one
+        launch) takes this geometry: search range 4, C in {32, 64, 96}, 16-byte aligned operands."""
+        L = _lib.lib()
+        if any(v.ptr % 16 for v in (f0, f1, out)) or (f0_copy is not None and f0_copy.ptr % 16) or \
+                (flow is not None and flow.ptr % 4):
+            return False
+        return bool(L.pwc_warp_cost_volume_concat_supported(f0.H, f0.W, f0.C, self.s_range, f0.cs, f1.cs,
+                                                            flow.cs if flow is not None else 0, out.cs,
+                                                            f0_copy.cs if f0_copy is not None else 0))
+
+    def _run(self, f0, f1, out, flow=None, flow_scale=1.0, f0_copy=None, coarse=False, concat=False, out_pad_writable=False):
         """flow given: f1 is the UN-warped map and the bilinear warp is fused in.
         coarse: one launch of pwc_cost_volume_coarse_f32 (optionally also copying f0 into
-        the `f0_copy` view, the features_0 slice of the estimator input)."""
+        the `f0_copy` view, the features_0 slice of the estimator input).
+        concat: one launch of pwc_warp_cost_volume_concat_f32 (same operands; out_pad_writable: channels 81..83 of
+        `out` are padding the kernel may zero)."""
         L = _lib.lib()
         s = _lib.current_stream()
         D = (2 * self.s_range + 1) ** 2
         npix = f0.N * f0.H * f0.W
         flops = 2.0 * npix * D * f0.C
+        if concat:
+            _launch(L.pwc_warp_cost_volume_concat_f32,
+                    (_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(flow.ptr) if flow is not None else None,
+                     flow.cs if flow is not None else 0, float(flow_scale), _p(out.ptr), out.cs,
+                     1 if out_pad_writable else 0,
+                     _p(f0_copy.ptr) if f0_copy is not None else None, f0_copy.cs if f0_copy is not None else 0,
+                     f0.N, f0.H, f0.W, f0.C, self.s_range, 0.1, s),
+                    "warp_cost_volume_concat" if flow is not None else "cost_volume_concat",
+                    f"cost_volume_mfma_kernel<C{f0.C}{',warp' if flow is not None else ''}>", flops,
+                    # (2C+81) or fused (2C+2+81) bytes per pixel, SURVEY.md 8d; the f0 concat copy is not credited
+                    4.0 * npix * (2 * f0.C + D + (2 if flow is not None else 0)))
+            return
         if coarse:
             assert self.coarse_ok(f0)
             _launch(L.pwc_cost_volume_coarse_f32,

@@ -593,6 +593,117 @@ def test_coarse_cost_volume_kernel_vs_oracle(pa, N, H, W, C, with_flow):
     assert float(E[..., 81:84].min()) == -3.0 and float(E[..., 84 + C:].max()) == -3.0
 
 
+# ------------------------------------------------------------------ matrix-pipe fused kernel (cost_volume_mfma.hip)
+def _run_concat(pa, f0, f1, flow, flow_scale, ecs, copy, pad, fill=-3.0, flow_cs=4):
+    """pwc_warp_cost_volume_concat_f32 into an estimator-style buffer [cv 81 | pad 3 | f0 C | rest]; returns E."""
+    from pwcnet_amd.modules import View, sub_view
+    N, H, W, C = f0.shape
+    g0, g1 = gpu(f0), gpu(f1)
+    fl = None
+    if flow is not None:
+        fl = torch.full((N, H, W, flow_cs), 9.0, device="cuda")
+        fl[..., :2] = gpu(flow)
+    E = torch.full((N, H, W, ecs), fill, device="cuda")
+    Ev = View(E.data_ptr(), ecs, N, H, W, ecs)
+    layer = pa.CostVolumeLayer(4)
+    v0, v1 = View(g0.data_ptr(), C, N, H, W, C), View(g1.data_ptr(), C, N, H, W, C)
+    fv = View(fl.data_ptr(), flow_cs, N, H, W, 2) if fl is not None else None
+    cpy = sub_view(Ev, 84, C) if copy else None
+    assert layer.concat_ok(v0, v1, sub_view(Ev, 0, 81), flow=fv, f0_copy=cpy)
+    layer._run(v0, v1, sub_view(Ev, 0, 81), flow=fv, flow_scale=flow_scale, f0_copy=cpy, concat=True,
+               out_pad_writable=pad)
+    torch.cuda.synchronize()
+    return E, g0
+
+
+@pytest.mark.parametrize("N,H,W,C,with_flow,copy,pad", [
+    (2, 28, 64, 96, True, True, True), (1, 56, 128, 64, True, True, True), (2, 40, 48, 32, True, True, True),
+    (3, 9, 21, 32, True, True, False), (1, 5, 3, 32, True, False, False), (1, 17, 10, 64, False, True, True),
+    (2, 8, 8, 96, True, False, True), (1, 30, 60, 64, True, True, True), (1, 15, 30, 96, False, False, False),
+    (1, 4, 16, 32, True, True, True), (2, 33, 17, 32, False, True, False)])
+def test_concat_cost_volume_kernel_vs_oracle(pa, N, H, W, C, with_flow, copy, pad):
+    """pwc_warp_cost_volume_concat_f32 (correlation on the matrix pipe): warp + cost volume + f0 copy in one launch
+    into channel slices of a wider buffer; ragged block rows / strips (H % 4, W % 16 != 0), single-block images,
+    every supported C, flows with far outliers, every combination of the optional parts.  Nothing outside the
+    declared slices may change."""
+    f0, f1 = rnd((N, H, W, C), 61), rnd((N, H, W, C), 62)
+    flow = util.flow_field(N, H, W, seed=63) / 5.0
+    f1w = orc.warp(f1, flow, "bilinear", flow_scale=5.0) if with_flow else f1
+    exp = orc.cost_volume(f0, f1w, 4)
+    ecs = 84 + C + 8
+    E, g0 = _run_concat(pa, f0, f1, flow if with_flow else None, 5.0, ecs, copy, pad)
+    close(E[..., :81], exp, rel=4e-6, floor=4e-7)
+    if copy:
+        assert torch.equal(E[..., 84:84 + C], g0)
+    else:
+        assert float(E[..., 84:84 + C].max()) == -3.0 and float(E[..., 84:84 + C].min()) == -3.0
+    if pad:
+        assert float(E[..., 81:84].abs().max()) == 0.0
+    else:
+        assert float(E[..., 81:84].min()) == -3.0 and float(E[..., 81:84].max()) == -3.0
+    assert float(E[..., 84 + C:].min()) == -3.0 and float(E[..., 84 + C:].max()) == -3.0
+
+
+def test_concat_cost_volume_known_answers(pa):
+    """Zero flow = plain cost volume; a constant integer flow = the cost volume of the shifted map (edge
+    replication from the warp's clipping, zeros outside from the cost volume's padding); the centre channel is
+    lrelu(mean_c f0 * f1w)."""
+    N, H, W, C = 1, 24, 40, 32
+    f0, f1 = rnd((N, H, W, C), 71), rnd((N, H, W, C), 72)
+    zero = np.zeros((N, H, W, 2), np.float32)
+    E, _ = _run_concat(pa, f0, f1, zero, 5.0, 128, False, True)
+    close(E[..., :81], orc.cost_volume(f0, f1, 4), rel=4e-6, floor=4e-7)
+    flow = zero.copy(); flow[..., 0], flow[..., 1] = 2.0 / 5.0, -3.0 / 5.0
+    shifted = f1[:, np.clip(np.arange(H) - 3, 0, H - 1)][:, :, np.clip(np.arange(W) + 2, 0, W - 1)]
+    E, _ = _run_concat(pa, f0, f1, flow, 5.0, 128, False, True)
+    close(E[..., :81], orc.cost_volume(f0, shifted, 4), rel=4e-6, floor=4e-7)
+    centre = (f0 * shifted).mean(axis=3)
+    centre = np.maximum(centre, 0.1 * centre)
+    close(E[..., 40], centre, rel=4e-6, floor=4e-7)
+
+
+def test_concat_cost_volume_full_size_vs_separate_launches(pa):
+    """BASELINE configs[1] level-4 geometry (8 x 112 x 256 x 32, estimator channel stride 160), flows ~ N(0, 3^2)
+    px with outliers: the one-launch kernel against warp + cost volume as separate launches, every entry."""
+    from pwcnet_amd.modules import View, sub_view
+    N, H, W, C = 8, 112, 256, 32
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    f0 = torch.randn((N, H, W, C), generator=g, device="cuda")
+    f1 = torch.randn((N, H, W, C), generator=g, device="cuda")
+    fl = torch.randn((N, H, W, 2), generator=g, device="cuda") * (3.0 / 5.0)
+    fl[0, 0, 0, 0], fl[0, 0, 0, 1], fl[7, 111, 255, 0] = 60.0, -60.0, -45.0
+    E = torch.zeros((N, H, W, 160), device="cuda")
+    Ev = View(E.data_ptr(), 160, N, H, W, 160)
+    v0, v1 = View(f0.data_ptr(), C, N, H, W, C), View(f1.data_ptr(), C, N, H, W, C)
+    fv = View(fl.data_ptr(), 2, N, H, W, 2)
+    layer = pa.CostVolumeLayer(4)
+    layer._run(v0, v1, sub_view(Ev, 0, 81), flow=fv, flow_scale=5.0, f0_copy=sub_view(Ev, 84, C), concat=True,
+               out_pad_writable=True)
+    f1w = pa.WarpingLayer("bilinear")(f1, fl * 5.0)
+    ref = layer(f0, f1w)
+    assert float((E[..., :81] - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(E[..., 84:116], f0) and float(E[..., 81:84].abs().max()) == 0.0
+    assert float(E[..., 116:].abs().max()) == 0.0
+
+
+def test_concat_cost_volume_rejects_what_it_does_not_support(pa):
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    assert L.pwc_warp_cost_volume_concat_supported(28, 64, 96, 4, 96, 96, 2, 224, 224) == 1
+    assert L.pwc_warp_cost_volume_concat_supported(28, 64, 128, 4, 128, 128, 2, 224, 224) == 0     # C
+    assert L.pwc_warp_cost_volume_concat_supported(28, 64, 32, 3, 32, 32, 2, 160, 160) == 0        # search range
+    assert L.pwc_warp_cost_volume_concat_supported(28, 64, 32, 4, 32, 32, 2, 81, 0) == 0           # out_cs % 4
+    x = torch.zeros((1, 8, 8, 128), device="cuda")
+    out = torch.zeros((1, 8, 8, 84), device="cuda")
+    rc = L.pwc_warp_cost_volume_concat_f32(_p(x), 128, _p(x), 128, None, 0, 1.0, _p(out), 84, 1, None, 0,
+                                           1, 8, 8, 128, 4, 0.1, None)
+    assert rc == -4
+    y = torch.zeros((1, 8, 8, 32), device="cuda")
+    rc = L.pwc_warp_cost_volume_concat_f32(_p(y), 32, _p(y), 32, None, 0, 1.0, _p(out), 84, 1, None, 0,
+                                           1, 8, 8, 32, 2, 0.1, None)
+    assert rc == -4
+
+
 def test_coarse_cost_volume_rejects_other_search_ranges(pa):
     from pwcnet_amd import _lib
     L = _lib.lib()
