@@ -184,6 +184,20 @@ int pwc_conv3x3_wino_f32(const float* x, int x_cs, const float* packed_u, const 
                          float* y, int y_cs, int N, int H, int W, int Cin_phys, int Cout,
                          int dilation, int apply_act, float slope, pwc_stream_t stream);
 long pwc_conv3x3_wino_workgroups(int N, int H, int W, int Cout, int dilation);
+/* Winograd F(4x4,3x3) form of the same convolution (csrc/conv3x3_wino4.hip): 36 multiplies per 4x4 outputs instead
+ * of 64, for the big full-resolution layers (modules.py:267-268 `optflow_4/conv2d..conv2d_2`, modules.py:308-316
+ * `context/conv2d_1..conv2d_3`).  fp32 throughout; its rounding error is ~10x that of F(2x2) per layer (2e-6 of the
+ * activation scale) and leaves the end-to-end flow error where a direct fp32 convolution puts it (profiles/
+ * r03_f4x4_numerics.txt).  packed_u comes from pwc_conv3x3_wino4_pack_f32 ([36][Cin_phys/16][Cout_pad][16] floats).
+ * Needs Cout % 32 == 0, Cin_phys % 16 == 0, y 16-byte aligned with y_cs % 4 == 0.  pwc_conv3x3_wino4_supported: 1
+ * where it is the faster kernel for the shape (large launches with Cin_phys >= 128, Cout >= 96), 0 otherwise. */
+size_t pwc_conv3x3_wino4_packed_floats(int Cin_phys, int Cout);
+int pwc_conv3x3_wino4_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin, int Cin_phys,
+                               int Cout, float* packed_u, pwc_stream_t stream);
+int pwc_conv3x3_wino4_f32(const float* x, int x_cs, const float* packed_u, const float* bias,
+                          float* y, int y_cs, int N, int H, int W, int Cin_phys, int Cout,
+                          int dilation, int apply_act, float slope, pwc_stream_t stream);
+int pwc_conv3x3_wino4_supported(int N, int H, int W, int Cin_phys, int Cout, int dilation);
 /* The same convolution with the input-channel stages dealt to `csplit` workgroups per tile (launches that would leave
  * most of the GPU's workgroup slots empty: the 14x32 / 28x64 pyramid levels).  Partial outputs go to `workspace`
  * (pwc_conv3x3_wino_split_workspace_floats floats, 16-byte aligned) and are summed in a fixed order, with the bias and the

@@ -625,3 +625,5 @@ static int wino_run(const float* x, int x_cs, const float* packed_u, const float
     }
     return pwc_launch_status();
 }
+
+#include "conv3x3_wino4.hip"   // F(4x4, 3x3) variant for the big full-resolution layers (same translation unit)

@@ -12,13 +12,17 @@
 // layers changes the flow error by x1.0 - 1.4 -- the level of the direct fp32 convolution (profiles/
 // r03_f4x4_numerics.txt).  U = G g G^T is computed in double and rounded once.
 //
-// Work decomposition (256 threads = 4 waves, ONE workgroup per CU: 144 accumulator + ~150 working registers):
+// Work decomposition (512 threads = 8 waves, ONE workgroup per CU, two waves per SIMD):
 //   workgroup = 4 x 8 Winograd tiles (16 x 32 output pixels) x 32 output channels;
 //   wave      = (tile group g: tile rows 2g, 2g+1 = 16 tiles = one MFMA column block;
-//                position half h: rows a = 3h .. 3h+2 of the 6 x 6 transformed tile = 18 of the 36 positions)
-//               x both 16-cout MFMA tiles: 18 x 2 accumulator tiles.  Splitting the POSITIONS over two waves
+//                position half h: rows a = 3h .. 3h+2 of the 6 x 6 transformed tile = 18 of the 36 positions;
+//                cout tile nt of 16): 18 accumulator tiles = 72 registers.  Splitting the POSITIONS over waves
 //               halves the accumulators AND the input-transform work per wave (the row pass produces 3 of 6 rows);
-//               the price is that both waves read the raw 6 x 6 patch from LDS.
+//               splitting the cout tiles too brings a wave under 256 registers, so that two waves share a SIMD and
+//               one's transforms, LDS reads and DMA issue run under the other's MFMAs (the first version -- 4 waves
+//               with both cout tiles, 364 registers, one wave per SIMD -- spent 164 us outside the MFMAs and 123 us
+//               in them, one after the other: 256 us against 286 us for F(2x2) on the 128 -> 128 layer).  The price:
+//               the two cout-tile waves of a (g, h) pair both read and transform the raw 6 x 6 patch.
 //   lane      = (tile j = lane & 15, k-slot q = lane >> 4): reads the 6 x 6 input pixels of its tile for channels
 //               4q..4q+3 (36 ds_read_b128), transforms them IN REGISTERS -- the result is the MFMA B-operand
 //               fragment V_xi[k = 4q+s][tile j] -- and at the end holds its 18 x 2 M_xi: the column pass of the
@@ -31,6 +35,7 @@
 //   the next stage as soon as they have been read.
 #pragma once
 #include "pwc_common.h"
+#include <type_traits>
 
 struct Wino4Args {
     const float* x;
@@ -50,11 +55,12 @@ struct Wino4Args {
 constexpr unsigned W4_OOB = 0x7FFF0000u;
 constexpr int W4_PS = 36;                    // patch records per patch row: 4 quarter rows (px & 3) of 9 (px >> 2)
 constexpr int W4_PH = 18, W4_PW = 34;
-constexpr int W4_NBP = 44;                   // 16-record DMA blocks of the patch (648 records used of 704)
+constexpr int W4_NW = 8, W4_T = 64 * W4_NW;
+constexpr int W4_NBP = 48;                   // 16-record DMA blocks of the patch (648 records used of 768): 6 per wave
 constexpr int W4_PREC = W4_NBP * 16;
 constexpr int W4_NBU = 72;                   // 16-row DMA blocks of the weights: 36 positions x 32 couts
-constexpr int W4_STAGE = (W4_PREC + W4_NBU * 16) * 16;     // floats per LDS stage: 118 784 B
-constexpr int W4_XCH = 4 * 64 * 68;          // floats of the output exchange (4 waves x 64 lanes x (64 + 4 pad)): 69 632 B
+constexpr int W4_STAGE = (W4_PREC + W4_NBU * 16) * 16;     // floats per LDS stage: 122 880 B
+constexpr int W4_XCH = W4_NW * 64 * 36;      // floats of the output exchange (8 waves x 64 lanes x (32 + 4 pad)): 73 728 B
 static_assert(W4_XCH <= W4_STAGE, "the exchange reuses the stage buffer");
 
 __device__ __forceinline__ int w4_wswz(int row) { return (4 - ((row >> 2) & 3)) & 3; }   // weight rows (as conv3x3_wino.hip)
@@ -65,8 +71,10 @@ __device__ __forceinline__ int w4_wswz(int row) { return (4 - ((row >> 2) & 3)) 
 // slots of a 256-byte bank row exactly once.
 __device__ __forceinline__ int w4_pswz(int py) { return ((py >> 2) & 1) << 1; }
 
+// ABL (scripts/exp_wino4.hip only; 0 in the library): 1 = no patch DMA, 2 = no weight DMA, 4 = no MFMA, 64 = no
+// transform arithmetic
 template <int ABL = 0>
-__global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const Wino4Args a) {
+__global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args a) {
     typedef __attribute__((address_space(3))) void* lptr_t;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const Wino4Args a
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int g = wave >> 1, h = wave & 1;          // tile group, position half
+    const int g = wave >> 2, h = (wave >> 1) & 1, nt = wave & 1;   // tile group, position half, cout tile
     const int fr = lane & 15, fq = lane >> 4;
     const int trl = fr >> 3, tc = fr & 7;           // tile (2g + trl, tc)
     float m1s;
@@ -106,11 +114,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const Wino4Args a
         (void*)(a.x + (size_t)n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
 
     // ---- LDS-DMA bookkeeping: per-lane byte offsets fixed over the channel loop, the stage in the scalar offset
-    constexpr int PPW = W4_NBP / 4;                 // patch blocks per wave (11)
+    constexpr int PPW = W4_NBP / W4_NW;             // patch blocks per wave (6)
     unsigned p_voff[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-        const int rec = (wave + 4 * i) * 16 + (lane >> 2);
+        const int rec = (wave + W4_NW * i) * 16 + (lane >> 2);
         const int py = rec / W4_PS, rem = rec - py * W4_PS;
         const int q = rem / 9, ci = rem - q * 9;
         const int px = 4 * ci + q;
@@ -119,8 +127,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const Wino4Args a
         const bool ok = py < W4_PH && px < W4_PW && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
         p_voff[i] = ok ? (unsigned)(((yy * a.W + xx) * a.x_cs + ch * 4) * 4) : W4_OOB;
     }
-    // weights: wave w fetches cout tile (w & 1) of positions 18 (w >> 1) + 9 P + i, i = 0..8, for part P
-    const int u_xi0 = 18 * (wave >> 1), u_sub = wave & 1;
+    // weights, in three parts P of 6 positions per half: wave w fetches cout tile (w & 1) of positions
+    // 18 ((w >> 1) & 1) + 6 P + 3 (w >> 2) + i, i = 0..2
+    const int u_xi0 = 18 * ((wave >> 1) & 1) + 3 * (wave >> 2), u_sub = wave & 1;
     const int u_co = n0 + u_sub * 16 + (lane >> 2);
     const unsigned u_voff = (u_co < Cout_pad) ? (unsigned)((((u_xi0 * nc16) * Cout_pad + u_co) * 16 + (lane & 3) * 4) * 4) : W4_OOB;
     const int u_step = nc16 * Cout_pad * 64;        // bytes between consecutive positions
@@ -128,17 +137,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const Wino4Args a
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             if (!(ABL & 1))
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(smem + (wave + 4 * i) * 256), 16, (int)p_voff[i],
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(smem + (wave + W4_NW * i) * 256), 16, (int)p_voff[i],
                                                          c16 * 64, 0, 0);
     };
     auto issue_u = [&](int c16, int part) {
         const int us = c16 * Cout_pad * 64;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int xi = u_xi0 + 9 * part + i;    // uniform
+        for (int i = 0; i < 3; ++i) {
+            const int xi = u_xi0 + 6 * part + i;    // uniform
             if (!(ABL & 2))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lptr_t)(smem + (W4_NBP + xi * 2 + u_sub) * 256), 16,
-                                                         (int)u_voff, us + (9 * part + i) * u_step, 0, 0);
+                                                         (int)u_voff, us + (6 * part + i) * u_step, 0, 0);
         }
     };
 #define W4_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
@@ -148,161 +157,176 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const Wino4Args a
     const int trow = 2 * g + trl;
     const float* pb_lo = smem + ((4 * trow) * W4_PS + tc) * 16 + ((fq ^ w4_pswz(4 * trow)) << 2);
     const float* pb_hi = smem + ((4 * trow) * W4_PS + tc) * 16 + ((fq ^ w4_pswz(4 * trow + 4)) << 2);
-    const int u_off = W4_PREC * 16 + fr * 16 + ((fq ^ w4_wswz(fr)) << 2);   // A-fragment row fr of a 16-row tile
+    const int u_off = W4_PREC * 16 + ((18 * h) * 32 + nt * 16 + fr) * 16 + ((fq ^ w4_wswz(fr)) << 2);   // this wave's A-fragment rows
 
-    f32x4 acc[18][2];
+    f32x4 acc[18];
     auto stage = [&](auto first, int c16) {
         constexpr bool FIRST = decltype(first)::value;
         const bool has_next = c16 + 1 < nc16;
-        W4_WAIT_VM(9);                               // patch(c) landed (weight part 0 of c may be in flight)
-        __syncthreads();                             // ... for every wave; part 1 of c-1 fully read
-        issue_u(c16, 1);
+        // in flight here (oldest first): patch(c), weight parts 0 and 1 of c
+        W4_WAIT_VM(6);                               // patch(c) landed
+        __syncthreads();                             // ... for every wave; part 2 of c-1 fully read
+        issue_u(c16, 2);
 
-        // ---- input transform, this wave's three rows a = 3h .. 3h+2 of  V = B^T d B
+        // ---- input transform, this wave's three rows a = 3h .. 3h+2 of  V = B^T d B  (both cout-tile waves of a
+        // (tile group, half) pair do it: the registers it would take to hand V over do not exist)
         //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-        f32x4 T[3][6];
+        f32x4 V[3][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {                // row pass, column j of the window
             f32x4 dd[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i)
                 dd[i] = *reinterpret_cast<const f32x4*>((i < 4 ? pb_lo : pb_hi) + (i * W4_PS + (j & 3) * 9 + (j >> 2)) * 16);
-            if (h == 0) {
-                T[0][j] = W4FMA(dd[0], 4.f, W4FMA(dd[2], -5.f, dd[4]));
+            if (ABL & 64) {                          // (ablation: no transform arithmetic)
+                V[0][j] = dd[0] + dd[3]; V[1][j] = dd[1] + dd[4]; V[2][j] = dd[2] + dd[5];
+            } else if (h == 0) {
+                V[0][j] = W4FMA(dd[0], 4.f, W4FMA(dd[2], -5.f, dd[4]));
                 const f32x4 s = dd[1] + dd[2], tt = dd[3] + dd[4], u = W4SUB(dd[1], dd[2]), v = W4SUB(dd[4], dd[3]);
-                T[1][j] = W4FMA(s, -4.f, tt);
-                T[2][j] = W4FMA(u, 4.f, v);
+                V[1][j] = W4FMA(s, -4.f, tt);
+                V[2][j] = W4FMA(u, 4.f, v);
             } else {
                 const f32x4 p = W4SUB(dd[4], dd[2]), q = W4SUB(dd[3], dd[1]);
-                T[0][j] = W4FMA(q, 2.f, p);
-                T[1][j] = W4FMA(q, -2.f, p);
-                T[2][j] = W4FMA(dd[1], 4.f, W4FMA(dd[3], -5.f, dd[5]));
+                V[0][j] = W4FMA(q, 2.f, p);
+                V[1][j] = W4FMA(q, -2.f, p);
+                V[2][j] = W4FMA(dd[1], 4.f, W4FMA(dd[3], -5.f, dd[5]));
             }
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) asm("" : "+v"(T[r][j]));      // keep the packed ops (see conv3x3_wino.hip)
-        f32x4 V[3][6];
+            for (int j = 0; j < 6; ++j) asm("" : "+v"(V[r][j]));      // keep the packed ops (see conv3x3_wino.hip)
+        if (!(ABL & 64)) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {                // column pass
-            const f32x4 e0 = T[r][0], e1 = T[r][1], e2 = T[r][2], e3 = T[r][3], e4 = T[r][4], e5 = T[r][5];
-            const f32x4 s = e1 + e2, tt = e3 + e4, u = W4SUB(e1, e2), v = W4SUB(e4, e3);
-            const f32x4 p = W4SUB(e4, e2), q = W4SUB(e3, e1);
-            V[r][0] = W4FMA(e0, 4.f, W4FMA(e2, -5.f, e4));
-            V[r][1] = W4FMA(s, -4.f, tt);
-            V[r][2] = W4FMA(u, 4.f, v);
-            V[r][3] = W4FMA(q, 2.f, p);
-            V[r][4] = W4FMA(q, -2.f, p);
-            V[r][5] = W4FMA(e1, 4.f, W4FMA(e3, -5.f, e5));
+            for (int r = 0; r < 3; ++r) {            // column pass, in place
+                const f32x4 e0 = V[r][0], e1 = V[r][1], e2 = V[r][2], e3 = V[r][3], e4 = V[r][4], e5 = V[r][5];
+                const f32x4 s = e1 + e2, tt = e3 + e4, u = W4SUB(e1, e2), v = W4SUB(e4, e3);
+                const f32x4 p = W4SUB(e4, e2), q = W4SUB(e3, e1);
+                V[r][0] = W4FMA(e0, 4.f, W4FMA(e2, -5.f, e4));
+                V[r][1] = W4FMA(s, -4.f, tt);
+                V[r][2] = W4FMA(u, 4.f, v);
+                V[r][3] = W4FMA(q, 2.f, p);
+                V[r][4] = W4FMA(q, -2.f, p);
+                V[r][5] = W4FMA(e1, 4.f, W4FMA(e3, -5.f, e5));
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) asm("" : "+v"(V[r][j]));
         }
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) asm("" : "+v"(V[r][j]));
 
-        // ---- 18 positions x 2 cout tiles x 4 k-steps of MFMA, in two parts of 9 positions
+        // ---- 18 positions x 4 k-steps of MFMA in three parts of 6 positions; two positions alternate (a dependent
+        // 16x16x4 MFMA would wait 8 cycles for its accumulator)
         auto mfma_part = [&](int part) {
 #pragma unroll
-            for (int xl = 9 * part; xl < 9 * part + 9; ++xl) {
+            for (int xp = 6 * part; xp < 6 * part + 6; xp += 2) {
                 f32x4 wf[2];
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    wf[nt] = *reinterpret_cast<const f32x4*>(smem + u_off + ((18 * h + xl) * 32 + nt * 16) * 16);
+                for (int e = 0; e < 2; ++e) wf[e] = *reinterpret_cast<const f32x4*>(smem + u_off + (xp + e) * 32 * 16);
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
-                    const int k = kk >> 1, nt = kk & 1;
+                    const int k = kk >> 1, xl = xp + (kk & 1);
                     if (ABL & 4) {
-                        if (FIRST && k == 0) acc[xl][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        asm volatile("" ::"v"(wf[nt][k]), "v"(V[xl / 6][xl % 6][k]));
+                        if (FIRST && k == 0) acc[xl] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        asm volatile("" ::"v"(wf[kk & 1][k]), "v"(V[xl / 6][xl % 6][k]));
                         continue;
                     }
-                    const f32x4 c = (FIRST && k == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[xl][nt];
-                    acc[xl][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][k], V[xl / 6][xl % 6][k], c, 0, 0, 0);
+                    const f32x4 c = (FIRST && k == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[xl];
+                    acc[xl] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kk & 1][k], V[xl / 6][xl % 6][k], c, 0, 0, 0);
                 }
             }
         };
-        W4_WAIT_VM(9);                               // weight part 0 of c landed (part 1 may be in flight)
+        W4_WAIT_VM(6);                               // weight part 0 of c landed (parts 1, 2 may be in flight)
         __syncthreads();                             // ... for every wave; patch(c) fully read
         if (has_next) issue_patch(c16 + 1);
         mfma_part(0);
-        if (has_next) W4_WAIT_VM(PPW); else W4_WAIT_VM(0);   // part 1 of c landed (patch(c+1) may be in flight)
-        __syncthreads();                             // ... for every wave; part 0 of c fully read
+        if (has_next) W4_WAIT_VM(3 + PPW); else W4_WAIT_VM(3);   // part 1 landed (part 2, patch(c+1) may be in flight)
+        __syncthreads();                             // ... for every wave; part 0 fully read
         if (has_next) issue_u(c16 + 1, 0);
         mfma_part(1);
+        if (has_next) W4_WAIT_VM(PPW + 3); else W4_WAIT_VM(0);   // part 2 landed (patch(c+1), part 0 of c+1 may be in flight)
+        __syncthreads();                             // ... for every wave; part 1 fully read
+        if (has_next) issue_u(c16 + 1, 1);
+        mfma_part(2);
     };
     issue_patch(0);
     issue_u(0, 0);
+    issue_u(0, 1);
     stage(std::true_type{}, 0);
     for (int c16 = 1; c16 < nc16; ++c16) stage(std::false_type{}, c16);
 
     // ---- output transform  Y = A^T M A,  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].
-    // Column pass (over b) on this wave's three rows a, then the partial row pass; the other half's partial sums
-    // come through LDS: wave h keeps cout tile h and sends cout tile 1 - h.
-    f32x4 Yp[2][4][4];                              // [nt][i'][j'] partial sums over a in this half
+    // Column pass (over b) on this wave's three rows a, then the partial row pass; the other half's partial sums come
+    // through LDS: wave h finishes output rows 2h, 2h+1 of the tile and sends the partials of the other two.
+    // (h is wave-uniform; the two halves are separate instantiations so that every array index is static)
+    auto epilogue = [&](auto h_c) {
+        constexpr int HH = decltype(h_c)::value;
+        f32x4 Yp[4][4];                             // [i'][j'] partial sums over a in this half
+        {
+            f32x4 Z[3][4];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        f32x4 Z[3][4];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const f32x4 m0 = acc[r * 6 + 0][nt], m1 = acc[r * 6 + 1][nt], m2 = acc[r * 6 + 2][nt];
-            const f32x4 m3 = acc[r * 6 + 3][nt], m4 = acc[r * 6 + 4][nt], m5 = acc[r * 6 + 5][nt];
-            const f32x4 s12 = m1 + m2, d12 = W4SUB(m1, m2), s34 = m3 + m4, d34 = W4SUB(m3, m4);
-            Z[r][0] = m0 + s12 + s34;
-            Z[r][1] = W4FMA(d34, 2.f, d12);
-            Z[r][2] = W4FMA(s34, 4.f, s12);
-            Z[r][3] = W4FMA(d34, 8.f, d12) + m5;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (h == 0) {                            // a = 0, 1, 2: columns [1 1 1], [0 1 -1], [0 1 1], [0 1 -1] of A^T
-                const f32x4 s = Z[1][j] + Z[2][j], dd = W4SUB(Z[1][j], Z[2][j]);
-                Yp[nt][0][j] = Z[0][j] + s;
-                Yp[nt][1][j] = dd;
-                Yp[nt][2][j] = s;
-                Yp[nt][3][j] = dd;
-            } else {                                 // a = 3, 4, 5: [1 1 0], [2 -2 0], [4 4 0], [8 -8 1]
-                const f32x4 s = Z[0][j] + Z[1][j], dd = W4SUB(Z[0][j], Z[1][j]);
-                Yp[nt][0][j] = s;
-                Yp[nt][1][j] = dd * 2.f;
-                Yp[nt][2][j] = s * 4.f;
-                Yp[nt][3][j] = W4FMA(dd, 8.f, Z[2][j]);
+            for (int r = 0; r < 3; ++r) {
+                const f32x4 m0 = acc[r * 6 + 0], m1 = acc[r * 6 + 1], m2 = acc[r * 6 + 2];
+                const f32x4 m3 = acc[r * 6 + 3], m4 = acc[r * 6 + 4], m5 = acc[r * 6 + 5];
+                const f32x4 s12 = m1 + m2, d12 = W4SUB(m1, m2), s34 = m3 + m4, d34 = W4SUB(m3, m4);
+                Z[r][0] = m0 + s12 + s34;
+                Z[r][1] = W4FMA(d34, 2.f, d12);
+                Z[r][2] = W4FMA(s34, 4.f, s12);
+                Z[r][3] = W4FMA(d34, 8.f, d12) + m5;
             }
-        }
-    }
-    __syncthreads();                                 // every wave is past its last LDS read of the stage
-    {
-        // exchange: wave (g, h) writes its cout tile 1-h partials to the slot of wave (g, 1-h); 16 f32x4 per lane,
-        // lane-major with a 4-float pad per lane row group (64 + 4 floats per lane: conflict-free b128 accesses)
-        float* dst = smem + ((g * 2 + (1 - h)) * 64 + lane) * 68;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + (i * 4 + j) * 4) = Yp[1 - h][i][j];
-    }
-    __syncthreads();
-    const float* src = smem + (wave * 64 + lane) * 68;
-    const int co = n0 + h * 16 + fq * 4;
-    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.y + (size_t)n * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
-    if (co < a.Cout) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + co);
-        const int py0 = ry + d * (y0 + 4 * trow), px0 = rx + d * (x0 + 4 * tc);     // real coordinates of output (0,0)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x4 yv = Yp[h][i][j] + *reinterpret_cast<const f32x4*>(src + (i * 4 + j) * 4) + b4;
-                if (a.apply_act) {                   // tf.nn.leaky_relu = max(v, slope * v)
-                    const f32x4 sv = yv * a.slope;
-                    yv[0] = fmaxf(yv[0], sv[0]); yv[1] = fmaxf(yv[1], sv[1]);
-                    yv[2] = fmaxf(yv[2], sv[2]); yv[3] = fmaxf(yv[3], sv[3]);
+                if (HH == 0) {                       // a = 0, 1, 2: columns [1 1 1], [0 1 -1], [0 1 1], [0 1 -1] of A^T
+                    const f32x4 s = Z[1][j] + Z[2][j], dd = W4SUB(Z[1][j], Z[2][j]);
+                    Yp[0][j] = Z[0][j] + s;
+                    Yp[1][j] = dd;
+                    Yp[2][j] = s;
+                    Yp[3][j] = dd;
+                } else {                             // a = 3, 4, 5: [1 1 0], [2 -2 0], [4 4 0], [8 -8 1]
+                    const f32x4 s = Z[0][j] + Z[1][j], dd = W4SUB(Z[0][j], Z[1][j]);
+                    Yp[0][j] = s;
+                    Yp[1][j] = dd * 2.f;
+                    Yp[2][j] = s * 4.f;
+                    Yp[3][j] = W4FMA(dd, 8.f, Z[2][j]);
                 }
-                const int py = py0 + i * d, px = px0 + j * d;
-                const unsigned vo = (py < a.H && px < a.W) ? (unsigned)(((py * a.W + px) * a.y_cs + co) * 4) : W4_OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yv), yrsrc, (int)vo, 0, 0);
             }
-    }
+        }
+        __syncthreads();                             // every wave is past its last LDS read of the stage
+        {
+            // exchange with the wave of the other half (same tile group, same cout tile = wave ^ 2): 8 f32x4 per lane,
+            // 32 + 4 floats per lane (conflict-free b128 accesses)
+            float* dst = smem + ((wave ^ 2) * 64 + lane) * 36;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + (i * 4 + j) * 4) = Yp[2 * (1 - HH) + i][j];
+        }
+        __syncthreads();
+        const float* src = smem + (wave * 64 + lane) * 36;
+        const int co = n0 + nt * 16 + fq * 4;
+        const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.y + (size_t)n * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
+        if (co < a.Cout) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + co);
+            const int py0 = ry + d * (y0 + 4 * trow + 2 * HH), px0 = rx + d * (x0 + 4 * tc);   // real coordinates of this wave's first output
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 yv = Yp[2 * HH + i][j] + *reinterpret_cast<const f32x4*>(src + (i * 4 + j) * 4) + b4;
+                    if (a.apply_act) {               // tf.nn.leaky_relu = max(v, slope * v)
+                        const f32x4 sv = yv * a.slope;
+                        yv[0] = fmaxf(yv[0], sv[0]); yv[1] = fmaxf(yv[1], sv[1]);
+                        yv[2] = fmaxf(yv[2], sv[2]); yv[3] = fmaxf(yv[3], sv[3]);
+                    }
+                    const int py = py0 + i * d, px = px0 + j * d;
+                    const unsigned vo = (py < a.H && px < a.W) ? (unsigned)(((py * a.W + px) * a.y_cs + co) * 4) : W4_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yv), yrsrc, (int)vo, 0, 0);
+                }
+        }
+    };
+    if (h == 0) epilogue(std::integral_constant<int, 0>{});
+    else epilogue(std::integral_constant<int, 1>{});
 #undef W4SUB
 #undef W4FMA
 #undef W4_WAIT_VM
@@ -360,11 +384,15 @@ extern "C" int pwc_conv3x3_wino4_pack_f32(const float* w_hwio, const int32_t* ci
     return pwc_launch_status();
 }
 
-// F(4x4) pays where the launch fills the GPU with 16 x 32-pixel blocks and the channel loop is long enough to
-// amortise the larger transforms: Cin_phys >= 64, Cout % 32 == 0, at least 256 workgroups, sub-lattices of at least
-// 14 rows (d = 16 on the 112-row level leaves 7-row sub-lattices: conv3x3_wino.hip's SPLIT geometry keeps those).
+// Where F(4x4) pays (measured against conv3x3_wino.hip: scripts/exp_wino4.hip on isolated layers, profiles/
+// r03_exp_wino4.txt, and in the forward, profiles/r03_timeline_batch8.txt): launches that fill the GPU with 16 x 32-pixel
+// blocks and whose channel loop is long -- undilated layers with Cin_phys >= 128 and Cout >= 128 (307 vs 323, 248 vs 267,
+// 103 vs 114, 70 vs 81 us), and the d = 8 layer whose 14 x 32 sub-lattices fill F(2x2)'s 16 x 16 blocks badly (208 vs 227
+// us).  128 -> 96 undilated and the d = 2, 4 layers are level or slower in the forward and stay on F(2x2); so do 7-row
+// sub-lattices (d = 16: conv3x3_wino.hip's SPLIT geometry) and launches of fewer than 256 workgroups.
 extern "C" int pwc_conv3x3_wino4_supported(int N, int H, int W, int Cin_phys, int Cout, int dilation) {
-    if (N <= 0 || H <= 0 || W <= 0 || dilation < 1 || Cin_phys < 64 || (Cin_phys % 16) || Cout < 64 || (Cout % 32)) return 0;
+    if (N <= 0 || H <= 0 || W <= 0 || dilation < 1 || Cin_phys < 128 || (Cin_phys % 16) || Cout < 96 || (Cout % 32)) return 0;
+    if (!((dilation == 1 && Cout >= 128) || dilation >= 8)) return 0;
     const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
     if (hs < 14 || ws < 28) return 0;
     const long blocks = (long)N * dilation * dilation * ((hs + 15) / 16) * ((ws + 31) / 32) * (Cout / 32);
@@ -373,14 +401,14 @@ extern "C" int pwc_conv3x3_wino4_supported(int N, int H, int W, int Cin_phys, in
 }
 
 template <int ABL>
-static int wino4_launch(Wino4Args& a, hipStream_t stream) {
+static int wino4_launch(const Wino4Args& a, hipStream_t stream) {
     const size_t lds = (size_t)W4_STAGE * sizeof(float);
     static PwcDevOnce attr_once;   // the attribute is per device
     if (pwc_first_on_device(&attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel<ABL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    hipLaunchKernelGGL((conv3x3_wino4_kernel<ABL>), dim3((unsigned)a.ntiles), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv3x3_wino4_kernel<ABL>), dim3((unsigned)a.ntiles), dim3(W4_T), lds, stream, a);
     return pwc_launch_status();
 }
 

@@ -31,7 +31,7 @@ from .weights import ChannelLayout, SCALES, conv_specs
 class PWCDCNet(object):
     def __init__(self, num_levels=6, search_range=4, warp_type="bilinear", use_dc=False,
                  output_level=4, name="pwcdcnet", seed=0, fuse_warp=False, use_plans=True, winograd=True,
-                 coarse_cv=True, persistent_outputs=False, max_plans=4, streams=None, concat_cv=True):
+                 coarse_cv=True, persistent_outputs=False, max_plans=4, streams=None, concat_cv=True, winograd4=True):
         self.num_levels = num_levels
         self.s_range = search_range
         self.warp_type = warp_type
@@ -54,6 +54,7 @@ class PWCDCNet(object):
 
         for mod in [self.fp_extractor, self.context] + self.of_estimators:
             mod.winograd = bool(winograd)
+            mod.winograd4 = bool(winograd4)
         _lib.lib()  # fail now, loudly, if the HIP library is missing
         self.store = VariableStore(seed=seed)
         # launch plans (one per input shape, device, stream): the forward is recorded once and
@@ -78,7 +79,6 @@ class PWCDCNet(object):
         # streams=None (default): 2 for even batches of at least 4 pairs, 1 otherwise; streams=1 switches it off
         # (per-kernel timings -- profilers, HIP events on the caller's stream -- need the single-stream form).
         self.streams = None if streams is None else max(1, int(streams))
-        self.max_plans = max(self.max_plans, 2 * (self.streams or 2))   # a plan per sub-batch stream + the whole-batch one
         self._side_streams = {}
 
     # ------------------------------------------------------------------ variables
@@ -134,6 +134,8 @@ class PWCDCNet(object):
         (then they are the launch plan's own tensors, overwritten by the next call of that shape)."""
         n_batch = getattr(images_0, "shape", (0,))[0]
         k = self.streams if self.streams is not None else (2 if (n_batch >= 4 and n_batch % 2 == 0) else 1)
+        if k > 1:
+            self.max_plans = max(self.max_plans, k + 1)     # a plan per sub-batch stream + the whole-batch one
         if (k > 1 and self.use_plans and not self.persistent_outputs and not with_features and _m._RECORDER is None
                 and getattr(images_0, "shape", (0,))[0] % k == 0 and images_0.shape[0] >= k):
             return self._call_on_side_streams(images_0, images_1, k)

@@ -404,6 +404,31 @@ def test_e2e_large_flows_vs_oracle(pa, gain, use_dc):
     assert err <= 1e-3
 
 
+def test_f4x4_layers_leave_the_flows_where_f2x2_puts_them(pa):
+    """BASELINE configs[1] batch: the big level-4 convs run on Winograd F(4x4,3x3) (pwc_conv3x3_wino4_f32); with
+    winograd4=False they run on F(2x2).  Flows of a few pixels (kernel gain 1.3): the two forwards must agree far
+    inside the 1e-3 px bound, and pair 0 must meet the oracle."""
+    w = util.model_weights(False, gain=1.3)
+    im0, im1 = util.smooth_images(8, 448, 1024, seed=95, shift=(-4, 3))
+    net4 = pa.PWCDCNet(streams=1)
+    net4.load_weights(w)
+    net2 = pa.PWCDCNet(streams=1, winograd4=False)
+    net2.load_weights(w)
+    from pwcnet_amd.profiler import OpTimer
+    t = OpTimer()
+    with t:
+        a, pyr_a = net4(gpu(im0), gpu(im1))
+    assert any(k.startswith("conv3x3_wino4") for k in t.summary()), sorted(t.summary())
+    b, pyr_b = net2(gpu(im0), gpu(im1))
+    mag = float(b.abs().max())
+    assert mag >= 1.0, mag
+    assert float((a - b).abs().max()) <= 1e-4, float((a - b).abs().max())
+    e_final, _ = orc.OraclePWCDCNet(w)(im0[:1], im1[:1])
+    err = float(np.abs(a[:1].cpu().numpy() - e_final).max())
+    print(f"F(4x4) layers: max |flow| {mag:.2f} px, vs F(2x2) {float((a - b).abs().max()):.2e}, vs oracle {err:.2e}")
+    assert err <= 1e-3 / 3, err
+
+
 def test_channel_split_launches_do_not_change_the_flows(pa, monkeypatch):
     """The coarse estimator levels run their Winograd convs with the channel loop dealt to several workgroups
     (pwc_conv3x3_wino_split_f32); with the split disabled the forward must give the same flows up to fp32 summation order."""

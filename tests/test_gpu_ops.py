@@ -173,6 +173,65 @@ def test_conv_winograd_dilated_vs_oracle(pa, N, H, W, cin, cout, dil):
     close(run_conv_wino(x, k, b, 0.1, dil=dil), orc.conv3x3(x, k, b, 1, dil, 0.1), rel=2e-5)
 
 
+def run_conv_wino4(x, k, b, slope, cin_map=None, y_cs=None, dil=1):
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    N, H, W, cs = x.shape
+    cin, cout = k.shape[2], k.shape[3]
+    xg, kg, bg = gpu(x), gpu(k), gpu(b)
+    packed = torch.empty(L.pwc_conv3x3_wino4_packed_floats(cs, cout), device="cuda")
+    cm = None if cin_map is None else torch.from_numpy(np.asarray(cin_map, np.int32)).cuda()
+    _lib.check(L.pwc_conv3x3_wino4_pack_f32(_p(kg), _p(cm) if cm is not None else None, cin, cs, cout, _p(packed), None))
+    y_cs = cout if y_cs is None else y_cs
+    y = torch.full((N, H, W, y_cs), -7.0, device="cuda")
+    _lib.check(L.pwc_conv3x3_wino4_f32(_p(xg), cs, _p(packed), _p(bg), _p(y), y_cs, N, H, W, cs, cout, dil,
+                                       0 if slope is None else 1, 0.0 if slope is None else slope, None))
+    torch.cuda.synchronize()
+    return y
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,dil", [
+    (1, 32, 64, 128, 128, 1), (2, 16, 32, 64, 32, 1), (1, 33, 47, 32, 64, 1), (1, 5, 3, 16, 32, 1), (2, 50, 70, 160, 96, 1),
+    (1, 56, 64, 128, 96, 2), (1, 40, 48, 64, 64, 4), (1, 112, 96, 32, 32, 8), (2, 19, 23, 48, 64, 3)])
+def test_conv_winograd_f4x4_vs_oracle(pa, N, H, W, cin, cout, dil):
+    """pwc_conv3x3_wino4_f32 (Winograd F(4x4,3x3)): ragged 16 x 32-pixel blocks, dilations (sub-lattices), short and long
+    channel loops, strided output with untouched neighbours.  Tolerance: F(4x4) rounds ~10x coarser than F(2x2)
+    (transform constants up to 8 and down to 1/24) -- 2e-6 of the activation scale measured, 2e-5 allowed."""
+    x = rnd((N, H, W, cin), 171)
+    k = rnd((3, 3, cin, cout), 172) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 173) * 0.1
+    close(run_conv_wino4(x, k, b, 0.1, dil=dil), orc.conv3x3(x, k, b, 1, dil, 0.1), rel=2e-5)
+    y = run_conv_wino4(x, k, b, None, y_cs=cout + 8, dil=dil)
+    close(y[..., :cout], orc.conv3x3(x, k, b, 1, dil, None), rel=2e-5)
+    assert float(y[..., cout:].min()) == -7.0 and float(y[..., cout:].max()) == -7.0
+
+
+def test_conv_winograd_f4x4_physical_layout_and_plan(pa):
+    """Padded / permuted physical input channels through cin_map (the estimator buffers), and the shapes the model routes
+    to F(4x4): the big level-4 layers of a batch, not single pairs or the small levels."""
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(5)
+    N, H, W, cin, cout, cs = 1, 32, 64, 147, 128, 160
+    cmap = np.full((cs,), -1, np.int32)
+    pos = np.sort(rs.choice(cs, cin, replace=False))
+    cmap[pos] = np.arange(cin, dtype=np.int32)
+    xl = rnd((N, H, W, cin), 181)
+    xp = rnd((N, H, W, cs), 182)                       # padding channels hold garbage-free finite values
+    xp[..., pos] = xl
+    k = rnd((3, 3, cin, cout), 183) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 184) * 0.1
+    close(run_conv_wino4(xp, k, b, 0.1, cin_map=cmap), orc.conv3x3(xl, k, b, 1, 1, 0.1), rel=2e-5)
+    assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 160, 128, 1) == 1
+    assert L.pwc_conv3x3_wino4_supported(8, 56, 128, 192, 128, 1) == 1
+    assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 128, 96, 8) == 1
+    assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 128, 96, 1) == 0      # F(2x2) is level there
+    assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 128, 128, 4) == 0     # ... and on the d = 2, 4 layers
+    assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 96, 64, 1) == 0
+    assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 128, 64, 16) == 0     # 7-row sub-lattices
+    assert L.pwc_conv3x3_wino4_supported(1, 112, 256, 128, 128, 1) == 0     # a single pair does not fill the GPU
+
+
 @pytest.mark.parametrize("N,H,W,cin,cout,dil,csplit", [
     (2, 14, 32, 256, 128, 1, 4), (1, 28, 64, 224, 96, 1, 2), (2, 14, 32, 112, 48, 1, 3), (1, 28, 64, 64, 32, 1, 2),
     (1, 20, 36, 128, 64, 2, 4), (8, 14, 32, 128, 128, 1, 0), (1, 16, 16, 80, 16, 1, 5)])
