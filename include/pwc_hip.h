@@ -276,6 +276,14 @@ int pwc_resize_bilinear_grad_f32(const float* dy, int dy_cs, float* dx, int dx_c
 int pwc_warp_bilinear_grad_f32(const float* x, int x_cs, const float* flow, int flow_cs, float flow_scale,
                                const float* dy, int dy_cs, float* dx, int dx_cs, float* dflow, int dflow_cs,
                                int dflow_accumulate, int N, int H, int W, int C, pwc_stream_t stream);
+/* The same gradient with a bit-reproducible scatter: the corner contributions to dx are added as 64-bit fixed-point
+ * integers (2^-36 steps) in `workspace` (pwc_warp_bilinear_grad_workspace_bytes bytes, 8-byte aligned; zeroed by the
+ * call) and converted once -- integer sums do not depend on the order of the atomics.  dx == NULL: no workspace needed. */
+size_t pwc_warp_bilinear_grad_workspace_bytes(int N, int H, int W, int C);
+int pwc_warp_bilinear_grad_det_f32(const float* x, int x_cs, const float* flow, int flow_cs, float flow_scale,
+                                   const float* dy, int dy_cs, float* dx, int dx_cs, float* dflow, int dflow_cs,
+                                   int dflow_accumulate, int N, int H, int W, int C, void* workspace,
+                                   size_t workspace_bytes, pwc_stream_t stream);
 /* Gradient of pwc_cost_volume_f32 (modules.py:158-204) w.r.t. both feature maps, leaky-relu and mean
  * included: cv = the forward output, dcv = its gradient.  df0 / df1w may be null.  search_range 4. */
 int pwc_cost_volume_grad_f32(const float* f0, int f0_cs, const float* f1w, int f1w_cs, const float* cv, int cv_cs,

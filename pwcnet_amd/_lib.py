@@ -62,6 +62,8 @@ SIGNATURES = {
     "pwc_lrelu_grad_channel_sums_f32": (_i, [_vp, _i, _vp, _i, _l, _i, _f, _vp, _sz, _vp, _i, _vp]),
     "pwc_resize_bilinear_grad_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "pwc_warp_bilinear_grad_f32": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "pwc_warp_bilinear_grad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "pwc_warp_bilinear_grad_det_f32": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "pwc_cost_volume_grad_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_flow_norm_grad_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _vp, _i, _i, _vp]),
     "pwc_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _vp]),

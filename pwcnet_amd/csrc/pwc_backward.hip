@@ -257,7 +257,11 @@ extern "C" int pwc_resize_bilinear_grad_f32(const float* dy, int dy_cs, float* d
 
 // ------------------------------------------------------------------ bilinear warp backward
 // out = sum_ij c_ij * x[corner_ij]  (modules.py:107-137); floor and clip have zero gradient, so
-//   dx[corner_ij] += c_ij * dy                       (scatter: fp32 atomics -- several pixels may share a corner)
+//   dx[corner_ij] += c_ij * dy                       (scatter: several pixels may share a corner.  With a workspace the
+//                                                     contributions are added as 64-bit FIXED-POINT integers -- integer
+//                                                     addition is associative, so the sums do not depend on the order
+//                                                     in which the atomics land: bit-reproducible training steps; the
+//                                                     fp32 atomics of the first version remain as the workspace-free form)
 //   dflow_x = scale * sum_c dy * [(fy1-fy)(x01-x00) + (fy-fy0)(x11-x10)]
 //   dflow_y = scale * sum_c dy * [(fx1-fx)(x10-x00) + (fx-fx0)(x11-x01)]
 // One wave per pixel row segment: lane = channel quad, the flow gradient is reduced over the pixel's lanes.
@@ -266,6 +270,7 @@ struct WarpGradArgs {
     const float* flow;
     const float* dy;
     float* dx;       // accumulated (atomics); may be null
+    long long* fix;  // null, or N*H*W*C zeroed 64-bit accumulators for dx (dense, channel stride C): deterministic form
     float* dflow;    // 2 channels, written or accumulated
     int x_cs, flow_cs, dy_cs, dx_cs, dflow_cs;
     int N, H, W, C;
@@ -304,7 +309,18 @@ __global__ __launch_bounds__(256) void warp_grad_kernel(const WarpGradArgs a) {
             const f32x4 dfy = wx0 * (v10 - v00) + wx1 * (v11 - v01);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { gx_sum += g[i] * dfx[i]; gy_sum += g[i] * dfy[i]; }
-            if (a.dx) {
+            if (a.fix) {
+                // 2^36 steps per unit: |sum| < 1.3e8 representable, 1.5e-11 resolution (fp32 gradients carry ~1e-7 relative)
+                constexpr float FIX = 68719476736.f;
+                unsigned long long* f = reinterpret_cast<unsigned long long*>(a.fix);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    atomicAdd(f + o00 * a.C + c + i, (unsigned long long)__float2ll_rn(wy0 * wx0 * g[i] * FIX));
+                    atomicAdd(f + o01 * a.C + c + i, (unsigned long long)__float2ll_rn(wy0 * wx1 * g[i] * FIX));
+                    atomicAdd(f + o10 * a.C + c + i, (unsigned long long)__float2ll_rn(wy1 * wx0 * g[i] * FIX));
+                    atomicAdd(f + o11 * a.C + c + i, (unsigned long long)__float2ll_rn(wy1 * wx1 * g[i] * FIX));
+                }
+            } else if (a.dx) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     atomicAdd(a.dx + o00 * a.dx_cs + c + i, wy0 * wx0 * g[i]);
@@ -329,20 +345,65 @@ __global__ __launch_bounds__(256) void warp_grad_kernel(const WarpGradArgs a) {
     }
 }
 
+// dx += fixed-point sums (deterministic form)
+__global__ __launch_bounds__(256) void warp_grad_fix_finish_kernel(const long long* __restrict__ fix, float* __restrict__ dx,
+                                                                   int dx_cs, long npix, int C) {
+    const long total = npix * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / C;
+        const int c = (int)(i - p * C);
+        dx[p * dx_cs + c] += (float)((double)fix[i] * (1.0 / 68719476736.0));
+    }
+}
+
+static int warp_grad_run(const float* x, int x_cs, const float* flow, int flow_cs, float flow_scale,
+                         const float* dy, int dy_cs, float* dx, int dx_cs, float* dflow, int dflow_cs,
+                         int dflow_accumulate, int N, int H, int W, int C, long long* fix, pwc_stream_t stream);
+
+extern "C" size_t pwc_warp_bilinear_grad_workspace_bytes(int N, int H, int W, int C) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    return (size_t)N * H * W * C * sizeof(long long);
+}
+
+extern "C" int pwc_warp_bilinear_grad_det_f32(const float* x, int x_cs, const float* flow, int flow_cs, float flow_scale,
+                                              const float* dy, int dy_cs, float* dx, int dx_cs, float* dflow, int dflow_cs,
+                                              int dflow_accumulate, int N, int H, int W, int C, void* workspace,
+                                              size_t workspace_bytes, pwc_stream_t stream) {
+    if (dx && (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 7u) ||
+               workspace_bytes < pwc_warp_bilinear_grad_workspace_bytes(N, H, W, C)))
+        return PWC_EINVAL;
+    return warp_grad_run(x, x_cs, flow, flow_cs, flow_scale, dy, dy_cs, dx, dx_cs, dflow, dflow_cs, dflow_accumulate, N, H, W,
+                         C, dx ? reinterpret_cast<long long*>(workspace) : nullptr, stream);
+}
+
 extern "C" int pwc_warp_bilinear_grad_f32(const float* x, int x_cs, const float* flow, int flow_cs, float flow_scale,
                                           const float* dy, int dy_cs, float* dx, int dx_cs, float* dflow, int dflow_cs,
                                           int dflow_accumulate, int N, int H, int W, int C, pwc_stream_t stream) {
+    return warp_grad_run(x, x_cs, flow, flow_cs, flow_scale, dy, dy_cs, dx, dx_cs, dflow, dflow_cs, dflow_accumulate, N, H, W,
+                         C, nullptr, stream);
+}
+
+static int warp_grad_run(const float* x, int x_cs, const float* flow, int flow_cs, float flow_scale,
+                         const float* dy, int dy_cs, float* dx, int dx_cs, float* dflow, int dflow_cs,
+                         int dflow_accumulate, int N, int H, int W, int C, long long* fix, pwc_stream_t stream) {
     if (!x || !flow || !dy || N <= 0 || H <= 0 || W <= 0 || C <= 0) return PWC_EINVAL;
     if (x_cs < C || dy_cs < C || flow_cs < 2 || (dx && dx_cs < C) || (dflow && dflow_cs < 2)) return PWC_EINVAL;
     if ((C & 3) || (x_cs & 3) || (dy_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(dy)) return PWC_EALIGN;
     WarpGradArgs a;
-    a.x = x; a.flow = flow; a.dy = dy; a.dx = dx; a.dflow = dflow;
+    a.x = x; a.flow = flow; a.dy = dy; a.dx = dx; a.dflow = dflow; a.fix = fix;
     a.x_cs = x_cs; a.flow_cs = flow_cs; a.dy_cs = dy_cs; a.dx_cs = dx_cs; a.dflow_cs = dflow_cs;
     a.N = N; a.H = H; a.W = W; a.C = C; a.flow_scale = flow_scale; a.dflow_accumulate = dflow_accumulate;
     const long npix = (long)N * H * W;
     const long blocks = (npix + 31) / 32;
     if (blocks >= (1L << 31)) return PWC_ERANGE;
+    if (fix && hipMemsetAsync(fix, 0, (size_t)npix * C * sizeof(long long), (hipStream_t)stream) != hipSuccess) return pwc_launch_status();
     hipLaunchKernelGGL(warp_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (fix) {
+        long fb = (npix * C + 255) / 256;
+        if (fb > 8192) fb = 8192;
+        hipLaunchKernelGGL(warp_grad_fix_finish_kernel, dim3((unsigned)fb), dim3(256), 0, (hipStream_t)stream,
+                           (const long long*)fix, dx, dx_cs, npix, C);
+    }
     return pwc_launch_status();
 }
 

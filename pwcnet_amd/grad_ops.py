@@ -76,9 +76,26 @@ def resize_grad(dy, dx, mul=1.0, accumulate=False):
                                                  float(mul), 1 if accumulate else 0, _s()), "resize_grad")
 
 
-def warp_grad(x, flow, flow_scale, dy, dx=None, dflow=None, dflow_accumulate=False):
-    """Gradient of the bilinear warp: dx += scatter (atomics), dflow (+)= ... (both optional Views)."""
-    _lib.check(_L().pwc_warp_bilinear_grad_f32(
+_WARP_WS = {}
+
+
+def warp_grad(x, flow, flow_scale, dy, dx=None, dflow=None, dflow_accumulate=False, deterministic=True):
+    """Gradient of the bilinear warp: dx += corner scatter, dflow (+)= ... (both optional Views).
+    deterministic (default): the scatter adds 64-bit fixed-point integers in a per-(device, stream) workspace, so the
+    result does not depend on the order of the atomics (bit-reproducible training steps); False: fp32 atomics."""
+    L = _L()
+    if deterministic and dx is not None:
+        need = L.pwc_warp_bilinear_grad_workspace_bytes(x.N, x.H, x.W, x.C)
+        key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+        ws = _WARP_WS.get(key)
+        if ws is None or ws.numel() * 8 < need:
+            ws = _WARP_WS[key] = torch.empty(((need + 7) // 8,), dtype=torch.int64, device="cuda")
+        _lib.check(L.pwc_warp_bilinear_grad_det_f32(
+            _p(x.ptr), x.cs, _p(flow.ptr), flow.cs, float(flow_scale), _p(dy.ptr), dy.cs, _p(dx.ptr), dx.cs,
+            _p(dflow.ptr) if dflow is not None else None, dflow.cs if dflow is not None else 0,
+            1 if dflow_accumulate else 0, x.N, x.H, x.W, x.C, _p(ws.data_ptr()), ws.numel() * 8, _s()), "warp_grad")
+        return
+    _lib.check(L.pwc_warp_bilinear_grad_f32(
         _p(x.ptr), x.cs, _p(flow.ptr), flow.cs, float(flow_scale), _p(dy.ptr), dy.cs,
         _p(dx.ptr) if dx is not None else None, dx.cs if dx is not None else 0,
         _p(dflow.ptr) if dflow is not None else None, dflow.cs if dflow is not None else 0,

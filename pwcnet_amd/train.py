@@ -54,6 +54,12 @@ class _Conv:
 
 
 class Trainer:
+    """Data-parallel semantics: every rank steps on its own pairs and the flat gradient buffer is summed over the ranks
+    with weight 1/world.  For the multiscale loss (a mean over the batch) that IS the gradient of the global batch.  For
+    the robust loss, weight * (mean_n L1 + eps)^q is not linear in the batch mean: N ranks at batch b follow the mean of
+    the per-rank robust losses, not the robust loss of the batch of N*b (the reference trains on one device).  The
+    per-level scale q * (L1 + eps)^(q-1) is read back to the host once per level and step."""
+
     def __init__(self, num_levels=6, search_range=4, warp_type="bilinear", use_dc=False, output_level=4,
                  name="pwcdcnet", weights=(0.32, 0.08, 0.02, 0.01, 0.005), gamma=0.0004, lr=1e-4, lr_scheduling=True,
                  seed=0, device="cuda", dist=None, loss="multiscale", epsilon=0.01, q=0.4):

@@ -2,6 +2,8 @@
 against torch.autograd on the float64 CPU restatement of the forward (oracle/torch_ref.py).
 
 Tolerances are relative to the largest reference gradient (fp32 kernels vs a float64 reference)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -97,6 +99,57 @@ def test_warp_grad(go):
     go.warp_grad(V(gx), V(gfl), scale, V(gdy), V(dx), V(dfl))
     close(dx, xt.grad, rel=1e-5)
     close(dfl, ft.grad, rel=1e-4)
+
+
+def test_warp_grad_is_bit_reproducible(go):
+    """Hundreds of source pixels collapse onto a few corners (a flow field that points at one spot): the default
+    scatter (64-bit fixed-point integer atomics) gives the same bits on every run and matches autograd; it also
+    accumulates into a non-zero dx."""
+    N, H, W, C = 2, 40, 56, 32
+    x, dy = rnd((N, H, W, C), 15), rnd((N, H, W, C), 16)
+    gy, gx_ = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    flow = np.stack([(20.3 - gx_) * 0.97, (17.6 - gy) * 0.97], axis=2)[None].repeat(N, 0).astype(np.float32)
+    flow += rnd((N, H, W, 2), 17) * 0.3
+    xt, ft = t64(x), t64(flow)
+    (tr.bilinear_warp(xt, ft) * t64(dy, False)).sum().backward()
+    gx, gfl, gdy = gpu(x), gpu(flow), gpu(dy)
+    outs = []
+    for _ in range(4):
+        dx = torch.zeros((N, H, W, C), device="cuda")
+        go.warp_grad(V(gx), V(gfl), 1.0, V(gdy), V(dx), None)
+        torch.cuda.synchronize()
+        outs.append(dx.clone())
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    close(outs[0], xt.grad, rel=1e-5)
+    base = gpu(rnd((N, H, W, C), 18))
+    dx = base.clone()
+    go.warp_grad(V(gx), V(gfl), 1.0, V(gdy), V(dx), None)
+    close(dx - base, xt.grad, rel=2e-5)      # (fp32 cancellation of the base in dx - base)
+    dxa = torch.zeros((N, H, W, C), device="cuda")
+    go.warp_grad(V(gx), V(gfl), 1.0, V(gdy), V(dxa), None, deterministic=False)      # fp32 atomics: same sums up to order
+    close(dxa, xt.grad, rel=1e-5)
+
+
+def test_train_step_is_bit_reproducible():
+    """Two trainers from the same weights on the same batch: identical losses and identical parameters after 3 steps
+    (fixed-order reductions everywhere, integer atomics in the warp gradient)."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    from pwcnet_amd.train import Trainer
+    N, H, W = 2, 64, 128
+    w = util.model_weights(False, gain=1.25)
+    im0, im1 = util.smooth_images(N, H, W, seed=71, shift=(3, -2))
+    gt = util.flow_field(N, H, W, seed=72, sigma=2.0, outliers=False).astype(np.float32)
+    g0, g1, ggt = gpu(im0), gpu(im1), gpu(gt)
+    runs = []
+    for _ in range(2):
+        tn = Trainer(weights=(0.32, 0.08, 0.02, 0.01, 0.005), gamma=4e-4, lr=1e-3)
+        tn.load_weights(w)
+        losses = [float(tn.step(g0, g1, ggt)) for _ in range(3)]
+        runs.append((losses, tn.state_dict()))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for k in runs[0][1]:
+        assert np.array_equal(np.asarray(runs[0][1][k]), np.asarray(runs[1][1][k])), k
 
 
 @pytest.mark.parametrize("N,H,W,C", [(1, 9, 11, 8), (2, 16, 24, 32), (1, 8, 8, 20)])
@@ -264,6 +317,45 @@ def test_train_step_gradients_vs_autograd(use_dc, loss):
         worst = max(worst, err)
         assert err <= 2e-3, f"{k}: relative gradient error {err:.3e}"
     print(f"worst relative gradient error over {len(ref_g)} variables: {worst:.3e}")
+
+
+def test_train_step_gradients_full_size_spot_check():
+    """One 448x1024 pair (the geometry `bench.py --mode train` times: LDS-staged weight-gradient tiling with its k-split
+    over pixel chunks, Winograd data gradients, full-size cost-volume / warp gradients): the gradients of the first
+    conv, a level-4 128 -> 128 conv, the dilated context convs, a stride-2 extractor conv -- in fact every variable --
+    against float64 autograd on the torch restatement (about a minute of CPU)."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    from pwcnet_amd.train import Trainer
+    N, H, W = 1, 448, 1024
+    w = util.model_weights(False, gain=1.2)
+    im0, im1 = util.smooth_images(N, H, W, seed=81, shift=(4, -3))
+    gt = util.flow_field(N, H, W, seed=82, sigma=2.0, outliers=False).astype(np.float32)
+    weights = (0.32, 0.08, 0.02, 0.01, 0.005)
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    ref_loss, ref_g, ref_pyr = _ref_grads(w, im0, im1, gt, weights, False, "multiscale")
+    tn = Trainer(weights=weights, gamma=0.0, lr=1e-4)
+    tn.load_weights(w)
+    pyr = tn.forward(gpu(im0), gpu(im1))
+    for a, b in zip(pyr, ref_pyr):
+        close(a, b, rel=2e-4)
+    ggt = gpu(gt)
+    loss = float(tn.loss_value(ggt))
+    assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss)
+    tn.backward(ggt)
+    torch.cuda.synchronize()
+    got = tn.gradients()
+    named = ["pwcdcnet/fp_extractor/conv2d/kernel", "pwcdcnet/optflow_4/conv2d_1/kernel", "pwcdcnet/context/conv2d_2/kernel",
+             "pwcdcnet/context/conv2d_4/kernel", "pwcdcnet/fp_extractor/conv2d_3/kernel", "pwcdcnet/optflow_4/conv2d_5/kernel"]
+    worst = 0.0
+    for k in sorted(ref_g):
+        r = ref_g[k].numpy()
+        err = float(np.abs(got[k] - r).max()) / max(float(np.abs(r).max()), 1e-12)
+        worst = max(worst, err)
+        if k in named:
+            print(f"  {k}: relative gradient error {err:.3e}")
+        assert err <= 2e-3, f"{k}: relative gradient error {err:.3e}"
+    print(f"full size: worst relative gradient error over {len(ref_g)} variables: {worst:.3e}")
 
 
 def test_train_step_reduces_the_loss_and_matches_adam():

@@ -114,6 +114,13 @@ def main():
     ap.add_argument("--val_fraction", type=float, default=0.1)
     ap.add_argument("--model_dir", type=str, default="./model")
     args = ap.parse_args()
+    # what the training path does not build is refused here, not by an assert after the data set has been read
+    if args.warp_type != "bilinear":
+        ap.error("--warp_type nearest has no gradient path here (the reference trains with its model default, bilinear)")
+    if args.num_levels != 6 or args.search_range != 4:
+        ap.error("training supports --num_levels 6 --search_range 4 (the reference's scales and *20 hard-code 6 levels)")
+    if not 0 <= args.output_level < args.num_levels:
+        ap.error("--output_level must be in [0, num_levels)")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -167,7 +174,8 @@ def main():
             n_steps += 1
         # validation: EPE of flows_final (reference train.py:77,124-131), sharded over the ranks
         from pwcnet_amd import PWCDCNet
-        net = PWCDCNet(use_dc=args.use_dc)
+        net = PWCDCNet(num_levels=args.num_levels, search_range=args.search_range, warp_type=args.warp_type,
+                       use_dc=args.use_dc, output_level=args.output_level)
         net.load_weights(trainer.state_dict())
         res = sharding.evaluate_pairs(lambda a, b: net(a / 255.0, b / 255.0)[0],
                                       lambda i: tuple(torch.from_numpy(x) for x in ds[val_idx[i]]),
