@@ -115,6 +115,13 @@ __device__ __forceinline__ float wino_minus_one() {
 // current tile's output transform and stores, so its fetch latency and the per-tile setup hide behind
 // them.  Correct, but the 7 offsets of the next tile live across the epilogue push the kernel over
 // 256 VGPRs (84 B of scratch per lane) and it measures 289 us against 255 us: not used by the library.
+// barriers of the stage pipeline: LDS only (pwc_lds_barrier) -- WINO_DRAIN_BARRIERS=1 restores the round-1/2 behaviour
+// (__syncthreads(), which drains every DMA piece in flight) for A/B measurements
+#ifndef WINO_DRAIN_BARRIERS
+#define WINO_SYNC() pwc_lds_barrier()
+#else
+#define WINO_SYNC() __syncthreads()
+#endif
 template <int ABL = 0, int NT = 2, int PIPE = 0, int GEO = 0, int PERSIST = 0>
 __global__ __launch_bounds__(256, NT >= 4 ? 1 : 2) void conv3x3_wino_kernel(const WinoArgs a) {
     static_assert(!PERSIST || PIPE, "the persistent loop is built on the pipelined stage");
@@ -243,13 +250,13 @@ __global__ __launch_bounds__(256, NT >= 4 ? 1 : 2) void conv3x3_wino_kernel(cons
         const bool has_next = c16 + 1 < c_end;
         if (PIPE) {
             WAIT_VM(UH);                             // patch(c) landed (weights A(c) may be in flight)
-            __syncthreads();                         // ... for every wave; positions 8-15 of c-1 fully read
+            WINO_SYNC();                         // ... for every wave; positions 8-15 of c-1 fully read
             issue_u(c16, 1);
         } else {
-            __syncthreads();                         // previous stage fully read
+            WINO_SYNC();                         // previous stage fully read
             issue_patch(c16); issue_u(c16, 0); issue_u(c16, 1);
             WAIT_VM(0);
-            __syncthreads();
+            WINO_SYNC();
         }
 
         // ---- input transform  V = B^T d B  (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]), in place
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 1 : 2) void conv3x3_wino_kernel(cons
         };
         if (PIPE) {
             WAIT_VM(UH);                             // weights A(c) landed (B(c) may be in flight)
-            __syncthreads();                         // ... for every wave; patch(c) fully read
+            WINO_SYNC();                         // ... for every wave; patch(c) fully read
             if (has_next) issue_patch(c16 + 1);
         }
         if (ABL & 8) __builtin_amdgcn_s_setprio(1);
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 1 : 2) void conv3x3_wino_kernel(cons
         if (ABL & 8) __builtin_amdgcn_s_setprio(0);
         if (PIPE) {
             if (has_next) WAIT_VM(PPW); else WAIT_VM(0);   // weights B(c) landed (patch(c+1) may be in flight)
-            __syncthreads();                         // ... for every wave; positions 0-7 of c fully read
+            WINO_SYNC();                         // ... for every wave; positions 0-7 of c fully read
             if (has_next) issue_u(c16 + 1, 0);
         }
         if (ABL & 8) __builtin_amdgcn_s_setprio(1);
@@ -608,6 +615,9 @@ static int wino_run(const float* x, int x_cs, const float* packed_u, const float
     // most of a workgroup's life waiting for its only patch: there the persistent form -- the next tile's first
     // stage is requested before the current tile's output transform and stores -- pays (64 accumulator registers,
     // no spill; with 32 couts it spills and loses, see the kernel comment).
+    // (A dedicated 16 -> 16 kernel -- weights resident in registers, double-buffered patch, LDS-only barriers -- was built
+    // and measured in round 3: 76.7 us against this kernel's 75.4 us on 16 x 224 x 512; its memory side alone runs in 38 us,
+    // its compute side alone in 49 us, together 77: removed again, see DESIGN.md.)
     const char* pe = getenv("PWC_WINO_PERSIST");
     const bool persist = (pe ? atoi(pe) != 0 : true) && bn == 16 && Cin_phys <= 32 && nblk > 1024 && csplit == 1;
     if (persist && geo == 0) { WINO_LAUNCH_P(1, 0, 1); return pwc_launch_status(); }

@@ -36,6 +36,9 @@
 #pragma once
 #include "pwc_common.h"
 #include <type_traits>
+#ifndef WINO_SYNC
+#define WINO_SYNC() pwc_lds_barrier()
+#endif
 
 struct Wino4Args {
     const float* x;
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args 
         const bool has_next = c16 + 1 < nc16;
         // in flight here (oldest first): patch(c), weight parts 0 and 1 of c
         W4_WAIT_VM(6);                               // patch(c) landed
-        __syncthreads();                             // ... for every wave; part 2 of c-1 fully read
+        WINO_SYNC();                             // ... for every wave; part 2 of c-1 fully read
         issue_u(c16, 2);
 
         // ---- input transform, this wave's three rows a = 3h .. 3h+2 of  V = B^T d B  (both cout-tile waves of a
@@ -237,15 +240,15 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args 
             }
         };
         W4_WAIT_VM(6);                               // weight part 0 of c landed (parts 1, 2 may be in flight)
-        __syncthreads();                             // ... for every wave; patch(c) fully read
+        WINO_SYNC();                             // ... for every wave; patch(c) fully read
         if (has_next) issue_patch(c16 + 1);
         mfma_part(0);
         if (has_next) W4_WAIT_VM(3 + PPW); else W4_WAIT_VM(3);   // part 1 landed (part 2, patch(c+1) may be in flight)
-        __syncthreads();                             // ... for every wave; part 0 fully read
+        WINO_SYNC();                             // ... for every wave; part 0 fully read
         if (has_next) issue_u(c16 + 1, 0);
         mfma_part(1);
         if (has_next) W4_WAIT_VM(PPW + 3); else W4_WAIT_VM(0);   // part 2 landed (patch(c+1), part 0 of c+1 may be in flight)
-        __syncthreads();                             // ... for every wave; part 1 fully read
+        WINO_SYNC();                             // ... for every wave; part 1 fully read
         if (has_next) issue_u(c16 + 1, 1);
         mfma_part(2);
     };
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args 
                 }
             }
         }
-        __syncthreads();                             // every wave is past its last LDS read of the stage
+        WINO_SYNC();                             // every wave is past its last LDS read of the stage
         {
             // exchange with the wave of the other half (same tile group, same cout tile = wave ^ 2): 8 f32x4 per lane,
             // 32 + 4 floats per lane (conflict-free b128 accesses)
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + (i * 4 + j) * 4) = Yp[2 * (1 - HH) + i][j];
         }
-        __syncthreads();
+        WINO_SYNC();
         const float* src = smem + (wave * 64 + lane) * 36;
         const int co = n0 + nt * 16 + fq * 4;
         const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4w_kernel(const Wino4Args
         constexpr bool FIRST = decltype(first)::value;
         const bool has_next = c16 + 1 < nc16;
         W4_WAIT_VM(6);                               // patch(c) landed
-        __syncthreads();
+        WINO_SYNC();
         issue_u(c16, 2);
 
         f32x4 V[3][6];
@@ -501,15 +504,15 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4w_kernel(const Wino4Args
             }
         };
         W4_WAIT_VM(6);
-        __syncthreads();
+        WINO_SYNC();
         if (has_next) issue_patch(c16 + 1);
         mfma_part(0);
         if (has_next) W4_WAIT_VM(3 + PPW); else W4_WAIT_VM(3);
-        __syncthreads();
+        WINO_SYNC();
         if (has_next) issue_u(c16 + 1, 0);
         mfma_part(1);
         if (has_next) W4_WAIT_VM(PPW + 3); else W4_WAIT_VM(0);
-        __syncthreads();
+        WINO_SYNC();
         if (has_next) issue_u(c16 + 1, 1);
         mfma_part(2);
     };
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4w_kernel(const Wino4Args
     };
     auto epilogue = [&](auto h_c) {
         constexpr int HH = decltype(h_c)::value;
-        __syncthreads();                             // every wave is past its last LDS read of the stage
+        WINO_SYNC();                             // every wave is past its last LDS read of the stage
         {
             f32x4 Ys[4][4];                          // the other cout tile: to the partner's slot
             partial(h_c, std::integral_constant<int, 1 - HH>{}, Ys);
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4w_kernel(const Wino4Args
         }
         f32x4 Yk[4][4];
         partial(h_c, h_c, Yk);
-        __syncthreads();
+        WINO_SYNC();
         const float* src = smem + (wave * 64 + lane) * 68;
         const int co = n0 + HH * 16 + fq * 4;
         const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(

@@ -49,6 +49,18 @@ __device__ __forceinline__ float pwc_mul_rounded(float a, float b) {
     return r;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a fence over global memory as well, which
+// hipcc lowers to `s_waitcnt vmcnt(0)` in front of the s_barrier: every LDS-DMA piece (buffer_load ... lds) and every
+// store in flight is drained at each barrier, and a software pipeline that waits for its pieces with counted
+// `s_waitcnt vmcnt(n)` is silently serialised (found in round 3 in the ISA of conv3x3_wino_kernel: all three barriers
+// of a stage were preceded by vmcnt(0)).  A wave must have waited for its OWN pieces of a region (s_waitcnt vmcnt)
+// before this barrier publishes the region to the other waves.
+__device__ __forceinline__ void pwc_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ float pwc_lrelu(float v, float slope) {
     // tf.nn.leaky_relu(x, alpha) = max(alpha*x, x)
     return fmaxf(v, slope * v);
