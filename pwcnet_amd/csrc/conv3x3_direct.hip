@@ -366,6 +366,79 @@ __global__ __launch_bounds__(256) void conv3x3_head2_wide_kernel(const DirectArg
     }
 }
 
+// ---------------------------------------------------------------- 3 -> 16 channels on the matrix pipe
+// The first convolution of the extractor (reference modules.py:64, `fp_extractor/conv2d`: 3 -> 16 channels, stride 2,
+// 448x1024 images) as a GEMM per 16 consecutive output pixels of a row: D[cout 16][pixel 16] = W[16][K] x X[K][16],
+// K = 27 = (tap, channel) padded to 28 = 7 x v_mfma_f32_16x16x4_f32.  conv3x3_smallcin_kernel spends ~150 VALU / LDS
+// instructions per 16 pixels x 16 couts (4 threads per pixel); here a wave spends 7 loads, 7 MFMAs and a 10-instruction
+// epilogue (measured 31 us against 38 us on 8 x 448 x 1024; with the next group's loads issued ahead: 34 us).
+//   A (weights): lane (cout = lane & 15, k = 4 i + (lane >> 4)), 7 registers for the whole kernel;
+//   B (pixels):  lane (k = 4 i + (lane >> 4), pixel = lane & 15): one buffer_load_dword per k-step whose per-lane offset
+//                is a kernel constant and whose scalar offset is the group's origin -- no address arithmetic in the loop
+//                (groups that touch the SAME padding take a masked path: out-of-image taps become out-of-range offsets);
+//   D: lane holds couts 4 (lane >> 4) .. + 3 of pixel lane & 15: one 16-byte store.
+constexpr unsigned C3M_OOB = 0x7FFF0000u;
+__global__ __launch_bounds__(256) void conv3x3_cin3_mfma_kernel(const DirectArgs a, int groups_per_row, int nrows, int rstep, int N) {
+    const int lane = threadIdx.x & 63;
+    const int fr = lane & 15, fq = lane >> 4;
+    float wa[7];
+    int kdy[7], kdx[7], kci[7];
+    unsigned koff[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int k = 4 * i + fq;
+        const bool kv = k < 27;
+        const int tap = kv ? k / 3 : 0, ci = kv ? k - 3 * tap : 0;
+        const int ty = tap / 3, tx = tap - 3 * ty;
+        wa[i] = kv ? a.w[k * 16 + fr] : 0.f;
+        kdy[i] = kv ? ty * a.dil : -(1 << 20);           // k = 27: never inside the image
+        kdx[i] = tx * a.dil + fr * a.stride;
+        kci[i] = ci;
+        koff[i] = kv ? (unsigned)(((kdy[i] * a.W + kdx[i]) * a.x_cs + ci) * 4) : C3M_OOB;
+    }
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((long)N * a.H * a.W * a.x_cs * 4), 0x00020000);
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 4 * fq);
+    // wave w owns column group w % groups_per_row and walks the rows (n, oy) from w / groups_per_row in steps of `rstep`
+    // (no division in the loop)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (wave >= rstep * groups_per_row) return;
+    const int gx = wave % groups_per_row;
+    int row = wave / groups_per_row;
+    int n = row / a.Ho, oy = row - n * a.Ho;
+    const int ox0 = gx * 16;
+    for (; row < nrows; row += rstep, oy += rstep) {
+        while (oy >= a.Ho) { oy -= a.Ho; ++n; }
+        const int iy0 = oy * a.stride - a.pad_t, ix0 = ox0 * a.stride - a.pad_l;
+        const bool interior = iy0 >= 0 && iy0 + 2 * a.dil < a.H && ix0 >= 0 && ix0 + 15 * a.stride + 2 * a.dil < a.W;
+        const long base = (((long)n * a.H + iy0) * a.W + ix0) * a.x_cs * 4;       // bytes; negative only on the masked path
+        float b[7];
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+                b[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)koff[i], (int)base, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const int iy = iy0 + kdy[i], ix = ix0 + kdx[i];
+                const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const long off = (((long)n * a.H + iy) * a.W + ix) * a.x_cs * 4 + kci[i] * 4;
+                b[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, ok ? (int)off : (int)C3M_OOB, 0, 0));
+            }
+        }
+        f32x4 acc = b4;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], b[i], acc, 0, 0, 0);
+        if (a.apply_act) {
+            acc[0] = pwc_lrelu(acc[0], a.slope); acc[1] = pwc_lrelu(acc[1], a.slope);
+            acc[2] = pwc_lrelu(acc[2], a.slope); acc[3] = pwc_lrelu(acc[3], a.slope);
+        }
+        if (ox0 + fr < a.Wo)
+            *reinterpret_cast<f32x4*>(a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox0 + fr) * a.y_cs + 4 * fq) = acc;
+    }
+}
+
+
 extern "C" int pwc_conv3x3_direct_f32(const float* x, int x_cs, const float* w_hwio, const float* bias,
                                       float* y, int y_cs, const float* residual, int res_cs, int N, int H,
                                       int W, int Cin, int Cout, int stride, int dilation, int apply_act,
@@ -385,6 +458,20 @@ extern "C" int pwc_conv3x3_direct_f32(const float* x, int x_cs, const float* w_h
     const bool vec4 = (Cin % 4 == 0) && (x_cs % 4 == 0) && pwc_aligned16(x);
     const unsigned gx = (unsigned)((a.M + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
+    if (Cin == 3 && Cout == 16 && !residual && (y_cs & 3) == 0 && pwc_aligned16(y) && pwc_aligned16(bias) &&
+        (long)N * H * W * x_cs * 4 < (long)C3M_OOB) {
+        const int gpr = (a.Wo + 15) / 16;
+        const long nrows = (long)N * a.Ho;
+        if (nrows < (1L << 30) && gpr <= 8192) {
+            long rstep = 8192 / gpr;                     // ~8 waves per SIMD, each walks the rows of its column group
+            if (rstep < 1) rstep = 1;
+            if (rstep > nrows) rstep = nrows;
+            const long blocks = (rstep * gpr + 3) / 4;
+            hipLaunchKernelGGL(conv3x3_cin3_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, gpr, (int)nrows,
+                               (int)rstep, N);
+            return pwc_launch_status();
+        }
+    }
     if (Cin == 3 && Cout == 16 && !residual && (y_cs & 3) == 0 && pwc_aligned16(y) && pwc_aligned16(bias)) {
         long blocks = (a.M * (Cout >> 2) + 255) / 256;
         if (blocks > 256 * 32) blocks = 256 * 32;

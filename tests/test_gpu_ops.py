@@ -401,6 +401,20 @@ def test_conv_direct_vs_oracle(pa, N, H, W, cin, cout, stride, dil, slope):
     close(run_conv_direct(x, k, b, stride, dil, slope), orc.conv3x3(x, k, b, stride, dil, slope))
 
 
+@pytest.mark.parametrize("N,H,W,stride,dil,slope", [
+    (2, 448, 1024, 2, 1, 0.1), (1, 33, 47, 2, 1, 0.1), (2, 16, 16, 1, 1, 0.1), (1, 21, 35, 1, 2, None), (3, 7, 5, 2, 1, 0.1),
+    (1, 64, 31, 2, 2, 0.1), (1, 1, 1, 2, 1, 0.1)])
+def test_conv_first_layer_mfma_kernel_vs_oracle(pa, N, H, W, stride, dil, slope):
+    """3 -> 16 channels (reference modules.py:64, fp_extractor/conv2d) runs conv3x3_cin3_mfma_kernel: interior groups,
+    groups on every SAME-padding border, ragged rows (Wo % 16 != 0), every stride / dilation the entry point accepts;
+    the first case is the bench layer at full size."""
+    x = rnd((N, H, W, 3), 140)
+    k = rnd((3, 3, 3, 16), 141) * float(1.0 / np.sqrt(27))
+    b = rnd((16,), 142) * 0.1
+    got = run_conv_direct(x, k, b, stride, dil, slope)
+    close(got, orc.conv3x3(x, k, b, stride, dil, slope))
+
+
 def test_conv_direct_residual_flow_head(pa):
     x = rnd((2, 14, 18, 32), 17)
     k = rnd((3, 3, 32, 2), 18) * 0.05
