@@ -12,27 +12,30 @@
 // layers changes the flow error by x1.0 - 1.4 -- the level of the direct fp32 convolution (profiles/
 // r03_f4x4_numerics.txt).  U = G g G^T is computed in double and rounded once.
 //
-// Work decomposition (512 threads = 8 waves, ONE workgroup per CU, two waves per SIMD):
-//   workgroup = 4 x 8 Winograd tiles (16 x 32 output pixels) x 32 output channels;
+// Work decomposition (256 threads = 4 waves, TWO workgroups per CU = two waves per SIMD):
+//   workgroup = 4 x 8 Winograd tiles (16 x 32 output pixels) x 16 output channels;
 //   wave      = (tile group g: tile rows 2g, 2g+1 = 16 tiles = one MFMA column block;
-//                position half h: rows a = 3h .. 3h+2 of the 6 x 6 transformed tile = 18 of the 36 positions;
-//                cout tile nt of 16): 18 accumulator tiles = 72 registers.  Splitting the POSITIONS over waves
-//               halves the accumulators AND the input-transform work per wave (the row pass produces 3 of 6 rows);
-//               splitting the cout tiles too brings a wave under 256 registers, so that two waves share a SIMD and
-//               one's transforms, LDS reads and DMA issue run under the other's MFMAs (the first version -- 4 waves
-//               with both cout tiles, 364 registers, one wave per SIMD -- spent 164 us outside the MFMAs and 123 us
-//               in them, one after the other: 256 us against 286 us for F(2x2) on the 128 -> 128 layer).  The price:
-//               the two cout-tile waves of a (g, h) pair both read and transform the raw 6 x 6 patch.
+//                position half h: rows a = 3h .. 3h+2 of the 6 x 6 transformed tile = 18 of the 36 positions):
+//               18 accumulator tiles = 72 registers.  Splitting the POSITIONS over waves halves the accumulators AND the
+//               input-transform work per wave (the row pass produces 3 of 6 rows).
+//               History: 4 waves with two cout tiles each (364 registers, one wave per SIMD) 256 us on the 128 -> 128
+//               layer; 8 waves = (g, h, cout tile) in ONE workgroup of 32 couts 247 us; this form -- the same waves as
+//               two independent workgroups of 16 couts, each with its own copy of the patch -- 249 us there, but 197
+//               against 210 us on 128 -> 96 and 107 against 117 us on 96 -> 64 (cout granularity 16; the two
+//               workgroups of a CU are not in lock step).  A 16 x 64-pixel form with both cout tiles per wave (one
+//               transform per 144 MFMAs) needs 256 registers to the last one, spilled 21 and measured 281 us.
 //   lane      = (tile j = lane & 15, k-slot q = lane >> 4): reads the 6 x 6 input pixels of its tile for channels
 //               4q..4q+3 (36 ds_read_b128), transforms them IN REGISTERS -- the result is the MFMA B-operand
-//               fragment V_xi[k = 4q+s][tile j] -- and at the end holds its 18 x 2 M_xi: the column pass of the
+//               fragment V_xi[k = 4q+s][tile j] -- and at the end holds its 18 M_xi: the column pass of the
 //               output transform is register-local, the row pass needs the other half's partial sums, exchanged
-//               through LDS once per tile (wave h finishes cout tile h).
+//               through LDS once per tile (wave h finishes output rows 2h, 2h+1).
 //   LDS per 16-channel stage: the raw 18 x 34 pixel patch (64-byte records, see w4_rec) and the transformed
-//   weights U[xi 36][32 cout][16 ch] (pre-swizzled by the packer), both filled by buffer_load_dwordx4 ... lds;
-//   out-of-image pixels are out-of-range buffer offsets = the zeros of the SAME padding.  One stage buffer,
-//   fetched in three parts (patch, positions {0-8, 18-26}, positions {9-17, 27-35}) that are each re-fetched for
-//   the next stage as soon as they have been read.
+//   weights U[xi 36][16 cout][16 ch] (pre-swizzled by the packer), both filled by buffer_load_dwordx4 ... lds;
+//   out-of-image pixels are out-of-range buffer offsets = the zeros of the SAME padding.  One stage buffer (78 KB),
+//   fetched in three parts (patch, positions {0-5, 18-23}, ...) that are each re-fetched for the next stage as soon
+//   as they have been read.
+// What bounds it: on gfx950 nothing overlaps an fp32 MFMA on its SIMD; per wave and stage 72 MFMAs carry
+// 180 packed VALU instructions of transform, 54 ds_read_b128 and 20 fetch pieces: a cap of 0.6 on the MFMA fraction.
 #pragma once
 #include "pwc_common.h"
 #include <type_traits>
@@ -50,7 +53,7 @@ struct Wino4Args {
     int Cin_phys, Cout;
     int apply_act;
     float slope;
-    int tiles_x, tiles_y, ncb;   // 16x32-pixel blocks per (sub-)image, cout blocks of 32
+    int tiles_x, tiles_y, ncb;   // 16x32-pixel blocks per (sub-)image, cout blocks of 16
     int dil;
     int ntiles;
 };
@@ -58,13 +61,14 @@ struct Wino4Args {
 constexpr unsigned W4_OOB = 0x7FFF0000u;
 constexpr int W4_PS = 36;                    // patch records per patch row: 4 quarter rows (px & 3) of 9 (px >> 2)
 constexpr int W4_PH = 18, W4_PW = 34;
-constexpr int W4_NW = 8, W4_T = 64 * W4_NW;
-constexpr int W4_NBP = 48;                   // 16-record DMA blocks of the patch (648 records used of 768): 6 per wave
+constexpr int W4_NW = 4, W4_T = 64 * W4_NW;
+constexpr int W4_PPW = 11;                   // patch DMA pieces per wave and stage: 44 requests for the 41 blocks (648 records of 64 B)
+constexpr int W4_NBP = 42;                   // ... of the patch image, + block 41 that swallows the three surplus (out-of-range) requests
 constexpr int W4_PREC = W4_NBP * 16;
-constexpr int W4_NBU = 72;                   // 16-row DMA blocks of the weights: 36 positions x 32 couts
-constexpr int W4_STAGE = (W4_PREC + W4_NBU * 16) * 16;     // floats per LDS stage: 122 880 B
-constexpr int W4_XCH = W4_NW * 64 * 36;      // floats of the output exchange (8 waves x 64 lanes x (32 + 4 pad)): 73 728 B
-static_assert(W4_XCH <= W4_STAGE, "the exchange reuses the stage buffer");
+constexpr int W4_NBU = 36;                   // 16-row DMA blocks of the weights: 36 positions x 16 couts
+constexpr int W4_STAGE = (W4_PREC + W4_NBU * 16) * 16;     // floats per LDS stage: 79 872 B -- two workgroups per CU
+constexpr int W4_XCH = W4_NW * 64 * 36;      // floats of the output exchange (4 waves x 64 lanes x (32 + 4 pad)): 36 864 B
+static_assert(W4_XCH <= W4_STAGE && 2 * W4_STAGE * 4 <= 160 * 1024, "the exchange reuses the stage buffer; two workgroups share a CU");
 
 __device__ __forceinline__ int w4_wswz(int row) { return (4 - ((row >> 2) & 3)) & 3; }   // weight rows (as conv3x3_wino.hip)
 // Patch image: pixel (py, px) of the 18 x 34 patch sits in record py * 36 + (px & 3) * 9 + (px >> 2) -- the 8 tile
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int g = wave >> 2, h = (wave >> 1) & 1, nt = wave & 1;   // tile group, position half, cout tile
+    const int g = wave >> 1, h = wave & 1;          // tile group, position half
     const int fr = lane & 15, fq = lane >> 4;
     const int trl = fr >> 3, tc = fr & 7;           // tile (2g + trl, tc)
     float m1s;
@@ -112,12 +116,12 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args 
     const int n = rest / (d * d);
     const int ry = sub / d, rx = sub - ry * d;      // pixel sub-lattice (y mod d, x mod d) of a dilated conv
     const int y0 = by * 16, x0 = bx * 32;           // output origin of the block, in sub-lattice coordinates
-    const int n0 = cb * 32;
+    const int n0 = cb * 16;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.x + (size_t)n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
 
     // ---- LDS-DMA bookkeeping: per-lane byte offsets fixed over the channel loop, the stage in the scalar offset
-    constexpr int PPW = W4_NBP / W4_NW;             // patch blocks per wave (6)
+    constexpr int PPW = W4_PPW;                     // patch pieces per wave: blocks wave, wave + 4, ... (>= 41: nothing to fetch)
     unsigned p_voff[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
@@ -130,18 +134,18 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args 
         const bool ok = py < W4_PH && px < W4_PW && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
         p_voff[i] = ok ? (unsigned)(((yy * a.W + xx) * a.x_cs + ch * 4) * 4) : W4_OOB;
     }
-    // weights, in three parts P of 6 positions per half: wave w fetches cout tile (w & 1) of positions
-    // 18 ((w >> 1) & 1) + 6 P + 3 (w >> 2) + i, i = 0..2
-    const int u_xi0 = 18 * ((wave >> 1) & 1) + 3 * (wave >> 2), u_sub = wave & 1;
-    const int u_co = n0 + u_sub * 16 + (lane >> 2);
+    // weights, in three parts P of 6 positions per half: wave w fetches positions 18 (w & 1) + 6 P + 3 (w >> 1) + i, i = 0..2
+    const int u_xi0 = 18 * (wave & 1) + 3 * (wave >> 1);
+    const int u_co = n0 + (lane >> 2);
     const unsigned u_voff = (u_co < Cout_pad) ? (unsigned)((((u_xi0 * nc16) * Cout_pad + u_co) * 16 + (lane & 3) * 4) * 4) : W4_OOB;
     const int u_step = nc16 * Cout_pad * 64;        // bytes between consecutive positions
     auto issue_patch = [&](int c16) {
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             if (!(ABL & 1))
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(smem + (wave + W4_NW * i) * 256), 16, (int)p_voff[i],
-                                                         c16 * 64, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    xrsrc, (lptr_t)(smem + (wave + W4_NW * i < W4_NBP - 1 ? wave + W4_NW * i : W4_NBP - 1) * 256), 16,
+                    (int)p_voff[i], c16 * 64, 0, 0);
     };
     auto issue_u = [&](int c16, int part) {
         const int us = c16 * Cout_pad * 64;
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args 
         for (int i = 0; i < 3; ++i) {
             const int xi = u_xi0 + 6 * part + i;    // uniform
             if (!(ABL & 2))
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lptr_t)(smem + (W4_NBP + xi * 2 + u_sub) * 256), 16,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lptr_t)(smem + (W4_NBP + xi) * 256), 16,
                                                          (int)u_voff, us + (6 * part + i) * u_step, 0, 0);
         }
     };
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args 
     const int trow = 2 * g + trl;
     const float* pb_lo = smem + ((4 * trow) * W4_PS + tc) * 16 + ((fq ^ w4_pswz(4 * trow)) << 2);
     const float* pb_hi = smem + ((4 * trow) * W4_PS + tc) * 16 + ((fq ^ w4_pswz(4 * trow + 4)) << 2);
-    const int u_off = W4_PREC * 16 + ((18 * h) * 32 + nt * 16 + fr) * 16 + ((fq ^ w4_wswz(fr)) << 2);   // this wave's A-fragment rows
+    const int u_off = W4_PREC * 16 + ((18 * h) * 16 + fr) * 16 + ((fq ^ w4_wswz(fr)) << 2);   // this wave's A-fragment rows
 
     f32x4 acc[18];
     auto stage = [&](auto first, int c16) {
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args 
             for (int xp = 6 * part; xp < 6 * part + 6; xp += 2) {
                 f32x4 wf[2];
 #pragma unroll
-                for (int e = 0; e < 2; ++e) wf[e] = *reinterpret_cast<const f32x4*>(smem + u_off + (xp + e) * 32 * 16);
+                for (int e = 0; e < 2; ++e) wf[e] = *reinterpret_cast<const f32x4*>(smem + u_off + (xp + e) * 16 * 16);
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
                     const int k = kk >> 1, xl = xp + (kk & 1);
@@ -296,9 +300,9 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args 
         }
         WINO_SYNC();                             // every wave is past its last LDS read of the stage
         {
-            // exchange with the wave of the other half (same tile group, same cout tile = wave ^ 2): 8 f32x4 per lane,
+            // exchange with the wave of the other half (same tile group = wave ^ 1): 8 f32x4 per lane,
             // 32 + 4 floats per lane (conflict-free b128 accesses)
-            float* dst = smem + ((wave ^ 2) * 64 + lane) * 36;
+            float* dst = smem + ((wave ^ 1) * 64 + lane) * 36;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args 
         }
         WINO_SYNC();
         const float* src = smem + (wave * 64 + lane) * 36;
-        const int co = n0 + nt * 16 + fq * 4;
+        const int co = n0 + fq * 4;
         const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.y + (size_t)n * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
         if (co < a.Cout) {
@@ -318,263 +322,6 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args 
                 for (int j = 0; j < 4; ++j) {
                     f32x4 yv = Yp[2 * HH + i][j] + *reinterpret_cast<const f32x4*>(src + (i * 4 + j) * 4) + b4;
                     if (a.apply_act) {               // tf.nn.leaky_relu = max(v, slope * v)
-                        const f32x4 sv = yv * a.slope;
-                        yv[0] = fmaxf(yv[0], sv[0]); yv[1] = fmaxf(yv[1], sv[1]);
-                        yv[2] = fmaxf(yv[2], sv[2]); yv[3] = fmaxf(yv[3], sv[3]);
-                    }
-                    const int py = py0 + i * d, px = px0 + j * d;
-                    const unsigned vo = (py < a.H && px < a.W) ? (unsigned)(((py * a.W + px) * a.y_cs + co) * 4) : W4_OOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yv), yrsrc, (int)vo, 0, 0);
-                }
-        }
-    };
-    if (h == 0) epilogue(std::integral_constant<int, 0>{});
-    else epilogue(std::integral_constant<int, 1>{});
-#undef W4SUB
-#undef W4FMA
-#undef W4_WAIT_VM
-}
-
-// ---------------------------------------------------------------- wide form: 16 x 64-pixel blocks, both cout tiles per wave
-// The 16 x 32-pixel form above fetches 123 KB of LDS-DMA per 16-channel stage for 8 x 72 MFMAs -- 5.1 multiply-adds per
-// fetched byte against F(2x2)'s 9.8 -- and its two cout-tile waves duplicate the input transform (measured: 4.2 VALU
-// instructions per MFMA, matrix pipe 48 % busy).  Here a workgroup covers 4 x 16 tiles (16 x 64 pixels) x 32 couts:
-//   wave = (tile group g = (tile-row pair gr, 8-column half gc), position half h), BOTH cout tiles: 18 x 2 accumulator
-//          tiles (144 registers) + the 72 of V -- the register file of two waves per SIMD, to the last few;
-//   the stage is 80 KB of patch (18 x 66 pixels) + 74 KB of weights for 8 x 144 MFMAs: 8 multiply-adds per byte, one
-//   transform per 144 MFMAs.
-constexpr int W4W_PSR = 66;                   // patch records per patch row: quarters (px & 3) of 17, 17, 16, 16
-constexpr int W4W_PH = 18, W4W_PW = 66;
-constexpr int W4W_NBP = 80;                   // 16-record DMA blocks of the patch (1188 records used of 1280): 10 per wave
-constexpr int W4W_PREC = W4W_NBP * 16;
-constexpr int W4W_STAGE = (W4W_PREC + W4_NBU * 16) * 16;   // floats per LDS stage: 155 648 B
-constexpr int W4W_XCH = W4_NW * 64 * 68;      // output exchange: 8 waves x 64 lanes x (64 + 4 pad) floats = 139 264 B
-static_assert(W4W_XCH <= W4W_STAGE && W4W_STAGE * 4 <= 160 * 1024, "LDS");
-__device__ __forceinline__ constexpr int w4w_qoff(int q) { return q == 0 ? 0 : q == 1 ? 17 : q == 2 ? 34 : 50; }
-
-template <int ABL = 0>
-__global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4w_kernel(const Wino4Args a) {
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int g = wave >> 1, h = wave & 1;          // tile group (gr = g >> 1, gc = g & 1), position half
-    const int fr = lane & 15, fq = lane >> 4;
-    const int trow = 2 * (g >> 1) + (fr >> 3), tc = 8 * (g & 1) + (fr & 7);   // this lane's tile
-    float m1s;
-    asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(m1s));
-    const f32x4 M1 = {m1s, m1s, m1s, m1s};
-#define W4SUB(p, q) __builtin_elementwise_fma((q), M1, (p))
-#define W4FMA(x, c, y) __builtin_elementwise_fma((x), f32x4{c, c, c, c}, (y))
-#define W4_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
-
-    const int d = a.dil;
-    const int Cout_pad = (a.Cout + 15) & ~15;
-    const int nc16 = a.Cin_phys >> 4;
-    const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.up, 0, 36 * a.Cin_phys * Cout_pad * 4, 0x00020000);
-
-    int lb = pwc_xcd_remap(blockIdx.x, a.ntiles);
-    const int cb = lb % a.ncb;
-    int rest = lb / a.ncb;
-    const int bx = rest % a.tiles_x;
-    rest /= a.tiles_x;
-    const int by = rest % a.tiles_y;
-    rest /= a.tiles_y;
-    const int sub = rest % (d * d);
-    const int n = rest / (d * d);
-    const int ry = sub / d, rx = sub - ry * d;
-    const int y0 = by * 16, x0 = bx * 64;
-    const int n0 = cb * 32;
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.x + (size_t)n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
-
-    constexpr int PPW = W4W_NBP / W4_NW;            // patch blocks per wave (10)
-    unsigned p_voff[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int rec = (wave + W4_NW * i) * 16 + (lane >> 2);
-        const int py = rec / W4W_PSR, rem = rec - py * W4W_PSR;
-        const int q = rem < 17 ? 0 : rem < 34 ? 1 : rem < 50 ? 2 : 3;
-        const int ci = rem - w4w_qoff(q);
-        const int px = 4 * ci + q;
-        const int yy = ry + d * (y0 - 1 + py), xx = rx + d * (x0 - 1 + px);
-        const int ch = (lane & 3) ^ w4_pswz(py);
-        const bool ok = py < W4W_PH && px < W4W_PW && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-        p_voff[i] = ok ? (unsigned)(((yy * a.W + xx) * a.x_cs + ch * 4) * 4) : W4_OOB;
-    }
-    const int u_xi0 = 18 * ((wave >> 1) & 1) + 3 * (wave >> 2), u_sub = wave & 1;
-    const int u_co = n0 + u_sub * 16 + (lane >> 2);
-    const unsigned u_voff = (u_co < Cout_pad) ? (unsigned)((((u_xi0 * nc16) * Cout_pad + u_co) * 16 + (lane & 3) * 4) * 4) : W4_OOB;
-    const int u_step = nc16 * Cout_pad * 64;
-    auto issue_patch = [&](int c16) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i)
-            if (!(ABL & 1))
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(smem + (wave + W4_NW * i) * 256), 16, (int)p_voff[i],
-                                                         c16 * 64, 0, 0);
-    };
-    auto issue_u = [&](int c16, int part) {
-        const int us = c16 * Cout_pad * 64;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int xi = u_xi0 + 6 * part + i;
-            if (!(ABL & 2))
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lptr_t)(smem + (W4W_NBP + xi * 2 + u_sub) * 256), 16,
-                                                         (int)u_voff, us + (6 * part + i) * u_step, 0, 0);
-        }
-    };
-
-    const float* pb_lo = smem + ((4 * trow) * W4W_PSR + tc) * 16 + ((fq ^ w4_pswz(4 * trow)) << 2);
-    const float* pb_hi = smem + ((4 * trow) * W4W_PSR + tc) * 16 + ((fq ^ w4_pswz(4 * trow + 4)) << 2);
-    const int u_off = W4W_PREC * 16 + ((18 * h) * 32 + fr) * 16 + ((fq ^ w4_wswz(fr)) << 2);
-
-    f32x4 acc[18][2];
-    auto stage = [&](auto first, int c16) {
-        constexpr bool FIRST = decltype(first)::value;
-        const bool has_next = c16 + 1 < nc16;
-        W4_WAIT_VM(6);                               // patch(c) landed
-        WINO_SYNC();
-        issue_u(c16, 2);
-
-        f32x4 V[3][6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            f32x4 dd[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-                dd[i] = *reinterpret_cast<const f32x4*>((i < 4 ? pb_lo : pb_hi) + (i * W4W_PSR + w4w_qoff(j & 3) + (j >> 2)) * 16);
-            if (ABL & 64) {
-                V[0][j] = dd[0] + dd[3]; V[1][j] = dd[1] + dd[4]; V[2][j] = dd[2] + dd[5];
-            } else if (h == 0) {
-                V[0][j] = W4FMA(dd[0], 4.f, W4FMA(dd[2], -5.f, dd[4]));
-                const f32x4 s = dd[1] + dd[2], tt = dd[3] + dd[4], u = W4SUB(dd[1], dd[2]), v = W4SUB(dd[4], dd[3]);
-                V[1][j] = W4FMA(s, -4.f, tt);
-                V[2][j] = W4FMA(u, 4.f, v);
-            } else {
-                const f32x4 p = W4SUB(dd[4], dd[2]), q = W4SUB(dd[3], dd[1]);
-                V[0][j] = W4FMA(q, 2.f, p);
-                V[1][j] = W4FMA(q, -2.f, p);
-                V[2][j] = W4FMA(dd[1], 4.f, W4FMA(dd[3], -5.f, dd[5]));
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) asm("" : "+v"(V[r][j]));
-        if (!(ABL & 64)) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const f32x4 e0 = V[r][0], e1 = V[r][1], e2 = V[r][2], e3 = V[r][3], e4 = V[r][4], e5 = V[r][5];
-                const f32x4 s = e1 + e2, tt = e3 + e4, u = W4SUB(e1, e2), v = W4SUB(e4, e3);
-                const f32x4 p = W4SUB(e4, e2), q = W4SUB(e3, e1);
-                V[r][0] = W4FMA(e0, 4.f, W4FMA(e2, -5.f, e4));
-                V[r][1] = W4FMA(s, -4.f, tt);
-                V[r][2] = W4FMA(u, 4.f, v);
-                V[r][3] = W4FMA(q, 2.f, p);
-                V[r][4] = W4FMA(q, -2.f, p);
-                V[r][5] = W4FMA(e1, 4.f, W4FMA(e3, -5.f, e5));
-            }
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) asm("" : "+v"(V[r][j]));
-        }
-
-        auto mfma_part = [&](int part) {
-#pragma unroll
-            for (int xl = 6 * part; xl < 6 * part + 6; ++xl) {
-                f32x4 wf[2];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) wf[nt] = *reinterpret_cast<const f32x4*>(smem + u_off + (xl * 32 + nt * 16) * 16);
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    const int k = kk >> 1, nt = kk & 1;
-                    if (ABL & 4) {
-                        if (FIRST && k == 0) acc[xl][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        asm volatile("" ::"v"(wf[nt][k]), "v"(V[xl / 6][xl % 6][k]));
-                        continue;
-                    }
-                    const f32x4 c = (FIRST && k == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[xl][nt];
-                    acc[xl][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][k], V[xl / 6][xl % 6][k], c, 0, 0, 0);
-                }
-            }
-        };
-        W4_WAIT_VM(6);
-        WINO_SYNC();
-        if (has_next) issue_patch(c16 + 1);
-        mfma_part(0);
-        if (has_next) W4_WAIT_VM(3 + PPW); else W4_WAIT_VM(3);
-        WINO_SYNC();
-        if (has_next) issue_u(c16 + 1, 0);
-        mfma_part(1);
-        if (has_next) W4_WAIT_VM(PPW + 3); else W4_WAIT_VM(0);
-        WINO_SYNC();
-        if (has_next) issue_u(c16 + 1, 1);
-        mfma_part(2);
-    };
-    issue_patch(0);
-    issue_u(0, 0);
-    issue_u(0, 1);
-    stage(std::true_type{}, 0);
-    for (int c16 = 1; c16 < nc16; ++c16) stage(std::false_type{}, c16);
-
-    // ---- output transform; wave h finishes cout tile h and sends the partials of cout tile 1 - h to wave ^ 1
-    auto partial = [&](auto h_c, auto nt_c, f32x4 (&Yp)[4][4]) {
-        constexpr int HH = decltype(h_c)::value, nt = decltype(nt_c)::value;
-        f32x4 Z[3][4];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const f32x4 m0 = acc[r * 6 + 0][nt], m1 = acc[r * 6 + 1][nt], m2 = acc[r * 6 + 2][nt];
-            const f32x4 m3 = acc[r * 6 + 3][nt], m4 = acc[r * 6 + 4][nt], m5 = acc[r * 6 + 5][nt];
-            const f32x4 s12 = m1 + m2, d12 = W4SUB(m1, m2), s34 = m3 + m4, d34 = W4SUB(m3, m4);
-            Z[r][0] = m0 + s12 + s34;
-            Z[r][1] = W4FMA(d34, 2.f, d12);
-            Z[r][2] = W4FMA(s34, 4.f, s12);
-            Z[r][3] = W4FMA(d34, 8.f, d12) + m5;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (HH == 0) {
-                const f32x4 s = Z[1][j] + Z[2][j], dd = W4SUB(Z[1][j], Z[2][j]);
-                Yp[0][j] = Z[0][j] + s; Yp[1][j] = dd; Yp[2][j] = s; Yp[3][j] = dd;
-            } else {
-                const f32x4 s = Z[0][j] + Z[1][j], dd = W4SUB(Z[0][j], Z[1][j]);
-                Yp[0][j] = s; Yp[1][j] = dd * 2.f; Yp[2][j] = s * 4.f; Yp[3][j] = W4FMA(dd, 8.f, Z[2][j]);
-            }
-        }
-    };
-    auto epilogue = [&](auto h_c) {
-        constexpr int HH = decltype(h_c)::value;
-        WINO_SYNC();                             // every wave is past its last LDS read of the stage
-        {
-            f32x4 Ys[4][4];                          // the other cout tile: to the partner's slot
-            partial(h_c, std::integral_constant<int, 1 - HH>{}, Ys);
-            float* dst = smem + ((wave ^ 1) * 64 + lane) * 68;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + (i * 4 + j) * 4) = Ys[i][j];
-        }
-        f32x4 Yk[4][4];
-        partial(h_c, h_c, Yk);
-        WINO_SYNC();
-        const float* src = smem + (wave * 64 + lane) * 68;
-        const int co = n0 + HH * 16 + fq * 4;
-        const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.y + (size_t)n * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
-        if (co < a.Cout) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + co);
-            const int py0 = ry + d * (y0 + 4 * trow), px0 = rx + d * (x0 + 4 * tc);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 yv = Yk[i][j] + *reinterpret_cast<const f32x4*>(src + (i * 4 + j) * 4) + b4;
-                    if (a.apply_act) {
                         const f32x4 sv = yv * a.slope;
                         yv[0] = fmaxf(yv[0], sv[0]); yv[1] = fmaxf(yv[1], sv[1]);
                         yv[2] = fmaxf(yv[2], sv[2]); yv[3] = fmaxf(yv[3], sv[3]);
@@ -644,18 +391,17 @@ extern "C" int pwc_conv3x3_wino4_pack_f32(const float* w_hwio, const int32_t* ci
     return pwc_launch_status();
 }
 
-// Where F(4x4) pays (measured against conv3x3_wino.hip: scripts/exp_wino4.hip on isolated layers, profiles/
-// r03_exp_wino4.txt, and in the forward, profiles/r03_timeline_batch8.txt): launches that fill the GPU with 16 x 32-pixel
-// blocks and whose channel loop is long -- undilated layers with Cin_phys >= 128 and Cout >= 128 (307 vs 323, 248 vs 267,
-// 103 vs 114, 70 vs 81 us), and the d = 8 layer whose 14 x 32 sub-lattices fill F(2x2)'s 16 x 16 blocks badly (208 vs 227
-// us).  128 -> 96 undilated and the d = 2, 4 layers are level or slower in the forward and stay on F(2x2); so do 7-row
-// sub-lattices (d = 16: conv3x3_wino.hip's SPLIT geometry) and launches of fewer than 256 workgroups.
+// Where F(4x4) pays (measured against conv3x3_wino.hip: scripts/exp_wino4.hip on isolated layers, profiles/r03_exp_wino4.txt,
+// and in the forward): launches that fill the GPU with 16 x 32-pixel blocks x 16 couts and whose channel loop is long --
+// Cin_phys >= 96 and Cout >= 64 on maps (or dilation sub-lattices) of at least 14 x 28 pixels that fill their blocks to
+// 80 % and make 256 workgroups.  x1.15 - 1.2 on the undilated 160/128 -> 128, 128 -> 96 and 96 -> 64 layers and on d = 8;
+// d = 2, 4 are worth x1.05; 7-row sub-lattices (d = 16: conv3x3_wino.hip's SPLIT geometry) and shorter launches stay on
+// F(2x2).  (The rule was swept in the forward: 256 / 384 / 512 / 1024 workgroups, with and without d = 2, 4.)
 extern "C" int pwc_conv3x3_wino4_supported(int N, int H, int W, int Cin_phys, int Cout, int dilation) {
-    if (N <= 0 || H <= 0 || W <= 0 || dilation < 1 || Cin_phys < 128 || (Cin_phys % 16) || Cout < 96 || (Cout % 32)) return 0;
-    if (!((dilation == 1 && Cout >= 128) || dilation >= 8)) return 0;
+    if (N <= 0 || H <= 0 || W <= 0 || dilation < 1 || Cin_phys < 96 || (Cin_phys % 16) || Cout < 64 || (Cout % 16)) return 0;
     const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
     if (hs < 14 || ws < 28) return 0;
-    const long blocks = (long)N * dilation * dilation * ((hs + 15) / 16) * ((ws + 31) / 32) * (Cout / 32);
+    const long blocks = (long)N * dilation * dilation * ((hs + 15) / 16) * ((ws + 31) / 32) * (Cout / 16);
     const double fill = (double)hs * ws / ((double)(((hs + 15) / 16) * 16) * (((ws + 31) / 32) * 32));
     return blocks >= 256 && fill >= 0.8 ? 1 : 0;
 }
@@ -672,24 +418,12 @@ static int wino4_launch(const Wino4Args& a, hipStream_t stream) {
     return pwc_launch_status();
 }
 
-template <int ABL>
-static int wino4w_launch(const Wino4Args& a, hipStream_t stream) {
-    const size_t lds = (size_t)W4W_STAGE * sizeof(float);
-    static PwcDevOnce attr_once;   // the attribute is per device
-    if (pwc_first_on_device(&attr_once)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4w_kernel<ABL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
-    hipLaunchKernelGGL((conv3x3_wino4w_kernel<ABL>), dim3((unsigned)a.ntiles), dim3(W4_T), lds, stream, a);
-    return pwc_launch_status();
-}
-
 extern "C" int pwc_conv3x3_wino4_f32(const float* x, int x_cs, const float* packed_u, const float* bias, float* y,
                                      int y_cs, int N, int H, int W, int Cin_phys, int Cout, int dilation,
                                      int apply_act, float slope, pwc_stream_t stream) {
     if (!x || !packed_u || !bias || !y) return PWC_EINVAL;
     if (N <= 0 || H <= 0 || W <= 0 || Cin_phys <= 0 || Cout <= 0 || dilation < 1) return PWC_EINVAL;
-    if (Cin_phys % 16 || Cout % 32) return PWC_EUNSUPPORTED;
+    if (Cin_phys % 16 || Cout % 16) return PWC_EUNSUPPORTED;
     if (x_cs < Cin_phys || y_cs < Cout) return PWC_EINVAL;
     if ((x_cs & 3) || (y_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(y) || !pwc_aligned16(packed_u) || !pwc_aligned16(bias))
         return PWC_EALIGN;
@@ -700,7 +434,7 @@ extern "C" int pwc_conv3x3_wino4_f32(const float* x, int x_cs, const float* pack
     a.N = N; a.H = H; a.W = W; a.Cin_phys = Cin_phys; a.Cout = Cout; a.apply_act = apply_act; a.slope = slope;
     a.dil = dilation;
     const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
-    a.tiles_x = (ws + 31) / 32; a.tiles_y = (hs + 15) / 16; a.ncb = Cout / 32;
+    a.tiles_x = (ws + 31) / 32; a.tiles_y = (hs + 15) / 16; a.ncb = Cout / 16;
     const long nblk = (long)N * dilation * dilation * a.tiles_x * a.tiles_y * a.ncb;
     if (nblk >= (1L << 31)) return PWC_ERANGE;
     a.ntiles = (int)nblk;

@@ -106,38 +106,11 @@ int main(int argc, char** argv) {
                    gf / t4 * 1e-3 * 1e3, t2 / t4);
             fflush(stdout);
         }
-        {   // wide form (16 x 64-pixel blocks, both cout tiles per wave)
-            Wino4Args a{};
-            a.x = x; a.up = u4; a.bias = b; a.y = y4; a.x_cs = sh.xcs; a.y_cs = ycs; a.N = sh.N; a.H = sh.H; a.W = sh.W;
-            a.Cin_phys = sh.Cin; a.Cout = sh.Cout; a.apply_act = 1; a.slope = 0.1f; a.dil = sh.dil;
-            const int hs = (sh.H + sh.dil - 1) / sh.dil, ws = (sh.W + sh.dil - 1) / sh.dil;
-            a.tiles_x = (ws + 63) / 64; a.tiles_y = (hs + 15) / 16; a.ncb = sh.Cout / 32;
-            a.ntiles = sh.N * sh.dil * sh.dil * a.tiles_x * a.tiles_y * a.ncb;
-            (void)hipMemset(y4, 0, npix * ycs * 4);
-            wino4w_launch<0>(a, 0);
-            (void)hipDeviceSynchronize();
-            (void)hipMemcpy(h4.data(), y4, h4.size() * 4, hipMemcpyDeviceToHost);
-            double mdw = 0; size_t badw = 0;
-            for (size_t p = 0; p < npix; ++p)
-                for (int c = 0; c < sh.Cout; ++c) {
-                    const double dlt = fabs((double)h4[p * ycs + c] - h2[p * ycs + c]);
-                    mdw = fmax(mdw, dlt);
-                    if (dlt > 2e-4) { if (badw < 4) printf("    wide mismatch n %zu y %zu x %zu c %d: %.6f vs %.6f\n", p / ((size_t)sh.H * sh.W), (p / sh.W) % sh.H, p % sh.W, c, h4[p * ycs + c], h2[p * ycs + c]); ++badw; }
-                }
-            const float tw = time_us([&](int) { wino4w_launch<0>(a, 0); }, 10);
-            const float tw2 = time_us([&](int) { wino4w_launch<0>(a, 0); }, 10);
-            printf("  WIDE F(4x4): max |diff| vs F(2x2) %.3e, %zu entries > 2e-4; %.1f / %.1f us; hip: %s\n", mdw, badw, tw, tw2, hipGetErrorString(hipGetLastError()));
-            if (idx == 0)
-                printf("  WIDE ablations: no patch DMA %.1f us | no weight DMA %.1f us | no DMA %.1f us | no MFMA %.1f us | no MFMA, no transform %.1f us | no transform %.1f us\n",
-                       time_us([&](int) { wino4w_launch<1>(a, 0); }, 10), time_us([&](int) { wino4w_launch<2>(a, 0); }, 10),
-                       time_us([&](int) { wino4w_launch<3>(a, 0); }, 10), time_us([&](int) { wino4w_launch<4>(a, 0); }, 10),
-                       time_us([&](int) { wino4w_launch<4 | 64>(a, 0); }, 10), time_us([&](int) { wino4w_launch<64>(a, 0); }, 10));
-        }
         if (idx == 0) {
             Wino4Args a{};
             a.x = x; a.up = u4; a.bias = b; a.y = y4; a.x_cs = sh.xcs; a.y_cs = ycs; a.N = sh.N; a.H = sh.H; a.W = sh.W;
             a.Cin_phys = sh.Cin; a.Cout = sh.Cout; a.apply_act = 1; a.slope = 0.1f; a.dil = 1;
-            a.tiles_x = (sh.W + 31) / 32; a.tiles_y = (sh.H + 15) / 16; a.ncb = sh.Cout / 32;
+            a.tiles_x = (sh.W + 31) / 32; a.tiles_y = (sh.H + 15) / 16; a.ncb = sh.Cout / 16;
             a.ntiles = sh.N * a.tiles_x * a.tiles_y * a.ncb;
             printf("  ablations: no patch DMA %.1f us | no weight DMA %.1f us | no DMA %.1f us | no MFMA %.1f us | no MFMA, no transform %.1f us | no transform %.1f us\n",
                    time_us([&](int) { wino4_launch<1>(a, 0); }, 10), time_us([&](int) { wino4_launch<2>(a, 0); }, 10),

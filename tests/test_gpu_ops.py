@@ -192,7 +192,8 @@ def run_conv_wino4(x, k, b, slope, cin_map=None, y_cs=None, dil=1):
 
 @pytest.mark.parametrize("N,H,W,cin,cout,dil", [
     (1, 32, 64, 128, 128, 1), (2, 16, 32, 64, 32, 1), (1, 33, 47, 32, 64, 1), (1, 5, 3, 16, 32, 1), (2, 50, 70, 160, 96, 1),
-    (1, 56, 64, 128, 96, 2), (1, 40, 48, 64, 64, 4), (1, 112, 96, 32, 32, 8), (2, 19, 23, 48, 64, 3)])
+    (1, 56, 64, 128, 96, 2), (1, 40, 48, 64, 64, 4), (1, 112, 96, 32, 32, 8), (2, 19, 23, 48, 64, 3), (1, 20, 40, 32, 16, 1),
+    (2, 30, 33, 80, 48, 1)])
 def test_conv_winograd_f4x4_vs_oracle(pa, N, H, W, cin, cout, dil):
     """pwc_conv3x3_wino4_f32 (Winograd F(4x4,3x3)): ragged 16 x 32-pixel blocks, dilations (sub-lattices), short and long
     channel loops, strided output with untouched neighbours.  Tolerance: F(4x4) rounds ~10x coarser than F(2x2)
@@ -225,11 +226,14 @@ def test_conv_winograd_f4x4_physical_layout_and_plan(pa):
     assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 160, 128, 1) == 1
     assert L.pwc_conv3x3_wino4_supported(8, 56, 128, 192, 128, 1) == 1
     assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 128, 96, 8) == 1
-    assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 128, 96, 1) == 0      # F(2x2) is level there
-    assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 128, 128, 4) == 0     # ... and on the d = 2, 4 layers
-    assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 96, 64, 1) == 0
+    assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 128, 96, 1) == 1      # 16-cout workgroups: 96 and 64 couts pay too
+    assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 128, 128, 4) == 1     # ... and the d = 2, 4 layers (x1.05)
+    assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 96, 64, 1) == 1
+    assert L.pwc_conv3x3_wino4_supported(4, 56, 128, 128, 96, 1) == 1       # a side-stream sub-batch at level 3
+    assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 64, 32, 1) == 0       # short channel loops stay on F(2x2)
     assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 128, 64, 16) == 0     # 7-row sub-lattices
-    assert L.pwc_conv3x3_wino4_supported(1, 112, 256, 128, 128, 1) == 0     # a single pair does not fill the GPU
+    assert L.pwc_conv3x3_wino4_supported(1, 56, 128, 128, 128, 1) == 0      # 128 workgroups do not fill the GPU
+    assert L.pwc_conv3x3_wino4_supported(8, 14, 32, 128, 128, 1) == 0       # ... nor does a coarse level
 
 
 @pytest.mark.parametrize("N,H,W,cin,cout,dil,csplit", [
@@ -423,7 +427,8 @@ def test_conv_direct_residual_flow_head(pa):
     close(run_conv_direct(x, k, b, 1, 1, None, residual=res), orc.conv3x3(x, k, b, 1, 1, None, residual=res))
 
 
-@pytest.mark.parametrize("N,H,W,res", [(1, 128, 128, True), (2, 131, 150, False), (1, 112, 256, True)])
+@pytest.mark.parametrize("N,H,W,res", [(1, 128, 128, True), (2, 131, 150, False), (1, 112, 256, True), (8, 112, 256, True),
+                                       (1, 8, 2050, False)])
 def test_conv_flow_head_tiled_kernel(pa, N, H, W, res):
     """32 -> 2 heads on maps of >= 16384 pixels take the LDS-tiled kernel (8 x 32-pixel tiles, ragged edges here)."""
     x = rnd((N, H, W, 32), 117)
