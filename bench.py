@@ -367,6 +367,20 @@ def main():
                 "note": "achieved/frac = multiply-adds the MFMA units execute (Winograd: 16 per 2x2 outputs "
                         "and 36 per 4x4 outputs instead of 9 per output, physical Cin); algorithmic_* = "
                         "2*M*9*Cin*Cout of the direct convolution the launch replaces (SURVEY.md 8d)"}
+        caps = {"conv3x3_wino_kernel": 0.83, "conv3x3_wino4_kernel": 0.62}
+        if dominant in caps:
+            roof["instruction_mix_cap"] = {
+                "frac": caps[dominant],
+                "why": "on gfx950 no VALU / LDS / memory instruction overlaps an fp32 MFMA of the same SIMD (measured: "
+                       "profiles/r03_exp_fp32_mfma_excludes_valu.txt); cap = 32 N_mfma / (32 N_mfma + 6.3 N_valu + 3 N_lds + "
+                       "7 N_dma) of the kernel's main loop (DESIGN.md 3.4)"}
+        total_ms = sum(v["ms"] for v in summ.values())
+        roof["other_mfma_kernels"] = {
+            k: {"frac": v["exec_flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "algorithmic_tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                "avg_launch_us": 1e3 * v["ms"] / v["launches"], "launches_per_step": v["launches"] / n_sampled,
+                "share_of_kernel_time": v["ms"] / total_ms}
+            for k, v in summ.items() if k != dominant and v.get("exec_flops", 0) > 0 and v["ms"] > 0.05 * total_ms}
         prof = os.path.join(ROOT, "profiles")
         pmc = os.path.join(prof, "pmc_traffic.json")
         if os.path.exists(pmc) and (B, H, Wd, args.use_dc) == (8, 448, 1024, False):

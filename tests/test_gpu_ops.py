@@ -230,7 +230,7 @@ def test_conv_winograd_f4x4_physical_layout_and_plan(pa):
     assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 128, 128, 4) == 1     # ... and the d = 2, 4 layers (x1.05)
     assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 96, 64, 1) == 1
     assert L.pwc_conv3x3_wino4_supported(4, 56, 128, 128, 96, 1) == 1       # a side-stream sub-batch at level 3
-    assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 64, 32, 1) == 0       # short channel loops stay on F(2x2)
+    assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 32, 32, 1) == 0       # short channel loops stay on F(2x2)
     assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 128, 64, 16) == 0     # 7-row sub-lattices
     assert L.pwc_conv3x3_wino4_supported(1, 56, 128, 128, 128, 1) == 0      # 128 workgroups do not fill the GPU
     assert L.pwc_conv3x3_wino4_supported(8, 14, 32, 128, 128, 1) == 0       # ... nor does a coarse level
