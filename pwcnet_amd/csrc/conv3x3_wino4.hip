@@ -79,7 +79,7 @@ __device__ __forceinline__ int w4_wswz(int row) { return (4 - ((row >> 2) & 3)) 
 __device__ __forceinline__ int w4_pswz(int py) { return ((py >> 2) & 1) << 1; }
 
 // ABL (scripts/exp_wino4.hip only; 0 in the library): 1 = no patch DMA, 2 = no weight DMA, 4 = no MFMA, 64 = no
-// transform arithmetic
+// transform arithmetic, 8 / 16 = the same patch / weight requests from a few hot cache lines
 template <int ABL = 0>
 __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args a) {
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args 
             if (!(ABL & 1))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     xrsrc, (lptr_t)(smem + (wave + W4_NW * i < W4_NBP - 1 ? wave + W4_NW * i : W4_NBP - 1) * 256), 16,
-                    (int)p_voff[i], c16 * 64, 0, 0);
+                    (ABL & 8) ? (int)(p_voff[i] & 4095u) : (int)p_voff[i], (ABL & 8) ? 0 : c16 * 64, 0, 0);
     };
     auto issue_u = [&](int c16, int part) {
         const int us = c16 * Cout_pad * 64;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(W4_T, 2) void conv3x3_wino4_kernel(const Wino4Args 
             const int xi = u_xi0 + 6 * part + i;    // uniform
             if (!(ABL & 2))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lptr_t)(smem + (W4_NBP + xi) * 256), 16,
-                                                         (int)u_voff, us + (6 * part + i) * u_step, 0, 0);
+                                                         (int)u_voff, (ABL & 16) ? 0 : us + (6 * part + i) * u_step, 0, 0);
         }
     };
 #define W4_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))

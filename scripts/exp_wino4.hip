@@ -116,6 +116,9 @@ int main(int argc, char** argv) {
                    time_us([&](int) { wino4_launch<1>(a, 0); }, 10), time_us([&](int) { wino4_launch<2>(a, 0); }, 10),
                    time_us([&](int) { wino4_launch<3>(a, 0); }, 10), time_us([&](int) { wino4_launch<4>(a, 0); }, 10),
                    time_us([&](int) { wino4_launch<4 | 64>(a, 0); }, 10), time_us([&](int) { wino4_launch<64>(a, 0); }, 10));
+            printf("  same instructions, fetches from hot lines: patch %.1f us | weights %.1f us | both %.1f us | both, no MFMA no transform %.1f us\n",
+                   time_us([&](int) { wino4_launch<8>(a, 0); }, 10), time_us([&](int) { wino4_launch<16>(a, 0); }, 10),
+                   time_us([&](int) { wino4_launch<24>(a, 0); }, 10), time_us([&](int) { wino4_launch<24 | 4 | 64>(a, 0); }, 10));
         }
         (void)hipFree(x); (void)hipFree(w); (void)hipFree(b); (void)hipFree(y2); (void)hipFree(y4); (void)hipFree(u2); (void)hipFree(u4);
     }
