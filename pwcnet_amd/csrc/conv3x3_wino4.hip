@@ -400,7 +400,7 @@ extern "C" int pwc_conv3x3_wino4_pack_f32(const float* w_hwio, const int32_t* ci
 // dense-connection estimators (use_dc=True: 205 pairs/s with F(4x4) on them, 212 - 215 without).  (The rule was swept in the
 // forward: 256 / 384 / 512 / 1024 workgroups, with and without d = 2, 4, Cin >= 96 / 64 / 48 / 32, Cout >= 64 / 32.)
 extern "C" int pwc_conv3x3_wino4_supported(int N, int H, int W, int Cin_phys, int Cout, int dilation) {
-    if (N <= 0 || H <= 0 || W <= 0 || dilation < 1 || Cin_phys < 48 || Cin_phys > 160 || (Cin_phys % 16) || Cout < 32 || (Cout % 16)) return 0;
+    if (N <= 0 || H <= 0 || W <= 0 || dilation < 1 || Cin_phys < 48 || Cin_phys > 256 || (Cin_phys % 16) || Cout < 32 || (Cout % 16)) return 0;
     const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
     if (hs < 14 || ws < 28) return 0;
     const long blocks = (long)N * dilation * dilation * ((hs + 15) / 16) * ((ws + 31) / 32) * (Cout / 16);

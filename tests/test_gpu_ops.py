@@ -224,7 +224,7 @@ def test_conv_winograd_f4x4_physical_layout_and_plan(pa):
     b = rnd((cout,), 184) * 0.1
     close(run_conv_wino4(xp, k, b, 0.1, cin_map=cmap), orc.conv3x3(xl, k, b, 1, 1, 0.1), rel=2e-5)
     assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 160, 128, 1) == 1
-    assert L.pwc_conv3x3_wino4_supported(8, 56, 128, 160, 128, 1) == 1
+    assert L.pwc_conv3x3_wino4_supported(8, 56, 128, 192, 128, 1) == 1
     assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 288, 128, 1) == 0     # the dense-connection inputs stay on F(2x2)
     assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 128, 96, 8) == 1
     assert L.pwc_conv3x3_wino4_supported(8, 112, 256, 128, 96, 1) == 1      # 16-cout workgroups: 96 and 64 couts pay too
