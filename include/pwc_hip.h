@@ -189,8 +189,9 @@ long pwc_conv3x3_wino_workgroups(int N, int H, int W, int Cout, int dilation);
  * `context/conv2d_1..conv2d_3`).  fp32 throughout; its rounding error is ~10x that of F(2x2) per layer (2e-6 of the
  * activation scale) and leaves the end-to-end flow error where a direct fp32 convolution puts it (profiles/
  * r03_f4x4_numerics.txt).  packed_u comes from pwc_conv3x3_wino4_pack_f32 ([36][Cin_phys/16][Cout_pad][16] floats).
- * Needs Cout % 32 == 0, Cin_phys % 16 == 0, y 16-byte aligned with y_cs % 4 == 0.  pwc_conv3x3_wino4_supported: 1
- * where it is the faster kernel for the shape (large launches with Cin_phys >= 128, Cout >= 96), 0 otherwise. */
+ * Needs Cout % 16 == 0, Cin_phys % 16 == 0, y 16-byte aligned with y_cs % 4 == 0.  pwc_conv3x3_wino4_supported: 1
+ * where it is the faster kernel for the shape (48 <= Cin_phys <= 256, Cout >= 32, at least 256 workgroups of 16 x 32
+ * pixels x 16 couts, sub-lattices of at least 14 x 28 pixels), 0 otherwise. */
 size_t pwc_conv3x3_wino4_packed_floats(int Cin_phys, int Cout);
 int pwc_conv3x3_wino4_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin, int Cin_phys,
                                int Cout, float* packed_u, pwc_stream_t stream);
