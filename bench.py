@@ -75,8 +75,6 @@ def parse(argv=None):
                          "--gpus 8 / 2 unless --gpus is given)")
     ap.add_argument("--spawn", action="store_true", help="go through torch.distributed.run even for --gpus 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-process-group", action="store_true",
-                    help="--gpus 1 in a plain process: skip the RCCL process group of world size 1")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget")
     ap.add_argument("--no-op-timing", action="store_true", help="skip the per-launch HIP events")
     ap.add_argument("--no-op-leg", action="store_true", help="skip the op-level correlation/warp leg")
@@ -197,15 +195,6 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with "
                          f"`python bench.py --gpus {args.gpus}` (it spawns the ranks itself) or pass the "
                          "matching --nproc-per-node")
-    own_group = False
-    if env_world is None and not args.no_process_group and args.mode != "train":
-        # one GPU, launched as a plain process: this process is rank 0 of a world of 1 and runs the SAME code as a rank of
-        # the N-GPU job -- RCCL process group, barriers around the timed region, all-gather of the statistics.  (Measured: a
-        # forward in a process that holds a live RCCL communicator created before the model is 1.4 % faster than in one that
-        # does not -- scripts/exp_poll.py, profiles/r03_exp_process_group.txt; a gloo group, a communicator created after
-        # the model, a destroyed one, extra streams, pinned / fine-grained allocations do not reproduce it.)
-        os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-        env_world, own_group = "1", True
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -222,12 +211,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl = RCCL on ROCm
             dist.barrier()
             torch.cuda.synchronize()
-        except Exception as e:                      # a world of 1 can do without: say so and go on
-            if not own_group:
-                raise
-            print(f"bench.py: no RCCL process group for the single-GPU run ({type(e).__name__}: {e}); continuing without",
-                  file=sys.stderr)
-            dist = None
         finally:
             sys.stdout.flush()
             try:                                    # the banner sits in C stdio's buffer when stdout is a pipe

@@ -266,3 +266,15 @@ def test_sub_batches_on_side_streams_give_the_same_flows(pa):
     # an odd batch falls back to the single-stream path
     c, _ = net(g0[:3], g1[:3])
     assert float((c - ra[:3]).abs().max()) <= 2e-5 * max(1.0, float(ra.abs().max()))
+    # called on a stream of the caller's: sub-batch 0 runs on THAT stream, the results are ordered after it
+    import torch
+    user = torch.cuda.Stream()
+    user.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(user):
+        for _ in range(2):
+            d, _ = net(h0, h1)
+        d2 = d * 1.0                                    # consumer on the caller's stream
+    user.synchronize()
+    assert float((d2 - rb).abs().max()) <= 2e-5 * max(1.0, float(rb.abs().max()))
+    side = [s for v in net._side_streams.values() for s in v]
+    assert all(s.cuda_stream != user.cuda_stream for s in side) and len(net._side_streams) == 2
