@@ -190,6 +190,8 @@ class PWCDCNet(object):
         skey = (str(dev), main.cuda_stream)
         streams = self._side_streams.get(skey)
         if streams is None or len(streams) != k - 1:
+            while len(self._side_streams) >= 4:              # callers that come with a new stream every time
+                self._side_streams.pop(next(iter(self._side_streams)))
             streams = self._side_streams[skey] = _pick_side_streams(dev, main, k - 1)
         final = torch.empty((N, H, W, 2), dtype=torch.float32, device=dev)
         pyr = [torch.empty((N, H >> (self.num_levels - l), W >> (self.num_levels - l), 2), dtype=torch.float32, device=dev)
