@@ -84,7 +84,7 @@ def parse(argv=None):
     ap.add_argument("--loss", choices=("multiscale", "robust"), default="multiscale", help="--mode train")
     ap.add_argument("--streams", type=int, default=0,
                     help="PWCDCNet(streams=K): the batch runs as K sub-batches on side HIP streams whose kernels overlap; "
-                         "0 = the model's default (2 for even batches >= 4, else 1), 1 = single stream.  The per-kernel "
+                         "0 = the model's default (2 for even batches >= 4 and for 2 large pairs, else 1), 1 = single stream.  The per-kernel "
                          "roofline legs always come from single-stream passes.")
     ap.add_argument("--persistent-outputs", action="store_true",
                     help="PWCDCNet(persistent_outputs=True): replays write into the plan's own output tensors")
@@ -238,7 +238,7 @@ def main():
     net = pwcnet_amd.PWCDCNet(use_dc=args.use_dc, persistent_outputs=args.persistent_outputs,
                               streams=args.streams if args.streams > 0 else None)
     net.load_weights(wts)
-    eff_streams = net.streams if net.streams is not None else (2 if (args.batch >= 4 and args.batch % 2 == 0) else 1)
+    eff_streams = net.streams if net.streams is not None else (2 if (args.batch % 2 == 0 and (args.batch >= 4 or (args.batch == 2 and args.height * args.width >= 256 * 512))) else 1)
     if args.persistent_outputs:
         eff_streams = 1
     overlapped = eff_streams > 1      # HIP events on the caller's stream do not bracket side-stream kernels

@@ -115,7 +115,7 @@ class PWCDCNet(object):
         # latency-bound coarse levels of one overlap the MFMA-bound layers of another (+4-5 % pairs/s at batch 8,
         # scripts/exp_two_streams.py, profiles/r02_bench_streams2.json).  Same results and the same stream semantics
         # for the caller (the side streams wait for the caller's stream, the caller's stream waits for them).
-        # streams=None (default): 2 for even batches of at least 4 pairs, 1 otherwise; streams=1 switches it off
+        # streams=None (default): 2 for even batches of at least 4 pairs (and for 2 pairs of at least 256x512 pixels), 1 otherwise; streams=1 switches it off
         # (per-kernel timings -- profilers, HIP events on the caller's stream -- need the single-stream form).
         self.streams = None if streams is None else max(1, int(streams))
         self._side_streams = {}
@@ -172,7 +172,10 @@ class PWCDCNet(object):
         tensors are new on every call unless the model was built with persistent_outputs=True
         (then they are the launch plan's own tensors, overwritten by the next call of that shape)."""
         n_batch = getattr(images_0, "shape", (0,))[0]
-        k = self.streams if self.streams is not None else (2 if (n_batch >= 4 and n_batch % 2 == 0) else 1)
+        k = self.streams
+        if k is None:       # even batches; a batch of 2 only at sizes where a single pair fills the GPU (+5 % at 448x1024)
+            hw = (images_0.shape[1] * images_0.shape[2]) if getattr(images_0, "ndim", 0) == 4 else 0
+            k = 2 if (n_batch % 2 == 0 and (n_batch >= 4 or (n_batch == 2 and hw >= 256 * 512))) else 1
         if k > 1:
             self.max_plans = max(self.max_plans, k + 1)     # a plan per sub-batch stream + the whole-batch one
         if (k > 1 and self.use_plans and not self.persistent_outputs and not with_features and _m._RECORDER is None
