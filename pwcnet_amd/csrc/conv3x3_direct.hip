@@ -199,88 +199,10 @@ __global__ __launch_bounds__(256) void conv3x3_head2_c32_kernel(const DirectArgs
     }
 }
 
-// Flow heads on large maps (32 -> 2, stride 1, dilation 1; modules.py:274,324 at pyramid level 4): the kernel above
-// re-reads every input pixel 9 times through L1 (32 us for the 31 MB of the 112 x 256 level = 1 TB/s).  Here a
-// workgroup stages the (8+2) x (32+2)-pixel patch of its 8 x 32-pixel tile in LDS ONCE, quad-major ([channel quad]
-// [pixel]: consecutive lanes = consecutive pixels read consecutive 16-byte slots, plane stride odd in slots so that the
-// 8 quads of a pixel land in different slots when written); thread = output pixel, 72 ds_read_b128 + 576 FMAs, the
-// weights of a (tap, quad) are wave-uniform (scalar loads).
+// Tile geometry of the LDS-staged flow-head kernel for wide inputs below ((8+2) x (32+2)-pixel patches, quad-major planes).
+// (The 32-channel heads of the large levels ran a kernel of this shape in rounds 1-2 -- 72 ds_read_b128 + 576 FMAs per
+// output -- and take conv3x3_head2_mfma_kernel now.)
 constexpr int HT_R = 8, HT_C = 32, HT_PW = HT_C + 2, HT_NP = (HT_R + 2) * HT_PW, HT_PLANE = HT_NP * 4 + 4;
-
-__global__ __launch_bounds__(256) void conv3x3_head2_tile_kernel(const DirectArgs a, int tiles_x, int tiles_y, int ntiles) {
-    __shared__ __attribute__((aligned(16))) float patch[8 * HT_PLANE];
-    __shared__ __attribute__((aligned(16))) float wsm[9 * 64];   // [tap][32 ci][2 co]: read as broadcasts
-    constexpr int NLD = (HT_NP * 8 + 255) / 256;             // b128 pieces per thread and tile (11)
-    const int t = threadIdx.x;
-    for (int e = t; e < 9 * 64; e += 256) wsm[e] = a.w[e];
-    // this thread's pieces (same for every tile): patch pixel (py, px), channel quad, LDS slot
-    int ppy[NLD], ppx[NLD], lslot[NLD];
-#pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-        const int e = t + 256 * j;
-        const int p = e >> 3, q = e & 7;
-        ppy[j] = p / HT_PW;
-        ppx[j] = p - ppy[j] * HT_PW;
-        lslot[j] = e < HT_NP * 8 ? q * HT_PLANE + p * 4 : -1;
-    }
-    // persistent: the workgroup walks tiles blockIdx.x, + gridDim.x, ...; the next tile's patch is fetched into
-    // registers while the current one is reduced from LDS (a workgroup with a single tile spends most of its life
-    // waiting for that one fetch)
-    f32x4 st[NLD];
-    auto fetch = [&](int tile) {
-        const int bx = tile % tiles_x;
-        const int by = (tile / tiles_x) % tiles_y;
-        const int n = tile / (tiles_x * tiles_y);
-        const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs + (t & 7) * 4;
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int y = by * HT_R - 1 + ppy[j], x = bx * HT_C - 1 + ppx[j];
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (lslot[j] >= 0 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
-                v = *reinterpret_cast<const f32x4*>(xn + ((size_t)y * a.W + x) * a.x_cs);
-            st[j] = v;
-        }
-    };
-    const int r = t >> 5, c = t & 31;
-    const float b0 = a.bias[0], b1 = a.bias[1];
-    int tile = blockIdx.x;
-    if (tile < ntiles) fetch(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
-        __syncthreads();                                      // the previous tile has been read (first pass: wsm written)
-#pragma unroll
-        for (int j = 0; j < NLD; ++j)
-            if (lslot[j] >= 0) *reinterpret_cast<f32x4*>(patch + lslot[j]) = st[j];
-        __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
-        float s0a = 0.f, s0b = 0.f, s1a = 0.f, s1b = 0.f;
-#pragma unroll
-        for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-            for (int tx = 0; tx < 3; ++tx) {
-                const float* pp = patch + ((r + ty) * HT_PW + c + tx) * 4;
-                const float* wt = wsm + (ty * 3 + tx) * 64;                  // [32 ci][2 co] of this tap
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(pp + q * HT_PLANE);
-                    const f32x4 wa = *reinterpret_cast<const f32x4*>(wt + q * 8), wb = *reinterpret_cast<const f32x4*>(wt + q * 8 + 4);
-                    s0a = fmaf(v[0], wa[0], s0a); s1a = fmaf(v[0], wa[1], s1a);
-                    s0b = fmaf(v[1], wa[2], s0b); s1b = fmaf(v[1], wa[3], s1b);
-                    s0a = fmaf(v[2], wb[0], s0a); s1a = fmaf(v[2], wb[1], s1a);
-                    s0b = fmaf(v[3], wb[2], s0b); s1b = fmaf(v[3], wb[3], s1b);
-                }
-            }
-        const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-        const int oy = by * HT_R + r, ox = bx * HT_C + c;
-        if (oy < a.H && ox < a.W) {
-            const size_t m = ((size_t)n * a.H + oy) * a.W + ox;
-            float v0 = (s0a + s0b) + b0, v1 = (s1a + s1b) + b1;
-            if (a.apply_act) { v0 = pwc_lrelu(v0, a.slope); v1 = pwc_lrelu(v1, a.slope); }
-            if (a.res) { v0 += a.res[m * a.res_cs]; v1 += a.res[m * a.res_cs + 1]; }
-            a.y[m * a.y_cs] = v0;
-            a.y[m * a.y_cs + 1] = v1;
-        }
-    }
-}
 
 // Flow heads of the dense-connection estimators (modules.py:269-274 with use_dc: Cin = 725 ... 3169 -> 2): the same
 // tile decomposition with a loop over 32-channel chunks.  The generic kernel below reads every input value 9 times
@@ -439,6 +361,73 @@ __global__ __launch_bounds__(256) void conv3x3_cin3_mfma_kernel(const DirectArgs
 }
 
 
+// ---------------------------------------------------------------- 32 -> 2 flow head as a 1x1 GEMM + 9 shifted adds
+// y[p, co] = sum_t sum_ci x[p + t, ci] w[t, ci, co]  =  sum_t Z[p + t][t, co],   Z[q][t, co] = sum_ci x[q, ci] w[t, ci, co]:
+// the inner sums are ONE small GEMM per input pixel (18 = 9 taps x 2 couts outputs, K = 32) on the matrix pipe -- 16 MFMAs
+// per 16 pixels instead of 576 FMAs per pixel and 216 ds_read_b128 per thread in the tiled kernel above -- and the outer
+// sum is 9 ds_read_b64 + 18 adds per output pixel from a Z tile in LDS (8 x 32 outputs need Z on 10 x 34 pixels; out-of-image
+// pixels load as zeros through the buffer range check, so their Z is the zero of the SAME padding).
+//   A (weights): rows m = 2 t + co (18 of 32), lane (m & 15, kq = lane >> 4) holds channels 8 kq + i, i = 0..7, of both M tiles;
+//   B (pixels):  lane (kq, pixel = lane & 15) loads channels 8 kq .. 8 kq + 7 of its pixel (two 16-byte loads).
+constexpr int HM_R = 8, HM_C = 32, HM_PW = HM_C + 2, HM_NP = (HM_R + 2) * HM_PW, HM_NG = (HM_NP + 15) / 16, HM_ZS = 20;
+__global__ __launch_bounds__(256) void conv3x3_head2_mfma_kernel(const DirectArgs a, int tiles_x, int tiles_y, int N) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) float zs[HM_NG * 16 * HM_ZS];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fr = lane & 15, kq = lane >> 4;
+    const int tile = blockIdx.x;
+    const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int y0 = by * HM_R, x0 = bx * HM_C;
+    float wa[2][8];
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = T * 16 + fr;                       // = 2 tap + co
+            wa[T][i] = m < 18 ? a.w[((m >> 1) * 32 + 8 * kq + i) * 2 + (m & 1)] : 0.f;
+        }
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + (size_t)n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
+    for (int g = wave; g < HM_NG; g += 4) {
+        const int j = g * 16 + fr;
+        const int py = j / HM_PW, px = j - py * HM_PW;
+        const int yy = y0 - 1 + py, xx = x0 - 1 + px;
+        const bool ok = j < HM_NP && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        const int vo = ok ? ((yy * a.W + xx) * a.x_cs + 8 * kq) * 4 : (int)C3M_OOB;
+        const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, vo, 0, 0));
+        const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, vo, 16, 0));
+        f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = z0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xv = i < 4 ? lo[i & 3] : hi[i & 3];
+            z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0][i], xv, z0, 0, 0, 0);
+            z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][i], xv, z1, 0, 0, 0);
+        }
+        // D: rows 4 kq + r of the M tile, column = pixel fr
+        *reinterpret_cast<f32x4*>(zs + j * HM_ZS + 4 * kq) = z0;
+        if (kq == 0) *reinterpret_cast<f32x2*>(zs + j * HM_ZS + 16) = f32x2{z1[0], z1[1]};
+    }
+    __syncthreads();
+    const int r = t >> 5, c = t & 31;
+    f32x2 acc = {a.bias[0], a.bias[1]};
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx)
+            acc += *reinterpret_cast<const f32x2*>(zs + ((r + ty) * HM_PW + c + tx) * HM_ZS + (ty * 3 + tx) * 2);
+    const int oy = y0 + r, ox = x0 + c;
+    if (oy < a.H && ox < a.W) {
+        const size_t m = ((size_t)n * a.H + oy) * a.W + ox;
+        float v0 = acc[0], v1 = acc[1];
+        if (a.apply_act) { v0 = pwc_lrelu(v0, a.slope); v1 = pwc_lrelu(v1, a.slope); }
+        if (a.res) { v0 += a.res[m * a.res_cs]; v1 += a.res[m * a.res_cs + 1]; }
+        a.y[m * a.y_cs] = v0;
+        a.y[m * a.y_cs + 1] = v1;
+    }
+}
+
+
 extern "C" int pwc_conv3x3_direct_f32(const float* x, int x_cs, const float* w_hwio, const float* bias,
                                       float* y, int y_cs, const float* residual, int res_cs, int N, int H,
                                       int W, int Cin, int Cout, int stride, int dilation, int apply_act,
@@ -479,12 +468,12 @@ extern "C" int pwc_conv3x3_direct_f32(const float* x, int x_cs, const float* w_h
                            (size_t)27 * Cout * sizeof(float), s, a);
         return pwc_launch_status();
     }
-    if (Cout == 2 && Cin == 32 && vec4 && stride == 1 && dilation == 1 && (long)H * W >= 16384) {
-        const int tiles_x = (W + HT_C - 1) / HT_C, tiles_y = (H + HT_R - 1) / HT_R;
+    if (Cout == 2 && Cin == 32 && vec4 && stride == 1 && dilation == 1 && (long)H * W >= 4096 &&
+        (long)H * W * x_cs * 4 < (long)C3M_OOB) {
+        const int tiles_x = (W + HM_C - 1) / HM_C, tiles_y = (H + HM_R - 1) / HM_R;
         const long nblk = (long)N * tiles_x * tiles_y;
         if (nblk < (1L << 31)) {
-            const long grid = nblk < 768 ? nblk : 768;       // 3 workgroups per CU (LDS), each walks its tiles
-            hipLaunchKernelGGL(conv3x3_head2_tile_kernel, dim3((unsigned)grid), dim3(256), 0, s, a, tiles_x, tiles_y, (int)nblk);
+            hipLaunchKernelGGL(conv3x3_head2_mfma_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a, tiles_x, tiles_y, N);
             return pwc_launch_status();
         }
     }

@@ -429,9 +429,11 @@ def test_conv_direct_residual_flow_head(pa):
 
 
 @pytest.mark.parametrize("N,H,W,res", [(1, 128, 128, True), (2, 131, 150, False), (1, 112, 256, True), (8, 112, 256, True),
-                                       (1, 8, 2050, False)])
-def test_conv_flow_head_tiled_kernel(pa, N, H, W, res):
-    """32 -> 2 heads on maps of >= 16384 pixels take the LDS-tiled kernel (8 x 32-pixel tiles, ragged edges here)."""
+                                       (1, 8, 2050, False), (2, 64, 64, True), (1, 65, 67, False), (3, 56, 128, True)])
+def test_conv_flow_head_gemm_kernel(pa, N, H, W, res):
+    """32 -> 2 heads on maps of >= 4096 pixels take conv3x3_head2_mfma_kernel (a 1x1 GEMM to 9 x 2 partial outputs per input
+    pixel on the matrix pipe + 9 shifted adds from LDS): 8 x 32-pixel tiles, ragged edges, one-tile maps; (8, 112, 256) is
+    the bench's level-4 head at full size."""
     x = rnd((N, H, W, 32), 117)
     k = rnd((3, 3, 32, 2), 118) * 0.05
     b = rnd((2,), 119) * 0.1
