@@ -55,10 +55,25 @@ __device__ __forceinline__ float pwc_mul_rounded(float a, float b) {
 // `s_waitcnt vmcnt(n)` is silently serialised (found in round 3 in the ISA of conv3x3_wino_kernel: all three barriers
 // of a stage were preceded by vmcnt(0)).  A wave must have waited for its OWN pieces of a region (s_waitcnt vmcnt)
 // before this barrier publishes the region to the other waves.
+// (Second finding, late in round 3: a workgroup-scope fence on the "local" address space is lowered to vmcnt(0) too -- the
+// backend counts buffer_load ... lds as LDS writes -- so this barrier drains the LDS-DMA pipeline just the same and the
+// counted waits in front of it only matter for what they guarantee, not for overlap.  PWC_FENCE_BARRIER=0 spells the barrier
+// out instead (`s_waitcnt lgkmcnt(0); s_barrier` with a "memory" clobber): the counted waits then really leave fetches in
+// flight across barriers -- checked in the ISA, results identical on every harness shape -- and the fetch/LDS skeleton of the
+// F(4x4) kernel drops from 154 to 134 us, but the complete kernels do not move (F(4x4) 252 against 247 us, F(2x2) 296
+// against 290 us): fetch time adds to MFMA time on gfx950 whether or not it is in flight early.  The fence
+// form stays the default.)
+#ifndef PWC_FENCE_BARRIER
+#define PWC_FENCE_BARRIER 1
+#endif
 __device__ __forceinline__ void pwc_lds_barrier() {
+#if PWC_FENCE_BARRIER
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 __device__ __forceinline__ float pwc_lrelu(float v, float slope) {
