@@ -98,7 +98,6 @@ __global__ __launch_bounds__(WB_T, 2) void conv3x3_wino4b_kernel(const Wino4bArg
     const int ah = qb >> 1, bh = qb & 1;
     const int fr = lane & 15, fq = lane >> 4;
     const int trl = fr >> 3, tc = fr & 7;           // tile (2g + trl, tc)
-    const bool hi32 = lane >= 32;
     float m1s;
     asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(m1s));   // -1.0f the optimiser cannot see through (see conv3x3_wino.hip)
     const f32x4 M1 = {m1s, m1s, m1s, m1s};
@@ -137,10 +136,10 @@ __global__ __launch_bounds__(WB_T, 2) void conv3x3_wino4b_kernel(const Wino4bArg
         const bool ok = py < WB_PH && px < WB_PW && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
         p_voff[i] = ok ? (unsigned)(((yy * a.W + xx) * a.x_cs + ch * 4) * 4) : WB_OOB;
     }
-    auto issue_patch = [&](int c16) {
+    auto issue_patch = [&](int c16, int i0, int i1) {      // pieces i0 .. i1-1 of this wave's WB_PPW
 #pragma unroll
         for (int i = 0; i < WB_PPW; ++i)
-            if (!(ABL & 1))
+            if (i >= i0 && i < i1 && !(ABL & 1))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     xrsrc, (lptr_t)(sm + (wave + WB_NW * i < WB_NBP - 1 ? wave + WB_NW * i : WB_NBP - 1) * 1024), 16,
                     (int)p_voff[i], c16 * 64, 0, 0);
@@ -150,7 +149,7 @@ __global__ __launch_bounds__(WB_T, 2) void conv3x3_wino4b_kernel(const Wino4bArg
     const unsigned u_lane = (unsigned)lane * 16u;
     const unsigned u_lane4 = wave < 4 ? u_lane : WB_OOB;            // piece wave + 32 exists for waves 0..3 only
     const int u_cb = cb * WB_U_BYTES;
-    auto issue_u = [&](int c16, int part) {
+    auto issue_u = [&](int c16, int part, int j0, int j1) {   // pieces j0 .. j1-1 of this wave's WB_UPW
         const int sbase = c16 * a.ncb * WB_U_BYTES + u_cb;
 #pragma unroll
         for (int j = 0; j < WB_UPW; ++j) {
@@ -158,159 +157,240 @@ __global__ __launch_bounds__(WB_T, 2) void conv3x3_wino4b_kernel(const Wino4bArg
             const int run = i >= 18 ? 1 : 0;
             const int rel = (18 * run + 6 * part) * WB_UX + (i - 18 * run) * 1024;
             const bool real = j < WB_UPW - 1 || wave < 4;
-            if (!(ABL & 2))
+            if (j >= j0 && j < j1 && !(ABL & 2))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lptr_t)(sm + (real ? WB_PATCH_BYTES + rel : WB_DUMMY)), 16,
                                                          (int)(j < WB_UPW - 1 ? u_lane : u_lane4), sbase + rel, 0, 0);
         }
     };
 #define WB_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
 #define WB_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // ABL & 128 (harness only): s_memtime stamps of wave-lane 0 at the four points of every phase top, kept in the 9 KB of LDS
+    // above the stage buffers and dumped by workgroup 0 (a.y is not written in this mode)
+    int stamp_n = 0;
+    auto stamp = [&]() {
+        if (ABL & 128) {
+            const unsigned long long tm = __builtin_readcyclecounter();
+            if (lane == 0 && stamp_n < 144) *reinterpret_cast<unsigned long long*>(sm + WB_LDS + (wave * 144 + stamp_n) * 8) = tm;
+            ++stamp_n;
+        }
+    };
 
     // ---- this lane's patch reads (conv3x3_wino4.hip): record (4 trow + i) * 36 + (j & 3) * 9 + (j >> 2) + tc, chunk
     // fq ^ pswz(py); pswz flips between window rows i < 4 and i >= 4: two per-lane bases, everything else an immediate
     const int trow = 2 * g + trl;
     const float* pb_lo = smem + ((4 * trow) * WB_PS + tc) * 16 + ((fq ^ wb_pswz(4 * trow)) << 2);
     const float* pb_hi = smem + ((4 * trow) * WB_PS + tc) * 16 + ((fq ^ wb_pswz(4 * trow + 4)) << 2);
-    // ... and its weight fragments: row (cout) fr of a 16-cout tile, 96 bytes per row:
-    // [uh set 0 | uh set 1 | um set 0 | um set 1 | ul set 0 | ul set 1], set f = channels {4f..4f+3, 4f+8..4f+11}
-    const char* const ub = sm + WB_PATCH_BYTES + (18 * ah + 3 * bh) * WB_UX + fr * 96 + (fq & 1) * 16;
-    const int u3 = fq < 2 ? 64 : 0;                 // MFMA 3: A = [ul | uh]
+    // ... and its weight fragments: per position 3072 bytes = [cout tile 2][k-slot 4][cout 16] x (uh 4 | um 4 channels) bf16, then
+    // [k-slot 4][cout 16] x (ul of tile 0 | ul of tile 1): three conflict-free ds_read_b128 of 1 KB per position
+    const char* const ub = sm + WB_PATCH_BYTES + (18 * ah + 3 * bh) * WB_UX + fq * 256 + fr * 16;
 
     f32x4 acc[9][2];
-    auto stage = [&](auto first, int c16) {
-        constexpr bool FIRST = decltype(first)::value;
-        const bool has_next = c16 + 1 < nc16;
-        // in flight here (oldest first): patch(c), weight parts 0 and 1 of c
-        WB_WAIT_VM(2 * WB_UPW);                      // patch(c) landed
-        WB_BAR();                                    // ... for every wave; part 2 of c-1 fully read
-        issue_u(c16, 2);
-
-        // ---- row pass of the input transform: this wave's rows a = 3ah .. 3ah+2 of  B^T d, all six columns
-        f32x4 V[3][6];
+    f32x4 V[3][6];
+#define WB_SCHED() __builtin_amdgcn_sched_barrier(0)
+    // ---- row pass of the input transform, one column j of the window: this wave's rows a = 3ah .. 3ah+2 of  B^T d.
+    // The six pixels of a column are READ one column ahead of their use (a wave has one partner on its SIMD: a read that is
+    // waited for at once costs its whole latency).
+    auto loadcol = [&](int j, f32x4 (&dd)[6]) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            f32x4 dd[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-                dd[i] = *reinterpret_cast<const f32x4*>((i < 4 ? pb_lo : pb_hi) + (i * WB_PS + (j & 3) * 9 + (j >> 2)) * 16);
-            if (ABL & 64) {
-                V[0][j] = dd[0] + dd[3]; V[1][j] = dd[1] + dd[4]; V[2][j] = dd[2] + dd[5];
-            } else if (ah == 0) {
-                V[0][j] = WBFMA(dd[0], 4.f, WBFMA(dd[2], -5.f, dd[4]));
-                const f32x4 s = dd[1] + dd[2], tt = dd[3] + dd[4], u = WBSUB(dd[1], dd[2]), v = WBSUB(dd[4], dd[3]);
-                V[1][j] = WBFMA(s, -4.f, tt);
-                V[2][j] = WBFMA(u, 4.f, v);
-            } else {
-                const f32x4 p = WBSUB(dd[4], dd[2]), q = WBSUB(dd[3], dd[1]);
-                V[0][j] = WBFMA(q, 2.f, p);
-                V[1][j] = WBFMA(q, -2.f, p);
-                V[2][j] = WBFMA(dd[1], 4.f, WBFMA(dd[3], -5.f, dd[5]));
-            }
+        for (int i = 0; i < 6; ++i)
+            dd[i] = *reinterpret_cast<const f32x4*>((i < 4 ? pb_lo : pb_hi) + (i * WB_PS + (j & 3) * 9 + (j >> 2)) * 16);
+    };
+    auto rowcol = [&](auto ahc, int j, const f32x4 (&dd)[6]) {     // ahc: the wave's row half as a compile-time constant (one basic block)
+        constexpr int AH = decltype(ahc)::value;
+        if (ABL & 64) {
+            V[0][j] = dd[0] + dd[3]; V[1][j] = dd[1] + dd[4]; V[2][j] = dd[2] + dd[5];
+        } else if (AH == 0) {
+            V[0][j] = WBFMA(dd[0], 4.f, WBFMA(dd[2], -5.f, dd[4]));
+            const f32x4 s = dd[1] + dd[2], tt = dd[3] + dd[4], u = WBSUB(dd[1], dd[2]), v = WBSUB(dd[4], dd[3]);
+            V[1][j] = WBFMA(s, -4.f, tt);
+            V[2][j] = WBFMA(u, 4.f, v);
+        } else {
+            const f32x4 p = WBSUB(dd[4], dd[2]), q = WBSUB(dd[3], dd[1]);
+            V[0][j] = WBFMA(q, 2.f, p);
+            V[1][j] = WBFMA(q, -2.f, p);
+            V[2][j] = WBFMA(dd[1], 4.f, WBFMA(dd[3], -5.f, dd[5]));
         }
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) asm("" : "+v"(V[r][j]));      // keep the packed ops (see conv3x3_wino.hip)
-
-        // ---- part P: column pass of row P (columns b = 3bh .. 3bh+2), split, lane exchange, 3 positions x 2 cout
-        // tiles x 3 MFMAs
-        auto part = [&](auto pc) {
-            constexpr int P = decltype(pc)::value;
-            f32x4 o[3];
-            {
-                const f32x4 e0 = V[P][0], e1 = V[P][1], e2 = V[P][2], e3 = V[P][3], e4 = V[P][4], e5 = V[P][5];
-                if (ABL & 64) {
-                    o[0] = e0 + e3; o[1] = e1 + e4; o[2] = e2 + e5;
-                } else if (bh == 0) {
-                    const f32x4 s = e1 + e2, tt = e3 + e4, u = WBSUB(e1, e2), v = WBSUB(e4, e3);
-                    o[0] = WBFMA(e0, 4.f, WBFMA(e2, -5.f, e4));
-                    o[1] = WBFMA(s, -4.f, tt);
-                    o[2] = WBFMA(u, 4.f, v);
-                } else {
-                    const f32x4 p = WBSUB(e4, e2), q = WBSUB(e3, e1);
-                    o[0] = WBFMA(q, 2.f, p);
-                    o[1] = WBFMA(q, -2.f, p);
-                    o[2] = WBFMA(e1, 4.f, WBFMA(e3, -5.f, e5));
-                }
-            }
-#pragma unroll
-            for (int bi = 0; bi < 3; ++bi) {
-                asm("" : "+v"(o[bi]));
-                // ---- exact split  v = h + m + l  (round-to-nearest bf16 terms; the residuals are exact in fp32)
-                const f32x4 v = o[bi];
-                unsigned H0, H1, M0, M1b, L0, L1;
-                {
-                    H0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, pwc_bf16x2));
-                    H1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, pwc_bf16x2));
-                    if (ABL & 32) {
-                        M0 = H0; M1b = H1; L0 = H0; L1 = H1;
-                    } else {
-                        const f32x4 hf = {__builtin_bit_cast(float, H0 << 16), __builtin_bit_cast(float, H0 & 0xffff0000u),
-                                          __builtin_bit_cast(float, H1 << 16), __builtin_bit_cast(float, H1 & 0xffff0000u)};
-                        const f32x4 r1 = v - hf;
-                        M0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r1[0], r1[1]}, pwc_bf16x2));
-                        M1b = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r1[2], r1[3]}, pwc_bf16x2));
-                        const f32x4 mf = {__builtin_bit_cast(float, M0 << 16), __builtin_bit_cast(float, M0 & 0xffff0000u),
-                                          __builtin_bit_cast(float, M1b << 16), __builtin_bit_cast(float, M1b & 0xffff0000u)};
-                        const f32x4 r2 = r1 - mf;
-                        L0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r2[0], r2[1]}, pwc_bf16x2));
-                        L1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r2[2], r2[3]}, pwc_bf16x2));
-                    }
-                }
-                // ---- trade halves with lane ^ 32: B1 = [vh | vm], B3 = [vh | vl] along k (8 channels per lane)
-                pwc_u32x4 b1, b3;
-                if (ABL & 32) {
-                    b1 = pwc_u32x4{H0, H1, M0, M1b};
-                    b3 = pwc_u32x4{H0, H1, L0, L1};
-                } else {
-                    const pwc_u32x2 s0 = __builtin_amdgcn_permlane32_swap(H0, M0, false, false);
-                    const pwc_u32x2 s1 = __builtin_amdgcn_permlane32_swap(H1, M1b, false, false);
-                    // s[0]: lanes < 32 own h, lanes >= 32 m of lane - 32;  s[1]: lanes < 32 h of lane + 32, lanes >= 32 own m
-                    b1 = pwc_u32x4{s0[0], s1[0], s0[1], s1[1]};
-                    const pwc_u32x2 t0 = __builtin_amdgcn_permlane32_swap(s0[0], L0, false, false);
-                    const pwc_u32x2 t1 = __builtin_amdgcn_permlane32_swap(s1[0], L1, false, false);
-                    // t[0]: lanes < 32 own h, lanes >= 32 l of lane - 32;  t[1] lanes >= 32: own l
-                    b3 = pwc_u32x4{t0[0], t1[0], hi32 ? t0[1] : s0[1], hi32 ? t1[1] : s1[1]};
-                }
-                const pwc_bf16x8 B1 = __builtin_bit_cast(pwc_bf16x8, b1), B3 = __builtin_bit_cast(pwc_bf16x8, b3);
-                const int XL = P * 3 + bi;
-                const char* const up = ub + (6 * P + bi) * WB_UX;
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    const pwc_bf16x8 A1 = *reinterpret_cast<const pwc_bf16x8*>(up + ct * 1536);
-                    const pwc_bf16x8 A2 = *reinterpret_cast<const pwc_bf16x8*>(up + ct * 1536 + 32);
-                    const pwc_bf16x8 A3 = *reinterpret_cast<const pwc_bf16x8*>(up + ct * 1536 + u3);
-                    if (ABL & 4) {
-                        if (FIRST) acc[XL][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        asm volatile("" ::"v"(A1), "v"(A2), "v"(A3), "v"(B1), "v"(B3));
-                        continue;
-                    }
-                    f32x4 c = FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[XL][ct];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A3, B3, c, 0, 0, 0);     // ul vh + uh vl
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, B1, c, 0, 0, 0);     // um vh + um vm
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B1, c, 0, 0, 0);     // uh vh + uh vm
-                    acc[XL][ct] = c;
-                }
-            }
-        };
-        WB_WAIT_VM(2 * WB_UPW);                      // weight part 0 of c landed (parts 1, 2 may be in flight)
-        WB_BAR();                                    // ... for every wave; patch(c) fully read
-        if (has_next) issue_patch(c16 + 1);
-        part(std::integral_constant<int, 0>{});
-        if (has_next) WB_WAIT_VM(WB_UPW + WB_PPW); else WB_WAIT_VM(WB_UPW);   // part 1 landed
-        WB_BAR();                                    // ... for every wave; part 0 fully read
-        if (has_next) issue_u(c16 + 1, 0);
-        part(std::integral_constant<int, 1>{});
-        if (has_next) WB_WAIT_VM(WB_PPW + WB_UPW); else WB_WAIT_VM(0);        // part 2 landed
-        WB_BAR();                                    // ... for every wave; part 1 fully read
-        if (has_next) issue_u(c16 + 1, 1);
-        part(std::integral_constant<int, 2>{});
+        for (int r = 0; r < 3; ++r) asm("" : "+v"(V[r][j]));              // keep the packed ops (see conv3x3_wino.hip)
     };
-    issue_patch(0);
-    issue_u(0, 0);
-    issue_u(0, 1);
+    // ---- one position.  Weights: [cout tile][k-slot][cout] x (uh 4 | um 4), then [k-slot][cout] x (ul tile 0 | ul tile 1):
+    // three ds_read_b128, issued one position ahead.  Split: v = h + m + l exactly (round-to-nearest bf16 terms; the residuals
+    // are exact in fp32).  k-slot layout of a lane (tile n, q): [term X of channels 4q..4q+3 | term Y of the same]:
+    //   MFMA 3: A = [ul | uh]  B = [vh | vl]     MFMA 2: A = [uh | um]  B = [vm | vm]     MFMA 1: A = [uh | um]  B = [vh | vh]
+    auto loadA = [&](const char* up, pwc_u32x4 (&A)[3]) {
+        A[0] = *reinterpret_cast<const pwc_u32x4*>(up);
+        A[1] = *reinterpret_cast<const pwc_u32x4*>(up + 1024);
+        A[2] = *reinterpret_cast<const pwc_u32x4*>(up + 2048);
+    };
+    auto split = [&](const f32x4 v, unsigned (&S)[6]) {
+        S[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, pwc_bf16x2));
+        S[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, pwc_bf16x2));
+        if (ABL & 32) {
+            S[2] = S[0]; S[3] = S[1]; S[4] = S[0]; S[5] = S[1];
+        } else {
+            f32x4 hf = {__builtin_bit_cast(float, S[0] << 16), __builtin_bit_cast(float, S[0] & 0xffff0000u),
+                        __builtin_bit_cast(float, S[1] << 16), __builtin_bit_cast(float, S[1] & 0xffff0000u)};
+            asm("" : "+v"(hf));                      // (a vector the optimiser cannot take apart: v_pk_add_f32)
+            const f32x4 r1 = v - hf;
+            S[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r1[0], r1[1]}, pwc_bf16x2));
+            S[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r1[2], r1[3]}, pwc_bf16x2));
+            f32x4 mf = {__builtin_bit_cast(float, S[2] << 16), __builtin_bit_cast(float, S[2] & 0xffff0000u),
+                        __builtin_bit_cast(float, S[3] << 16), __builtin_bit_cast(float, S[3] & 0xffff0000u)};
+            asm("" : "+v"(mf));
+            const f32x4 r2 = r1 - mf;
+            S[4] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r2[0], r2[1]}, pwc_bf16x2));
+            S[5] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r2[2], r2[3]}, pwc_bf16x2));
+        }
+    };
+    auto mfmas = [&](auto first, int XL, const pwc_u32x4 (&A)[3], const unsigned (&S)[6]) {
+        constexpr bool FIRST = decltype(first)::value;
+        typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+        const u32x6 W = {S[0], S[1], S[0], S[1], S[4], S[5]};       // (h, h) and (h, l) are overlapping register windows of it
+        const pwc_bf16x8 Bhh = __builtin_bit_cast(pwc_bf16x8, __builtin_shufflevector(W, W, 0, 1, 2, 3));
+        const pwc_bf16x8 Bhl = __builtin_bit_cast(pwc_bf16x8, __builtin_shufflevector(W, W, 2, 3, 4, 5));
+        const pwc_bf16x8 Bmm = __builtin_bit_cast(pwc_bf16x8, pwc_u32x4{S[2], S[3], S[2], S[3]});
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const pwc_bf16x8 Ahm = __builtin_bit_cast(pwc_bf16x8, A[ct]);
+            const pwc_bf16x8 Alh = __builtin_bit_cast(pwc_bf16x8, pwc_u32x4{A[2][2 * ct], A[2][2 * ct + 1], A[ct][0], A[ct][1]});
+            if (ABL & 4) {
+                if (FIRST) acc[XL][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                asm volatile("" ::"v"(Ahm), "v"(Alh), "v"(Bhh), "v"(Bmm), "v"(Bhl));
+                continue;
+            }
+            f32x4 c = FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[XL][ct];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Alh, Bhl, c, 0, 0, 0);      // ul vh + uh vl
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahm, Bmm, c, 0, 0, 0);      // uh vm + um vm
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahm, Bhh, c, 0, 0, 0);      // uh vh + um vh
+            acc[XL][ct] = c;
+        }
+    };
+    // ---- part P of a stage: column pass of row P (columns b = 3bh .. 3bh+2), then its three positions; in part 2 the
+    // row pass of the NEXT stage (its patch is resident since two phases) is spread between the positions.  Order within
+    // the part, fixed by scheduling barriers: the LDS reads of step k+1 are issued before the arithmetic of step k.
+    // ---- part P of a stage: column pass of row P (columns b = 3bh .. 3bh+2), then its three positions; in part 2 (NR) the
+    // row pass of the NEXT stage (its patch is resident since two phases) is spread between the positions.  Software pipeline
+    // inside the part: the LDS reads of step k+1 are issued first, then one scheduling region holds the split of position
+    // k+1, the row pass of two columns and the six MFMAs of position k -- independent work the scheduler interleaves (two
+    // waves of a SIMD that run the same code arrive at their MFMAs together: VALU and matrix work have to alternate INSIDE a
+    // wave; measured scripts/exp_pos.hip: 515 -> 430 cycles per position and wave pair).
+    auto part = [&](auto first, auto pc, auto nr, auto ahc, auto&& dma) {
+        constexpr int P = decltype(pc)::value;
+        constexpr bool NR = decltype(nr)::value;
+        const char* const up = ub + (6 * P) * WB_UX;
+        pwc_u32x4 A[3];
+        f32x4 d0[6], d1[6];
+        loadA(up, A);
+        if (NR) { loadcol(0, d0); loadcol(1, d1); }
+        f32x4 o[3];
+        {
+            const f32x4 e0 = V[P][0], e1 = V[P][1], e2 = V[P][2], e3 = V[P][3], e4 = V[P][4], e5 = V[P][5];
+            if (ABL & 64) {
+                o[0] = e0 + e3; o[1] = e1 + e4; o[2] = e2 + e5;
+            } else if (bh == 0) {
+                const f32x4 s = e1 + e2, tt = e3 + e4, u = WBSUB(e1, e2), v = WBSUB(e4, e3);
+                o[0] = WBFMA(e0, 4.f, WBFMA(e2, -5.f, e4));
+                o[1] = WBFMA(s, -4.f, tt);
+                o[2] = WBFMA(u, 4.f, v);
+            } else {
+                const f32x4 p = WBSUB(e4, e2), q = WBSUB(e3, e1);
+                o[0] = WBFMA(q, 2.f, p);
+                o[1] = WBFMA(q, -2.f, p);
+                o[2] = WBFMA(e1, 4.f, WBFMA(e3, -5.f, e5));
+            }
+#pragma unroll
+            for (int bi = 0; bi < 3; ++bi) asm("" : "+v"(o[bi]));
+        }
+        unsigned S0[6], S1[6];
+        split(o[0], S0);
+        WB_SCHED();
+        // step 0: one region = split of position 1, two columns of the next stage's row pass, the MFMAs of position 0; then the
+        // LDS reads of step 1 (their latency is covered by the split and the row pass that open the next region)
+        dma(0);
+        split(o[1], S1);
+        if (NR) { rowcol(ahc, 0, d0); rowcol(ahc, 1, d1); }
+        mfmas(first, P * 3 + 0, A, S0);
+        WB_SCHED();
+        loadA(up + WB_UX, A);
+        if (NR) { loadcol(2, d0); loadcol(3, d1); }
+        WB_SCHED();
+        // step 1
+        dma(1);
+        split(o[2], S0);
+        if (NR) { rowcol(ahc, 2, d0); rowcol(ahc, 3, d1); }
+        mfmas(first, P * 3 + 1, A, S1);
+        WB_SCHED();
+        loadA(up + 2 * WB_UX, A);
+        if (NR) { loadcol(4, d0); loadcol(5, d1); }
+        WB_SCHED();
+        // step 2
+        dma(2);
+        if (NR) { rowcol(ahc, 4, d0); rowcol(ahc, 5, d1); }
+        mfmas(first, P * 3 + 2, A, S0);
+    };
+    // ---- pipeline.  LDS: one patch buffer, the weights of a stage in three parts (fixed regions).  A phase = one part.
+    // At the top of a phase (after its barrier) the region read in the PREVIOUS phase is re-fetched for its next use,
+    // two phases ahead: top of part 0: weights part 2 of this stage + the next stage's patch (the patch is only read in
+    // part 2); top of part 1: part 0 of the next stage; top of part 2: part 1 of the next stage.
+    auto stage = [&](auto first, int c16) {
+        const bool has_next = c16 + 1 < nc16;
+        // in flight here (oldest first): weight parts 0 and 1 of c
+        stamp();
+        WB_WAIT_VM(WB_UPW);                          // part 0 landed
+        stamp();
+        WB_BAR();                                    // ... for every wave; part 2 of c-1 and patch(c) fully read
+        stamp();
+        stamp();
+        // the 5 (+ 6) fetches of a phase are issued in three slots between its positions: a burst of all waves at the top
+        // of the phase keeps every wave in the issue queue of the 64 B/clk fetch path (measured: 600 - 1400 cycles per phase)
+        part(first, std::integral_constant<int, 0>{}, std::false_type{}, std::integral_constant<int, 0>{}, [&](int slot) {
+            issue_u(c16, 2, slot == 0 ? 0 : slot == 1 ? 2 : 4, slot == 0 ? 2 : slot == 1 ? 4 : 5);
+            if (has_next) issue_patch(c16 + 1, 2 * slot, 2 * slot + 2);
+        });
+        stamp();
+        if (has_next) WB_WAIT_VM(WB_UPW + WB_PPW); else WB_WAIT_VM(WB_UPW);   // part 1 landed
+        stamp();
+        WB_BAR();                                    // ... for every wave; part 0 fully read
+        stamp();
+        stamp();
+        part(first, std::integral_constant<int, 1>{}, std::false_type{}, std::integral_constant<int, 0>{}, [&](int slot) {
+            if (has_next) issue_u(c16 + 1, 0, slot == 0 ? 0 : slot == 1 ? 2 : 4, slot == 0 ? 2 : slot == 1 ? 4 : 5);
+        });
+        stamp();
+        if (has_next) WB_WAIT_VM(WB_UPW); else WB_WAIT_VM(0);                 // part 2 and patch(c+1) landed
+        stamp();
+        WB_BAR();                                    // ... for every wave; part 1 fully read
+        stamp();
+        stamp();
+        auto dma2 = [&](int slot) {
+            if (has_next) issue_u(c16 + 1, 1, slot == 0 ? 0 : slot == 1 ? 2 : 4, slot == 0 ? 2 : slot == 1 ? 4 : 5);
+        };
+        if (!has_next) part(first, std::integral_constant<int, 2>{}, std::false_type{}, std::integral_constant<int, 0>{}, dma2);
+        else if (ah == 0) part(first, std::integral_constant<int, 2>{}, std::true_type{}, std::integral_constant<int, 0>{}, dma2);
+        else part(first, std::integral_constant<int, 2>{}, std::true_type{}, std::integral_constant<int, 1>{}, dma2);
+    };
+    issue_patch(0, 0, WB_PPW);
+    issue_u(0, 0, 0, WB_UPW);
+    issue_u(0, 1, 0, WB_UPW);
+    WB_WAIT_VM(2 * WB_UPW);                          // patch(0) landed
+    WB_BAR();
+    {
+        f32x4 d0[6], d1[6];
+        loadcol(0, d0);
+#pragma unroll
+        for (int j = 0; j < 6; j += 2) {
+            loadcol(j + 1, d1);
+            WB_SCHED();
+            if (ah == 0) rowcol(std::integral_constant<int, 0>{}, j, d0); else rowcol(std::integral_constant<int, 1>{}, j, d0);
+            if (j + 2 < 6) loadcol(j + 2, d0);
+            WB_SCHED();
+            if (ah == 0) rowcol(std::integral_constant<int, 0>{}, j + 1, d1); else rowcol(std::integral_constant<int, 1>{}, j + 1, d1);
+        }
+    }
     stage(std::true_type{}, 0);
     for (int c16 = 1; c16 < nc16; ++c16) stage(std::false_type{}, c16);
+    stamp();
+#undef WB_SCHED
 
     // ---- output transform  Y = A^T M A,  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]: this wave holds the
     // 3 x 3 block (ah, bh) of M and forms its 4 x 4 partial sums; wave qb finishes output row qb of the tile and gets
@@ -377,9 +457,15 @@ __global__ __launch_bounds__(WB_T, 2) void conv3x3_wino4b_kernel(const Wino4bArg
                 }
                 const int px = px0 + j * d;
                 const unsigned vo = (py < a.H && px < a.W) ? (unsigned)(((py * a.W + px) * a.y_cs + co) * 4) : WB_OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pwc_u32x4, yv), yrsrc, (int)vo, 0, 0);
+                if (!(ABL & 128)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pwc_u32x4, yv), yrsrc, (int)vo, 0, 0);
             }
         }
+    }
+    if (ABL & 128) {
+        stamp();
+        WB_BAR();
+        if (blockIdx.x == 0)
+            for (int i = t; i < WB_NW * 144 * 2; i += WB_T) reinterpret_cast<unsigned*>(a.y)[i] = reinterpret_cast<unsigned*>(sm + WB_LDS)[i];
     }
 #undef WB_WAIT_VM
 #undef WB_BAR
@@ -389,8 +475,9 @@ __global__ __launch_bounds__(WB_T, 2) void conv3x3_wino4b_kernel(const Wino4bArg
 
 // ---------------------------------------------------------------- weight transform, split and packing
 // U_xi = (G g G^T)[a][b], xi = 6a + b, in double (G as conv3x3_wino4.hip); u = h + m + l with round-to-nearest bf16
-// terms (|u - h - m - l| <= 2^-27 |u|); image [c16][cout group][xi][cout 32][term 3][set 2][8]: set f holds the channels
-// {4f..4f+3, 4f+8..4f+11} of the 16-channel stage in that order (the k order the lane exchange of the kernel produces).
+// terms (|u - h - m - l| <= 2^-27 |u|); image [c16][cout group][xi] x 3072 bytes: [cout tile 2][k-slot 4][cout 16][uh 4 | um 4],
+// then [k-slot 4][cout 16][ul of tile 0: 4 | ul of tile 1: 4]; k-slot q holds channels 4q..4q+3 of the 16-channel stage
+// (what lane (n, q) of the kernel transforms).
 __global__ void conv3x3_wino4b_pack_kernel(const float* __restrict__ w, const int32_t* __restrict__ cin_map, int Cin,
                                            int Cin_phys, int Cout, int ncb, unsigned short* __restrict__ packed) {
     const size_t total = (size_t)(Cin_phys >> 4) * ncb * 36 * 32 * 16;      // one thread per (c16, cg, xi, cout, channel)
@@ -398,7 +485,7 @@ __global__ void conv3x3_wino4b_pack_kernel(const float* __restrict__ w, const in
                             {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
-        const int s16 = (int)(idx & 15);             // slot: set f = s16 >> 3, element e = s16 & 7
+        const int ch = (int)(idx & 15);
         size_t r = idx >> 4;
         const int co32 = (int)(r & 31);
         r >>= 5;
@@ -406,8 +493,6 @@ __global__ void conv3x3_wino4b_pack_kernel(const float* __restrict__ w, const in
         r /= 36;
         const int cg = (int)(r % ncb);
         const int c16 = (int)(r / ncb);
-        const int f = s16 >> 3, e = s16 & 7;
-        const int ch = e < 4 ? 4 * f + e : 8 + 4 * f + (e - 4);
         const int cphys = c16 * 16 + ch;
         const int clog = cin_map ? cin_map[cphys] : (cphys < Cin ? cphys : -1);
         const int co = cg * 32 + co32;
@@ -425,10 +510,11 @@ __global__ void conv3x3_wino4b_pack_kernel(const float* __restrict__ w, const in
         const __bf16 m = (__bf16)(float)r1;
         const double r2 = r1 - (double)(float)m;
         const __bf16 l = (__bf16)(float)r2;
-        unsigned short* row = packed + ((((size_t)c16 * ncb + cg) * 36 + xi) * 32 + co32) * 48;
-        row[s16] = __builtin_bit_cast(unsigned short, h);
-        row[16 + s16] = __builtin_bit_cast(unsigned short, m);
-        row[32 + s16] = __builtin_bit_cast(unsigned short, l);
+        const int ct = co32 >> 4, i = co32 & 15, q = ch >> 2, e = ch & 3;
+        unsigned short* pos = packed + (((size_t)c16 * ncb + cg) * 36 + xi) * (WB_UX / 2);
+        pos[ct * 512 + (q * 16 + i) * 8 + e] = __builtin_bit_cast(unsigned short, h);
+        pos[ct * 512 + (q * 16 + i) * 8 + 4 + e] = __builtin_bit_cast(unsigned short, m);
+        pos[1024 + (q * 16 + i) * 8 + ct * 4 + e] = __builtin_bit_cast(unsigned short, l);
     }
 }
 
@@ -464,9 +550,9 @@ static int wino4b_launch(const Wino4bArgs& a, hipStream_t stream) {
     static PwcDevOnce attr_once;   // the attribute is per device
     if (pwc_first_on_device(&attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4b_kernel<ABL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, WB_LDS);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, WB_LDS + ((ABL & 128) ? 9216 : 0));
     }
-    hipLaunchKernelGGL((conv3x3_wino4b_kernel<ABL>), dim3((unsigned)a.ntiles), dim3(WB_T), WB_LDS, stream, a);
+    hipLaunchKernelGGL((conv3x3_wino4b_kernel<ABL>), dim3((unsigned)a.ntiles), dim3(WB_T), WB_LDS + ((ABL & 128) ? 9216 : 0), stream, a);
     return pwc_launch_status();
 }
 

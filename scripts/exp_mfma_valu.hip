@@ -19,6 +19,24 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* src, int it
         if (!(MODE & 1)) return;
         f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
         float x = threadIdx.x * 1e-3f, y = 1.0f;
+        if (BF == 2) {
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            bf16x8 xa, xb;
+            for (int e = 0; e < 8; ++e) { xa[e] = (__bf16)(x + e); xb[e] = (__bf16)1.0f; }
+            f32x4 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+            for (int i = 0; i < iters; ++i) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {     // 64 MFMAs of 16 cycles per iteration
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, xb, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, xb, c1, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, xb, c2, 0, 0, 0);
+                    c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, xb, c3, 0, 0, 0);
+                }
+            }
+            c0 += c1 + c2 + c3;
+            if (c0[0] == 12345.f) out[threadIdx.x] = c0[0] + c0[3];
+            return;
+        }
         if (BF) {
             typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
             typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -153,5 +171,17 @@ int main() {
         printf("bf16 32x32x16 MFMA + ds_read_b128: MFMA alone %7.1f us | LDS alone %7.1f | both %7.1f | sum %7.1f\n", m2, v2, b2, m2 + v2);
     }
     kind<11>("lds-dma 1KB", out, src, iters);
+    {   // round 4: the same pairing with v_mfma_f32_16x16x32_bf16 (64 per iteration, 16 cycles each)
+        const float m = run<1, 1, 2>(out, src, iters), v = run<1, 2, 2>(out, src, iters), b = run<1, 3, 2>(out, src, iters);
+        printf("bf16 16x16x32 MFMA + v_fma_f32: MFMA alone %7.1f us (%.1f cyc/MFMA) | VALU alone %7.1f | both %7.1f | sum %7.1f\n", m, m * 2400.f / (iters * 64.f), v, b, m + v);
+        const float m3 = run<4, 1, 2>(out, src, iters), v3 = run<4, 2, 2>(out, src, iters), b3 = run<4, 3, 2>(out, src, iters);
+        printf("bf16 16x16x32 MFMA + v_mov_b32: MFMA alone %7.1f us | VALU alone %7.1f | both %7.1f | sum %7.1f\n", m3, v3, b3, m3 + v3);
+        const float m4 = run<4, 1, 1>(out, src, iters), v4 = run<4, 2, 1>(out, src, iters), b4 = run<4, 3, 1>(out, src, iters);
+        printf("bf16 32x32x16 MFMA + v_mov_b32: MFMA alone %7.1f us | VALU alone %7.1f | both %7.1f | sum %7.1f\n", m4, v4, b4, m4 + v4);
+        const float m5 = run<0, 1, 1>(out, src, iters), v5 = run<0, 2, 1>(out, src, iters), b5 = run<0, 3, 1>(out, src, iters);
+        printf("bf16 32x32x16 MFMA + v_pk_fma_f32: MFMA alone %7.1f us | VALU alone %7.1f | both %7.1f | sum %7.1f\n", m5, v5, b5, m5 + v5);
+        const float m6 = run<0, 1, 2>(out, src, iters), v6 = run<0, 2, 2>(out, src, iters), b6 = run<0, 3, 2>(out, src, iters);
+        printf("bf16 16x16x32 MFMA + v_pk_fma_f32: MFMA alone %7.1f us | VALU alone %7.1f | both %7.1f | sum %7.1f\n", m6, v6, b6, m6 + v6);
+    }
     return 0;
 }

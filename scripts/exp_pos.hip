@@ -1,0 +1,481 @@
+// What does ONE POSITION of conv3x3_wino4b.hip cost?  (split of a transformed f32x4 into h/m/l bf16 pairs + three ds_read_b128
+// of split weights + 2 cout tiles x 3 v_mfma_f32_16x16x32_bf16), in a loop, 512-thread workgroups (two waves per SIMD), one per
+// CU, no barriers, no DMA.  Variants:
+//   0: split, then the six MFMAs (compiler order)          1: the same with sched_group_barrier: 1 MFMA : 7 VALU
+//   2: the l-term products as v_mfma_f32_16x16x16_bf16 (2-register operands: no tuple has to be built from two loads)
+//   3: MFMAs + weight reads only (split hoisted out)       4: split only (+ weight reads)         5: MFMAs only
+//   6: variant 0 with the residuals as packed subtractions (v_pk_add_f32)
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize scripts/exp_pos.hip -o scripts/exp_pos.bin
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+
+__device__ __forceinline__ void split(const f32x4 v, unsigned (&S)[6], bool packed) {
+    S[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+    S[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+    f32x4 hf = {__builtin_bit_cast(float, S[0] << 16), __builtin_bit_cast(float, S[0] & 0xffff0000u),
+                __builtin_bit_cast(float, S[1] << 16), __builtin_bit_cast(float, S[1] & 0xffff0000u)};
+    if (packed) asm("" : "+v"(hf));
+    const f32x4 r1 = v - hf;
+    S[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r1[0], r1[1]}, bf16x2));
+    S[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r1[2], r1[3]}, bf16x2));
+    f32x4 mf = {__builtin_bit_cast(float, S[2] << 16), __builtin_bit_cast(float, S[2] & 0xffff0000u),
+                __builtin_bit_cast(float, S[3] << 16), __builtin_bit_cast(float, S[3] & 0xffff0000u)};
+    if (packed) asm("" : "+v"(mf));
+    const f32x4 r2 = r1 - mf;
+    S[4] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r2[0], r2[1]}, bf16x2));
+    S[5] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r2[2], r2[3]}, bf16x2));
+}
+
+template <int VAR>
+__global__ __launch_bounds__(512, 2) void k(float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < 27 * 1024 / 4; i += 512) reinterpret_cast<unsigned*>(sm)[i] = 0x3f803f80u;
+    __syncthreads();
+    const char* ub = sm + lane * 16;
+    f32x4 acc[9][2];
+    for (int x = 0; x < 9; ++x) acc[x][0] = acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 v = {1.f + t * 1e-3f, 2.f, 3.f + t * 1e-4f, 4.f};
+    unsigned S[6];
+    if (VAR == 3 || VAR == 5) split(v, S, false);
+    u32x4 A5[3] = {u32x4{1, 2, 3, 4}, u32x4{5, 6, 7, 8}, u32x4{9, 10, 11, 12}};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int x = 0; x < 9; ++x) {
+            if (VAR != 3 && VAR != 5) {
+                v = v * 1.0001f;
+                asm("" : "+v"(v));
+                split(v, S, VAR == 6);
+            }
+            const char* up = ub + x * 3072;
+            u32x4 A[3];
+            if (VAR == 5) { A[0] = A5[0]; A[1] = A5[1]; A[2] = A5[2]; }
+            else { A[0] = *reinterpret_cast<const u32x4*>(up); A[1] = *reinterpret_cast<const u32x4*>(up + 1024); A[2] = *reinterpret_cast<const u32x4*>(up + 2048); }
+            if (VAR == 4) {
+                acc[x][0] += __builtin_bit_cast(f32x4, A[0]) + __builtin_bit_cast(f32x4, A[2]);
+                acc[x][1][0] += __builtin_bit_cast(float, S[0] ^ S[2] ^ S[4]) + __builtin_bit_cast(float, S[1] ^ S[3] ^ S[5]);
+                acc[x][1] += __builtin_bit_cast(f32x4, A[1]);
+                continue;
+            }
+            const u32x6 W = {S[0], S[1], S[0], S[1], S[4], S[5]};
+            const bf16x8 Bhh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(W, W, 0, 1, 2, 3));
+            const bf16x8 Bhl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(W, W, 2, 3, 4, 5));
+            const bf16x8 Bmm = __builtin_bit_cast(bf16x8, u32x4{S[2], S[3], S[2], S[3]});
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const bf16x8 Ahm = __builtin_bit_cast(bf16x8, A[ct]);
+                f32x4 c = acc[x][ct];
+                if (VAR == 2) {
+                    const s16x4 ul = __builtin_bit_cast(s16x4, u32x2{A[2][2 * ct], A[2][2 * ct + 1]});
+                    const s16x4 uh = __builtin_bit_cast(s16x4, u32x2{A[ct][0], A[ct][1]});
+                    const s16x4 vh = __builtin_bit_cast(s16x4, u32x2{S[0], S[1]});
+                    const s16x4 vl = __builtin_bit_cast(s16x4, u32x2{S[4], S[5]});
+                    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ul, vh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(uh, vl, c, 0, 0, 0);
+                } else {
+                    const bf16x8 Alh = __builtin_bit_cast(bf16x8, u32x4{A[2][2 * ct], A[2][2 * ct + 1], A[ct][0], A[ct][1]});
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Alh, Bhl, c, 0, 0, 0);
+                }
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahm, Bmm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahm, Bhh, c, 0, 0, 0);
+                acc[x][ct] = c;
+            }
+            if (VAR == 1) {
+#pragma unroll
+                for (int g = 0; g < 6; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);   // 7 VALU
+                }
+            }
+        }
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int x = 0; x < 9; ++x) s += acc[x][0] + acc[x][1];
+    if (s[0] == 12345.f) out[t] = s[0] + s[1] + s[2] + s[3];
+}
+
+
+// explicit software pipeline: the split of position x+1 is written BEFORE the MFMAs of position x (double-buffered split
+// registers); GB = 1: sched_group_barrier 1 MFMA : NV VALU
+template <int GB, int NV>
+__global__ __launch_bounds__(512, 2) void k2(float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < 27 * 1024 / 4; i += 512) reinterpret_cast<unsigned*>(sm)[i] = 0x3f803f80u;
+    __syncthreads();
+    const char* ub = sm + lane * 16;
+    f32x4 acc[9][2];
+    for (int x = 0; x < 9; ++x) acc[x][0] = acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 v = {1.f + t * 1e-3f, 2.f, 3.f + t * 1e-4f, 4.f};
+    unsigned S[2][6];
+    u32x4 A[2][3];
+    split(v, S[0], true);
+    A[0][0] = *reinterpret_cast<const u32x4*>(ub); A[0][1] = *reinterpret_cast<const u32x4*>(ub + 1024); A[0][2] = *reinterpret_cast<const u32x4*>(ub + 2048);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int x = 0; x < 9; ++x) {
+            const int cur = x & 1, nxt = cur ^ 1;
+            const char* up = ub + ((x + 1) % 9) * 3072;
+            A[nxt][0] = *reinterpret_cast<const u32x4*>(up); A[nxt][1] = *reinterpret_cast<const u32x4*>(up + 1024); A[nxt][2] = *reinterpret_cast<const u32x4*>(up + 2048);
+            v = v * 1.0001f;
+            asm("" : "+v"(v));
+            split(v, S[nxt], true);
+            const u32x6 W = {S[cur][0], S[cur][1], S[cur][0], S[cur][1], S[cur][4], S[cur][5]};
+            const bf16x8 Bhh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(W, W, 0, 1, 2, 3));
+            const bf16x8 Bhl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(W, W, 2, 3, 4, 5));
+            const bf16x8 Bmm = __builtin_bit_cast(bf16x8, u32x4{S[cur][2], S[cur][3], S[cur][2], S[cur][3]});
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const bf16x8 Ahm = __builtin_bit_cast(bf16x8, A[cur][ct]);
+                const bf16x8 Alh = __builtin_bit_cast(bf16x8, u32x4{A[cur][2][2 * ct], A[cur][2][2 * ct + 1], A[cur][ct][0], A[cur][ct][1]});
+                f32x4 c = acc[x][ct];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Alh, Bhl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahm, Bmm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahm, Bhh, c, 0, 0, 0);
+                acc[x][ct] = c;
+            }
+            if (GB) {
+#pragma unroll
+                for (int g = 0; g < 6; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);   // NV VALU
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int x = 0; x < 9; ++x) s += acc[x][0] + acc[x][1];
+    if (s[0] == 12345.f) out[t] = s[0] + s[1] + s[2] + s[3] + __builtin_bit_cast(float, S[0][0] ^ S[1][1]);
+}
+template <int GB, int NV> float run2(float* out, int iters) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k2<GB, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
+    hipLaunchKernelGGL((k2<GB, NV>), dim3(256), dim3(512), 28 * 1024, 0, out, iters);
+    (void)hipDeviceSynchronize();
+    float best = 1e9;
+    for (int r = 0; r < 3; ++r) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((k2<GB, NV>), dim3(256), dim3(512), 28 * 1024, 0, out, iters);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
+    }
+    return best * 1e3f;
+}
+
+// ONE wave per SIMD (256 threads, 512 registers): a wave owns 9 positions x 2 tile groups x NCT cout tiles; the weight
+// fragments of a position are read once and serve both tile groups; split of the next (position, tile group) before the
+// MFMAs of the current one.  NPK packed fp32 operations per (position, tile group) stand in for the transform.
+template <int NCT, int NPK, int GB>
+__global__ __launch_bounds__(256, 1) void k3(float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < 60 * 1024 / 4; i += 256) reinterpret_cast<unsigned*>(sm)[i] = 0x3f803f80u;
+    __syncthreads();
+    const char* ub = sm + lane * 16;
+    f32x4 acc[9][2][NCT];
+    for (int x = 0; x < 9; ++x) for (int g = 0; g < 2; ++g) for (int c = 0; c < NCT; ++c) acc[x][g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 v[2] = {{1.f + t * 1e-3f, 2.f, 3.f + t * 1e-4f, 4.f}, {1.5f + t * 1e-3f, 2.5f, 3.5f + t * 1e-4f, 4.5f}};
+    f32x4 w[4] = {{1.f, 2.f, 3.f, 4.f}, {1.5f, 2.5f, 3.5f, 4.5f}, {0.5f, 0.25f, 0.125f, 1.f}, {3.f, 2.f, 1.f, 0.5f}};
+    unsigned S[2][6];
+    u32x4 A[2][NCT + NCT / 2];
+    split(v[0], S[0], true);
+#pragma unroll
+    for (int c = 0; c < NCT + NCT / 2; ++c) A[0][c] = *reinterpret_cast<const u32x4*>(ub + c * 1024);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int x = 0; x < 9; ++x) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int cur = g, nxt = g ^ 1;               // split buffers alternate with the tile group
+                const int ac = x & 1, an = ac ^ 1;
+                if (g == 0) {                                 // next position's weights: NCT + NCT/2 reads of 1 KB
+                    const char* up = ub + ((x + 1) % 9) * (NCT + NCT / 2) * 1024;
+#pragma unroll
+                    for (int c = 0; c < NCT + NCT / 2; ++c) A[an][c] = *reinterpret_cast<const u32x4*>(up + c * 1024);
+                }
+#pragma unroll
+                for (int i = 0; i < NPK; ++i) { w[i & 3] = __builtin_elementwise_fma(w[i & 3], w[(i + 1) & 3], w[(i + 2) & 3]); asm("" : "+v"(w[i & 3])); }
+                v[nxt] = v[nxt] + w[0];
+                asm("" : "+v"(v[nxt]));
+                split(v[nxt], S[nxt], true);
+                const u32x6 W = {S[cur][0], S[cur][1], S[cur][0], S[cur][1], S[cur][4], S[cur][5]};
+                const bf16x8 Bhh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(W, W, 0, 1, 2, 3));
+                const bf16x8 Bhl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(W, W, 2, 3, 4, 5));
+                const bf16x8 Bmm = __builtin_bit_cast(bf16x8, u32x4{S[cur][2], S[cur][3], S[cur][2], S[cur][3]});
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const u32x4 ul2 = A[ac][NCT + (ct >> 1)];
+                    const bf16x8 Ahm = __builtin_bit_cast(bf16x8, A[ac][ct]);
+                    const bf16x8 Alh = __builtin_bit_cast(bf16x8, u32x4{ul2[2 * (ct & 1)], ul2[2 * (ct & 1) + 1], A[ac][ct][0], A[ac][ct][1]});
+                    f32x4 c = acc[x][g][ct];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Alh, Bhl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahm, Bmm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahm, Bhh, c, 0, 0, 0);
+                    acc[x][g][ct] = c;
+                }
+                if (GB) {
+#pragma unroll
+                    for (int gg = 0; gg < 3 * NCT; ++gg) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, GB, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int x = 0; x < 9; ++x) for (int g = 0; g < 2; ++g) for (int c = 0; c < NCT; ++c) s += acc[x][g][c];
+    if (s[0] == 12345.f) out[t] = s[0] + s[1] + s[2] + s[3] + __builtin_bit_cast(float, S[0][0] ^ S[1][1]) + w[0][0] + w[1][1] + w[2][2] + w[3][3];
+}
+template <int NCT, int NPK, int GB> float run3(float* out, int iters) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k3<NCT, NPK, GB>), hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+    hipLaunchKernelGGL((k3<NCT, NPK, GB>), dim3(256), dim3(256), 60 * 1024, 0, out, iters);
+    (void)hipDeviceSynchronize();
+    float best = 1e9;
+    for (int r = 0; r < 3; ++r) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((k3<NCT, NPK, GB>), dim3(256), dim3(256), 60 * 1024, 0, out, iters);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
+    }
+    return best * 1e3f;
+}
+
+// as k2, but the weight fragments of a (position, cout tile) are ONE 24-byte record per lane [ul 4 | uh 4 | um 4] read as a
+// 6-register value: (ul, uh) and (uh, um) are overlapping register windows of it -- no tuple is assembled by v_mov
+template <int GB, int NV>
+__global__ __launch_bounds__(512, 2) void k4(float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < 27 * 1024 / 4; i += 512) reinterpret_cast<unsigned*>(sm)[i] = 0x3f803f80u;
+    __syncthreads();
+    const char* ub = sm + lane * 24;
+    f32x4 acc[9][2];
+    for (int x = 0; x < 9; ++x) acc[x][0] = acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 v = {1.f + t * 1e-3f, 2.f, 3.f + t * 1e-4f, 4.f};
+    unsigned S[2][6];
+    u32x6 A[2][2];
+    split(v, S[0], true);
+    A[0][0] = *reinterpret_cast<const u32x6*>(ub); A[0][1] = *reinterpret_cast<const u32x6*>(ub + 1536);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int x = 0; x < 9; ++x) {
+            const int cur = x & 1, nxt = cur ^ 1;
+            const char* up = ub + ((x + 1) % 9) * 3072;
+            A[nxt][0] = *reinterpret_cast<const u32x6*>(up); A[nxt][1] = *reinterpret_cast<const u32x6*>(up + 1536);
+            v = v * 1.0001f;
+            asm("" : "+v"(v));
+            split(v, S[nxt], true);
+            const u32x6 W = {S[cur][0], S[cur][1], S[cur][0], S[cur][1], S[cur][4], S[cur][5]};
+            const bf16x8 Bhh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(W, W, 0, 1, 2, 3));
+            const bf16x8 Bhl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(W, W, 2, 3, 4, 5));
+            const bf16x8 Bmm = __builtin_bit_cast(bf16x8, u32x4{S[cur][2], S[cur][3], S[cur][2], S[cur][3]});
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const bf16x8 Alh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(A[cur][ct], A[cur][ct], 0, 1, 2, 3));
+                const bf16x8 Ahm = __builtin_bit_cast(bf16x8, __builtin_shufflevector(A[cur][ct], A[cur][ct], 2, 3, 4, 5));
+                f32x4 c = acc[x][ct];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Alh, Bhl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahm, Bmm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahm, Bhh, c, 0, 0, 0);
+                acc[x][ct] = c;
+            }
+            if (GB) {
+#pragma unroll
+                for (int g = 0; g < 6; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);   // NV VALU
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int x = 0; x < 9; ++x) s += acc[x][0] + acc[x][1];
+    if (s[0] == 12345.f) out[t] = s[0] + s[1] + s[2] + s[3] + __builtin_bit_cast(float, S[0][0] ^ S[1][1]);
+}
+template <int GB, int NV> float run4(float* out, int iters) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k4<GB, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
+    hipLaunchKernelGGL((k4<GB, NV>), dim3(256), dim3(512), 28 * 1024, 0, out, iters);
+    (void)hipDeviceSynchronize();
+    float best = 1e9;
+    for (int r = 0; r < 3; ++r) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((k4<GB, NV>), dim3(256), dim3(512), 28 * 1024, 0, out, iters);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
+    }
+    return best * 1e3f;
+}
+
+// as k2 with the operand tuples assembled by v_pk_mov_b32 (one instruction per register PAIR) and, DOT = 1, the residuals
+// by v_dot2_f32_bf16 (x - h without unpacking h:  r = (-1) * h.lo + 0 * h.hi + x)
+__device__ __forceinline__ u32x2 pkmov(u32x2 a) {
+    u32x2 r;
+    asm("v_pk_mov_b32 %0, %1, %1 op_sel:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+template <int DOT>
+__device__ __forceinline__ void split5(const f32x4 v, unsigned (&S)[6]) {
+    S[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+    S[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+    f32x4 r1, r2;
+    if (DOT) {
+        const unsigned KLO = 0x0000bf80u, KHI = 0xbf800000u;     // (-1, 0), (0, -1) as bf16 pairs
+        asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r1[0]) : "v"(S[0]), "s"(KLO), "v"(v[0]));
+        asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r1[1]) : "v"(S[0]), "s"(KHI), "v"(v[1]));
+        asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r1[2]) : "v"(S[1]), "s"(KLO), "v"(v[2]));
+        asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r1[3]) : "v"(S[1]), "s"(KHI), "v"(v[3]));
+    } else {
+        f32x4 hf = {__builtin_bit_cast(float, S[0] << 16), __builtin_bit_cast(float, S[0] & 0xffff0000u),
+                    __builtin_bit_cast(float, S[1] << 16), __builtin_bit_cast(float, S[1] & 0xffff0000u)};
+        asm("" : "+v"(hf));
+        r1 = v - hf;
+    }
+    S[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r1[0], r1[1]}, bf16x2));
+    S[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r1[2], r1[3]}, bf16x2));
+    if (DOT) {
+        const unsigned KLO = 0x0000bf80u, KHI = 0xbf800000u;
+        asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r2[0]) : "v"(S[2]), "s"(KLO), "v"(r1[0]));
+        asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r2[1]) : "v"(S[2]), "s"(KHI), "v"(r1[1]));
+        asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r2[2]) : "v"(S[3]), "s"(KLO), "v"(r1[2]));
+        asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r2[3]) : "v"(S[3]), "s"(KHI), "v"(r1[3]));
+    } else {
+        f32x4 mf = {__builtin_bit_cast(float, S[2] << 16), __builtin_bit_cast(float, S[2] & 0xffff0000u),
+                    __builtin_bit_cast(float, S[3] << 16), __builtin_bit_cast(float, S[3] & 0xffff0000u)};
+        asm("" : "+v"(mf));
+        r2 = r1 - mf;
+    }
+    S[4] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r2[0], r2[1]}, bf16x2));
+    S[5] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r2[2], r2[3]}, bf16x2));
+}
+template <int DOT, int PKM>
+__global__ __launch_bounds__(512, 2) void k5(float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < 27 * 1024 / 4; i += 512) reinterpret_cast<unsigned*>(sm)[i] = 0x3f803f80u;
+    __syncthreads();
+    const char* ub = sm + lane * 16;
+    f32x4 acc[9][2];
+    for (int x = 0; x < 9; ++x) acc[x][0] = acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 v = {1.f + t * 1e-3f, 2.f, 3.f + t * 1e-4f, 4.f};
+    unsigned S[2][6];
+    u32x4 A[2][3];
+    split5<DOT>(v, S[0]);
+    A[0][0] = *reinterpret_cast<const u32x4*>(ub); A[0][1] = *reinterpret_cast<const u32x4*>(ub + 1024); A[0][2] = *reinterpret_cast<const u32x4*>(ub + 2048);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int x = 0; x < 9; ++x) {
+            const int cur = x & 1, nxt = cur ^ 1;
+            const char* up = ub + ((x + 1) % 9) * 3072;
+            A[nxt][0] = *reinterpret_cast<const u32x4*>(up); A[nxt][1] = *reinterpret_cast<const u32x4*>(up + 1024); A[nxt][2] = *reinterpret_cast<const u32x4*>(up + 2048);
+            v = v * 1.0001f;
+            asm("" : "+v"(v));
+            split5<DOT>(v, S[nxt]);
+            bf16x8 Bhh, Bhl, Bmm;
+            if (PKM) {
+                const u32x2 H = {S[cur][0], S[cur][1]}, M = {S[cur][2], S[cur][3]};
+                const u32x2 H2 = pkmov(H), M2 = pkmov(M);
+                const u32x6 W = {H[0], H[1], H2[0], H2[1], S[cur][4], S[cur][5]};
+                Bhh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(W, W, 0, 1, 2, 3));
+                Bhl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(W, W, 2, 3, 4, 5));
+                Bmm = __builtin_bit_cast(bf16x8, u32x4{M[0], M[1], M2[0], M2[1]});
+            } else {
+                const u32x6 W = {S[cur][0], S[cur][1], S[cur][0], S[cur][1], S[cur][4], S[cur][5]};
+                Bhh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(W, W, 0, 1, 2, 3));
+                Bhl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(W, W, 2, 3, 4, 5));
+                Bmm = __builtin_bit_cast(bf16x8, u32x4{S[cur][2], S[cur][3], S[cur][2], S[cur][3]});
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const bf16x8 Ahm = __builtin_bit_cast(bf16x8, A[cur][ct]);
+                bf16x8 Alh;
+                if (PKM) {
+                    const u32x2 l2 = pkmov(u32x2{A[cur][2][2 * ct], A[cur][2][2 * ct + 1]}), h2 = pkmov(u32x2{A[cur][ct][0], A[cur][ct][1]});
+                    Alh = __builtin_bit_cast(bf16x8, u32x4{l2[0], l2[1], h2[0], h2[1]});
+                } else {
+                    Alh = __builtin_bit_cast(bf16x8, u32x4{A[cur][2][2 * ct], A[cur][2][2 * ct + 1], A[cur][ct][0], A[cur][ct][1]});
+                }
+                f32x4 c = acc[x][ct];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Alh, Bhl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahm, Bmm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahm, Bhh, c, 0, 0, 0);
+                acc[x][ct] = c;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int x = 0; x < 9; ++x) s += acc[x][0] + acc[x][1];
+    if (s[0] == 12345.f) out[t] = s[0] + s[1] + s[2] + s[3] + __builtin_bit_cast(float, S[0][0] ^ S[1][1]);
+}
+template <int DOT, int PKM> float run5(float* out, int iters) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k5<DOT, PKM>), hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
+    hipLaunchKernelGGL((k5<DOT, PKM>), dim3(256), dim3(512), 28 * 1024, 0, out, iters);
+    (void)hipDeviceSynchronize();
+    float best = 1e9;
+    for (int r = 0; r < 3; ++r) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((k5<DOT, PKM>), dim3(256), dim3(512), 28 * 1024, 0, out, iters);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
+    }
+    return best * 1e3f;
+}
+
+template <int VAR> float run(float* out, int iters) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
+    hipLaunchKernelGGL((k<VAR>), dim3(256), dim3(512), 28 * 1024, 0, out, iters);
+    (void)hipDeviceSynchronize();
+    float best = 1e9;
+    for (int r = 0; r < 3; ++r) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((k<VAR>), dim3(256), dim3(512), 28 * 1024, 0, out, iters);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
+    }
+    return best * 1e3f;
+}
+int main() {
+    float* out; (void)hipMalloc(&out, 4096);
+    const int iters = 400;
+    const char* names[] = {"0 split, then 6 MFMAs (compiler order)", "1 sched_group_barrier 1 MFMA : 7 VALU", "2 l-terms as 16x16x16 MFMAs",
+                           "3 MFMAs + weight reads only", "4 split + weight reads only", "5 MFMAs only", "6 as 0, packed residual subtractions"};
+    float us[7];
+    us[0] = run<0>(out, iters); us[1] = run<1>(out, iters); us[2] = run<2>(out, iters); us[3] = run<3>(out, iters);
+    us[4] = run<4>(out, iters); us[5] = run<5>(out, iters); us[6] = run<6>(out, iters);
+    // per SIMD: 2 waves x 9 positions x iters
+    for (int i = 0; i < 7; ++i)
+        printf("%-44s %8.1f us = %6.1f cycles @2.4GHz per position and wave pair (one SIMD's share); MFMA floor 2 x 6 x 16 = 192 (variant 2: 2 x 8 x 16?)\n",
+               names[i], us[i], us[i] * 2400.f / (9.f * iters));
+    const float p0 = run2<0, 0>(out, iters), p6 = run2<1, 6>(out, iters), p7 = run2<1, 7>(out, iters), p8 = run2<1, 8>(out, iters), p5 = run2<1, 5>(out, iters);
+    printf("software-pipelined (split of x+1 before the MFMAs of x): compiler order %.1f | 1 MFMA : 5 VALU %.1f | : 6 %.1f | : 7 %.1f | : 8 %.1f cycles per position and wave pair\n",
+           p0 * 2400.f / (9.f * iters), p5 * 2400.f / (9.f * iters), p6 * 2400.f / (9.f * iters), p7 * 2400.f / (9.f * iters), p8 * 2400.f / (9.f * iters));
+    printf("24-byte weight records as 6-register windows, software-pipelined: compiler order %.1f | 1 MFMA : 4 VALU %.1f | : 5 %.1f cycles per position and wave pair\n",
+           run4<0, 0>(out, iters) * 2400.f / (9.f * iters), run4<1, 4>(out, iters) * 2400.f / (9.f * iters), run4<1, 5>(out, iters) * 2400.f / (9.f * iters));
+    printf("software-pipelined, tuples by v_pk_mov_b32 / residuals by v_dot2_f32_bf16: neither %.1f | pk_mov %.1f | dot2 %.1f | both %.1f cycles per position and wave pair\n",
+           run5<0, 0>(out, iters) * 2400.f / (9.f * iters), run5<0, 1>(out, iters) * 2400.f / (9.f * iters), run5<1, 0>(out, iters) * 2400.f / (9.f * iters), run5<1, 1>(out, iters) * 2400.f / (9.f * iters));
+    {   // one wave per SIMD; cycles per position (2 tile groups x NCT cout tiles x 3 MFMAs of 16 cycles)
+        const float c4 = 2400.f / (9.f * iters);
+        printf("one wave per SIMD, 2 tile groups x 4 cout tiles (24 MFMAs = 384 cycles per position): no transform %.1f | 16 packed ops per tile group %.1f | 16 packed, 1 MFMA : 3 VALU %.1f | : 4 %.1f | : 5 %.1f\n",
+               run3<4, 0, 0>(out, iters) * c4, run3<4, 16, 0>(out, iters) * c4, run3<4, 16, 3>(out, iters) * c4, run3<4, 16, 4>(out, iters) * c4, run3<4, 16, 5>(out, iters) * c4);
+        printf("one wave per SIMD, 2 tile groups x 2 cout tiles (12 MFMAs = 192 cycles per position): no transform %.1f | 16 packed ops per tile group %.1f | 16 packed, 1 MFMA : 6 VALU %.1f | : 8 %.1f\n",
+               run3<2, 0, 0>(out, iters) * c4, run3<2, 16, 0>(out, iters) * c4, run3<2, 16, 6>(out, iters) * c4, run3<2, 16, 8>(out, iters) * c4);
+    }
+    return 0;
+}

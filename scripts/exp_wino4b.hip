@@ -266,6 +266,26 @@ int main(int argc, char** argv) {
                    time_us([&](int) { wino4b_launch<32>(a, 0); }, 10), time_us([&](int) { wino4b_launch<32 | 64>(a, 0); }, 10),
                    time_us([&](int) { wino4b_launch<3 | 32 | 64>(a, 0); }, 10), time_us([&](int) { wino4b_launch<4 | 32 | 64>(a, 0); }, 10));
             fflush(stdout);
+            // timeline of workgroup 0 (s_memtime stamps, 100 MHz ticks -> printed raw): once alone on the GPU, once in the full launch
+            for (int full = 0; full < 2; ++full) {
+                Wino4bArgs b2 = a;
+                if (!full) { b2.N = 1; b2.ntiles = 1; }
+                (void)hipMemset(yb, 0, 8 * 144 * 8);
+                wino4b_launch<128>(b2, 0);
+                (void)hipDeviceSynchronize();
+                std::vector<unsigned long long> st(8 * 144);
+                (void)hipMemcpy(st.data(), yb, st.size() * 8, hipMemcpyDeviceToHost);
+                printf("  timeline (%s), per wave: per phase [vm-wait, barrier, dma-issue, part] in ticks; stamps are s_memtime\n", full ? "full launch, block 0" : "one workgroup alone");
+                const int nph = 3 * (sh.Cin / 16);
+                for (int wv = 0; wv < 8; wv += 1) {
+                    const unsigned long long* q = &st[wv * 144];
+                    printf("    wave %d total %llu :", wv, q[4 * nph + 1] - q[0]);
+                    for (int ph = 0; ph < nph && ph < 9; ++ph)
+                        printf(" [%llu %llu %llu %llu]", q[4 * ph + 1] - q[4 * ph], q[4 * ph + 2] - q[4 * ph + 1], q[4 * ph + 3] - q[4 * ph + 2], q[4 * ph + 4] - q[4 * ph + 3]);
+                    printf(" ... epilogue %llu\n", q[4 * nph + 1] - q[4 * nph]);
+                }
+            }
+            fflush(stdout);
         }
         (void)hipFree(x); (void)hipFree(w); (void)hipFree(b); (void)hipFree(y2); (void)hipFree(y4); (void)hipFree(yb);
         (void)hipFree(u2); (void)hipFree(u4); (void)hipFree(ub);
