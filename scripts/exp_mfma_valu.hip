@@ -118,6 +118,15 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* src, int it
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds + (threadIdx.x >> 6) * 1024 + 512), 16, (int)voff, 8192, 0, 0);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds + (threadIdx.x >> 6) * 1024 + 768), 16, (int)voff, 12288, 0, 0);
                     if ((j & 3) == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else if (KIND == 12) {
+                    asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1\n v_cvt_pk_bf16_f32 %1, %1, %2\n v_cvt_pk_bf16_f32 %2, %2, %3\n v_cvt_pk_bf16_f32 %3, %3, %0"
+                                 : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
+                } else if (KIND == 13) {
+                    asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[0,1]\n v_pk_mov_b32 %1, %2, %2 op_sel:[0,1]\n v_pk_mov_b32 %2, %3, %3 op_sel:[0,1]\n v_pk_mov_b32 %3, %0, %0 op_sel:[0,1]"
+                                 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+                } else if (KIND == 14) {
+                    asm volatile("v_lshlrev_b32 %0, 16, %1\n v_and_b32 %1, 0xffff0000, %2\n v_lshlrev_b32 %2, 16, %3\n v_and_b32 %3, 0xffff0000, %0"
+                                 : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));
                 } else if (KIND == 7) {
                     asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4"
                                  : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(c));
@@ -180,6 +189,26 @@ int main() {
         printf("bf16 32x32x16 MFMA + v_mov_b32: MFMA alone %7.1f us | VALU alone %7.1f | both %7.1f | sum %7.1f\n", m4, v4, b4, m4 + v4);
         const float m5 = run<0, 1, 1>(out, src, iters), v5 = run<0, 2, 1>(out, src, iters), b5 = run<0, 3, 1>(out, src, iters);
         printf("bf16 32x32x16 MFMA + v_pk_fma_f32: MFMA alone %7.1f us | VALU alone %7.1f | both %7.1f | sum %7.1f\n", m5, v5, b5, m5 + v5);
+        {
+            const float a = run<2, 1, 2>(out, src, iters), b = run<2, 2, 2>(out, src, iters), c = run<2, 3, 2>(out, src, iters);
+            printf("bf16 16x16x32 MFMA + v_pk_add_f32: MFMA alone %7.1f us | VALU alone %7.1f | both %7.1f | sum %7.1f\n", a, b, c, a + b);
+        }
+        {
+            const float a = run<12, 1, 2>(out, src, iters), b = run<12, 2, 2>(out, src, iters), c = run<12, 3, 2>(out, src, iters);
+            printf("bf16 16x16x32 MFMA + v_cvt_pk_bf16_f32: MFMA alone %7.1f us | VALU alone %7.1f | both %7.1f | sum %7.1f\n", a, b, c, a + b);
+        }
+        {
+            const float a = run<13, 1, 2>(out, src, iters), b = run<13, 2, 2>(out, src, iters), c = run<13, 3, 2>(out, src, iters);
+            printf("bf16 16x16x32 MFMA + v_pk_mov_b32: MFMA alone %7.1f us | VALU alone %7.1f | both %7.1f | sum %7.1f\n", a, b, c, a + b);
+        }
+        {
+            const float a = run<14, 1, 2>(out, src, iters), b = run<14, 2, 2>(out, src, iters), c = run<14, 3, 2>(out, src, iters);
+            printf("bf16 16x16x32 MFMA + v_lshlrev_b32 / v_and_b32: MFMA alone %7.1f us | VALU alone %7.1f | both %7.1f | sum %7.1f\n", a, b, c, a + b);
+        }
+        {
+            const float a = run<3, 1, 2>(out, src, iters), b = run<3, 2, 2>(out, src, iters), c = run<3, 3, 2>(out, src, iters);
+            printf("bf16 16x16x32 MFMA + v_add_f32: MFMA alone %7.1f us | VALU alone %7.1f | both %7.1f | sum %7.1f\n", a, b, c, a + b);
+        }
         const float m6 = run<0, 1, 2>(out, src, iters), v6 = run<0, 2, 2>(out, src, iters), b6 = run<0, 3, 2>(out, src, iters);
         printf("bf16 16x16x32 MFMA + v_pk_fma_f32: MFMA alone %7.1f us | VALU alone %7.1f | both %7.1f | sum %7.1f\n", m6, v6, b6, m6 + v6);
     }

@@ -437,6 +437,341 @@ template <int DOT, int PKM> float run5(float* out, int iters) {
     return best * 1e3f;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// the position body as hand-scheduled inline asm on PINNED registers: operand tuples are overlapping register windows
+//   weights  XA = [ul 2 | uh 2 | um 2]:  (ul, uh) = XA[0:3], (uh, um) = XA[2:5]      (ds_read_b64 + ds_read_b128)
+//   values   W  = [h 2 | h' 2 | l 2]:    (h, h') = W[0:3],   (h', l) = W[2:5];       MM = [m 2 | m' 2]
+// 26 VALU per position (6 cvt, 8 unpack, 8 v_sub, 4 v_mov -- NO packed fp32 / v_pk_mov: those serialise with the MFMA pipe),
+// interleaved 4-5 per MFMA; register sets A / B alternate.
+#define SET_A_XA0 "v[200:203]", "v[202:205]"
+typedef unsigned u32x6b __attribute__((ext_vector_type(6)));
+struct PState { u32x6b xa0, xa1, w; u32x4 mm; };
+#define WB_SPLIT_ASM(H0, H1, HD, M0, M1, MD, L0, L1, MFMA0, MFMA1, MFMA2, MFMA3, MFMA4, MFMA5)                                   \
+    MFMA0 "v_cvt_pk_bf16_f32 " H0 ", v244, v245\n\t"                                                                                 \
+    "v_cvt_pk_bf16_f32 " H1 ", v246, v247\n\t"                                                                                       \
+    "v_lshlrev_b32 v248, 16, " H0 "\n\t"                                                                                             \
+    "v_and_b32 v249, 0xffff0000, " H0 "\n\t"                                                                                         \
+    MFMA1 "v_lshlrev_b32 v250, 16, " H1 "\n\t"                                                                                       \
+    "v_and_b32 v251, 0xffff0000, " H1 "\n\t"                                                                                         \
+    "v_sub_f32 v244, v244, v248\n\t" "v_sub_f32 v245, v245, v249\n\t"                                                                \
+    MFMA2 "v_sub_f32 v246, v246, v250\n\t" "v_sub_f32 v247, v247, v251\n\t"                                                          \
+    "v_cvt_pk_bf16_f32 " M0 ", v244, v245\n\t"                                                                                       \
+    "v_cvt_pk_bf16_f32 " M1 ", v246, v247\n\t"                                                                                       \
+    MFMA3 "v_lshlrev_b32 v248, 16, " M0 "\n\t"                                                                                       \
+    "v_and_b32 v249, 0xffff0000, " M0 "\n\t"                                                                                         \
+    "v_lshlrev_b32 v250, 16, " M1 "\n\t"                                                                                             \
+    "v_and_b32 v251, 0xffff0000, " M1 "\n\t"                                                                                         \
+    MFMA4 "v_sub_f32 v244, v244, v248\n\t" "v_sub_f32 v245, v245, v249\n\t"                                                          \
+    "v_sub_f32 v246, v246, v250\n\t" "v_sub_f32 v247, v247, v251\n\t"                                                                \
+    MFMA5 "v_cvt_pk_bf16_f32 " L0 ", v244, v245\n\t"                                                                                 \
+    "v_cvt_pk_bf16_f32 " L1 ", v246, v247\n\t"                                                                                       \
+    HD MD
+// (HD / MD spell the whole operand list of the pair copy)
+#define WB_NOSPLIT_ASM(H0, H1, HD, M0, M1, MD, L0, L1, MFMA0, MFMA1, MFMA2, MFMA3, MFMA4, MFMA5) MFMA0 MFMA1 MFMA2 MFMA3 MFMA4 MFMA5
+__global__ __launch_bounds__(512, 2) void k6_full(float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < 27 * 1024 / 4; i += 512) reinterpret_cast<unsigned*>(sm)[i] = 0x3f803f80u;
+    __syncthreads();
+    const unsigned ad = lane * 16, ad2 = lane * 8;
+    f32x4 acc[9][2];
+    for (int x = 0; x < 9; ++x) acc[x][0] = acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 v = {1.f + t * 1e-3f, 2.f, 3.f + t * 1e-4f, 4.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int P = 0; P < 3; ++P) {
+            u32x6b a0, a1, w, b0, b1, wb; u32x4 mm, mmb;
+            f32x4 x0 = v * 1.0001f, x1 = v * 1.0002f, x2 = v * 1.0003f;
+            v = x2;
+            // prologue: position 0 -> set A (loads + split, no MFMA)
+            asm volatile(
+                "ds_read_b128 v[202:205], %[ad] offset:%[o]\n\t ds_read_b64 v[200:201], %[ad2] offset:%[o]+2048\n\t"
+                "ds_read_b128 v[208:211], %[ad] offset:%[o]+1024\n\t ds_read_b64 v[206:207], %[ad2] offset:%[o]+2560\n\t"
+                WB_SPLIT_ASM("v212", "v213", "v_mov_b32 v214, v212\n\t v_mov_b32 v215, v213\n\t", "v218", "v219", "v_mov_b32 v220, v218\n\t v_mov_b32 v221, v219\n\t", "v216", "v217", "", "", "", "", "", "")
+                "s_waitcnt lgkmcnt(0)"
+                : "={v[200:205]}"(a0), "={v[206:211]}"(a1), "={v[212:217]}"(w), "={v[218:221]}"(mm), "+{v[244:247]}"(x0)
+                : [ad] "v"(ad), [ad2] "v"(ad2), [o] "n"(P * 9216) : "v248", "v249", "v250", "v251", "memory");
+            // step 0: MFMAs of position 0 (set A) + loads / split of position 1 -> set B
+#define MF(acc_, a_, b_) "v_mfma_f32_16x16x32_bf16 %[" acc_ "], " a_ ", " b_ ", %[" acc_ "]\n\t"
+            asm volatile(
+                "ds_read_b128 v[224:227], %[ad] offset:%[o]\n\t ds_read_b64 v[222:223], %[ad2] offset:%[o]+2048\n\t"
+                "ds_read_b128 v[230:233], %[ad] offset:%[o]+1024\n\t ds_read_b64 v[228:229], %[ad2] offset:%[o]+2560\n\t"
+                WB_SPLIT_ASM("v234", "v235", "v_mov_b32 v236, v234\n\t v_mov_b32 v237, v235\n\t", "v240", "v241", "v_mov_b32 v242, v240\n\t v_mov_b32 v243, v241\n\t", "v238", "v239",
+                             MF("c0", "v[200:203]", "v[214:217]"), MF("c1", "v[206:209]", "v[214:217]"), MF("c0", "v[202:205]", "v[218:221]"),
+                             MF("c1", "v[208:211]", "v[218:221]"), MF("c0", "v[202:205]", "v[212:215]"), MF("c1", "v[208:211]", "v[212:215]"))
+                "s_waitcnt lgkmcnt(0)"
+                : [c0] "+v"(acc[3 * P][0]), [c1] "+v"(acc[3 * P][1]), "={v[222:227]}"(b0), "={v[228:233]}"(b1), "={v[234:239]}"(wb), "={v[240:243]}"(mmb), "+{v[244:247]}"(x1)
+                : [ad] "v"(ad), [ad2] "v"(ad2), [o] "n"(P * 9216 + 3072), "{v[200:205]}"(a0), "{v[206:211]}"(a1), "{v[212:217]}"(w), "{v[218:221]}"(mm)
+                : "v248", "v249", "v250", "v251", "memory");
+            // step 1: MFMAs of position 1 (set B) + loads / split of position 2 -> set A
+            asm volatile(
+                "ds_read_b128 v[202:205], %[ad] offset:%[o]\n\t ds_read_b64 v[200:201], %[ad2] offset:%[o]+2048\n\t"
+                "ds_read_b128 v[208:211], %[ad] offset:%[o]+1024\n\t ds_read_b64 v[206:207], %[ad2] offset:%[o]+2560\n\t"
+                WB_SPLIT_ASM("v212", "v213", "v_mov_b32 v214, v212\n\t v_mov_b32 v215, v213\n\t", "v218", "v219", "v_mov_b32 v220, v218\n\t v_mov_b32 v221, v219\n\t", "v216", "v217",
+                             MF("c0", "v[222:225]", "v[236:239]"), MF("c1", "v[228:231]", "v[236:239]"), MF("c0", "v[224:227]", "v[240:243]"),
+                             MF("c1", "v[230:233]", "v[240:243]"), MF("c0", "v[224:227]", "v[234:237]"), MF("c1", "v[230:233]", "v[234:237]"))
+                "s_waitcnt lgkmcnt(0)"
+                : [c0] "+v"(acc[3 * P + 1][0]), [c1] "+v"(acc[3 * P + 1][1]), "={v[200:205]}"(a0), "={v[206:211]}"(a1), "={v[212:217]}"(w), "={v[218:221]}"(mm), "+{v[244:247]}"(x2)
+                : [ad] "v"(ad), [ad2] "v"(ad2), [o] "n"(P * 9216 + 6144), "{v[222:227]}"(b0), "{v[228:233]}"(b1), "{v[234:239]}"(wb), "{v[240:243]}"(mmb)
+                : "v248", "v249", "v250", "v251", "memory");
+            // step 2: MFMAs of position 2 (set A)
+            asm volatile(
+                MF("c0", "v[200:203]", "v[214:217]") MF("c1", "v[206:209]", "v[214:217]") MF("c0", "v[202:205]", "v[218:221]")
+                MF("c1", "v[208:211]", "v[218:221]") MF("c0", "v[202:205]", "v[212:215]") MF("c1", "v[208:211]", "v[212:215]")
+                : [c0] "+v"(acc[3 * P + 2][0]), [c1] "+v"(acc[3 * P + 2][1])
+                : "{v[200:205]}"(a0), "{v[206:211]}"(a1), "{v[212:217]}"(w), "{v[218:221]}"(mm));
+        }
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int x = 0; x < 9; ++x) s += acc[x][0] + acc[x][1];
+    if (s[0] == 12345.f) out[t] = s[0] + s[1] + s[2] + s[3];
+}
+#undef MF
+__global__ __launch_bounds__(512, 2) void k6_nomfma(float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < 27 * 1024 / 4; i += 512) reinterpret_cast<unsigned*>(sm)[i] = 0x3f803f80u;
+    __syncthreads();
+    const unsigned ad = lane * 16, ad2 = lane * 8;
+    f32x4 acc[9][2];
+    for (int x = 0; x < 9; ++x) acc[x][0] = acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 v = {1.f + t * 1e-3f, 2.f, 3.f + t * 1e-4f, 4.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int P = 0; P < 3; ++P) {
+            u32x6b a0, a1, w, b0, b1, wb; u32x4 mm, mmb;
+            f32x4 x0 = v * 1.0001f, x1 = v * 1.0002f, x2 = v * 1.0003f;
+            v = x2;
+            // prologue: position 0 -> set A (loads + split, no MFMA)
+            asm volatile(
+                "ds_read_b128 v[202:205], %[ad] offset:%[o]\n\t ds_read_b64 v[200:201], %[ad2] offset:%[o]+2048\n\t"
+                "ds_read_b128 v[208:211], %[ad] offset:%[o]+1024\n\t ds_read_b64 v[206:207], %[ad2] offset:%[o]+2560\n\t"
+                WB_SPLIT_ASM("v212", "v213", "v_mov_b32 v214, v212\n\t v_mov_b32 v215, v213\n\t", "v218", "v219", "v_mov_b32 v220, v218\n\t v_mov_b32 v221, v219\n\t", "v216", "v217", "", "", "", "", "", "")
+                "s_waitcnt lgkmcnt(0)"
+                : "={v[200:205]}"(a0), "={v[206:211]}"(a1), "={v[212:217]}"(w), "={v[218:221]}"(mm), "+{v[244:247]}"(x0)
+                : [ad] "v"(ad), [ad2] "v"(ad2), [o] "n"(P * 9216) : "v248", "v249", "v250", "v251", "memory");
+            // step 0: MFMAs of position 0 (set A) + loads / split of position 1 -> set B
+#define MF(acc_, a_, b_) ""
+            asm volatile(
+                "ds_read_b128 v[224:227], %[ad] offset:%[o]\n\t ds_read_b64 v[222:223], %[ad2] offset:%[o]+2048\n\t"
+                "ds_read_b128 v[230:233], %[ad] offset:%[o]+1024\n\t ds_read_b64 v[228:229], %[ad2] offset:%[o]+2560\n\t"
+                WB_SPLIT_ASM("v234", "v235", "v_mov_b32 v236, v234\n\t v_mov_b32 v237, v235\n\t", "v240", "v241", "v_mov_b32 v242, v240\n\t v_mov_b32 v243, v241\n\t", "v238", "v239",
+                             MF("c0", "v[200:203]", "v[214:217]"), MF("c1", "v[206:209]", "v[214:217]"), MF("c0", "v[202:205]", "v[218:221]"),
+                             MF("c1", "v[208:211]", "v[218:221]"), MF("c0", "v[202:205]", "v[212:215]"), MF("c1", "v[208:211]", "v[212:215]"))
+                "s_waitcnt lgkmcnt(0)"
+                : [c0] "+v"(acc[3 * P][0]), [c1] "+v"(acc[3 * P][1]), "={v[222:227]}"(b0), "={v[228:233]}"(b1), "={v[234:239]}"(wb), "={v[240:243]}"(mmb), "+{v[244:247]}"(x1)
+                : [ad] "v"(ad), [ad2] "v"(ad2), [o] "n"(P * 9216 + 3072), "{v[200:205]}"(a0), "{v[206:211]}"(a1), "{v[212:217]}"(w), "{v[218:221]}"(mm)
+                : "v248", "v249", "v250", "v251", "memory");
+            // step 1: MFMAs of position 1 (set B) + loads / split of position 2 -> set A
+            asm volatile(
+                "ds_read_b128 v[202:205], %[ad] offset:%[o]\n\t ds_read_b64 v[200:201], %[ad2] offset:%[o]+2048\n\t"
+                "ds_read_b128 v[208:211], %[ad] offset:%[o]+1024\n\t ds_read_b64 v[206:207], %[ad2] offset:%[o]+2560\n\t"
+                WB_SPLIT_ASM("v212", "v213", "v_mov_b32 v214, v212\n\t v_mov_b32 v215, v213\n\t", "v218", "v219", "v_mov_b32 v220, v218\n\t v_mov_b32 v221, v219\n\t", "v216", "v217",
+                             MF("c0", "v[222:225]", "v[236:239]"), MF("c1", "v[228:231]", "v[236:239]"), MF("c0", "v[224:227]", "v[240:243]"),
+                             MF("c1", "v[230:233]", "v[240:243]"), MF("c0", "v[224:227]", "v[234:237]"), MF("c1", "v[230:233]", "v[234:237]"))
+                "s_waitcnt lgkmcnt(0)"
+                : [c0] "+v"(acc[3 * P + 1][0]), [c1] "+v"(acc[3 * P + 1][1]), "={v[200:205]}"(a0), "={v[206:211]}"(a1), "={v[212:217]}"(w), "={v[218:221]}"(mm), "+{v[244:247]}"(x2)
+                : [ad] "v"(ad), [ad2] "v"(ad2), [o] "n"(P * 9216 + 6144), "{v[222:227]}"(b0), "{v[228:233]}"(b1), "{v[234:239]}"(wb), "{v[240:243]}"(mmb)
+                : "v248", "v249", "v250", "v251", "memory");
+            // step 2: MFMAs of position 2 (set A)
+            asm volatile(
+                MF("c0", "v[200:203]", "v[214:217]") MF("c1", "v[206:209]", "v[214:217]") MF("c0", "v[202:205]", "v[218:221]")
+                MF("c1", "v[208:211]", "v[218:221]") MF("c0", "v[202:205]", "v[212:215]") MF("c1", "v[208:211]", "v[212:215]")
+                : [c0] "+v"(acc[3 * P + 2][0]), [c1] "+v"(acc[3 * P + 2][1])
+                : "{v[200:205]}"(a0), "{v[206:211]}"(a1), "{v[212:217]}"(w), "{v[218:221]}"(mm));
+        }
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int x = 0; x < 9; ++x) s += acc[x][0] + acc[x][1];
+    if (s[0] == 12345.f) out[t] = s[0] + s[1] + s[2] + s[3];
+}
+#undef MF
+__global__ __launch_bounds__(512, 2) void k6_novalu(float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < 27 * 1024 / 4; i += 512) reinterpret_cast<unsigned*>(sm)[i] = 0x3f803f80u;
+    __syncthreads();
+    const unsigned ad = lane * 16, ad2 = lane * 8;
+    f32x4 acc[9][2];
+    for (int x = 0; x < 9; ++x) acc[x][0] = acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 v = {1.f + t * 1e-3f, 2.f, 3.f + t * 1e-4f, 4.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int P = 0; P < 3; ++P) {
+            u32x6b a0, a1, w, b0, b1, wb; u32x4 mm, mmb;
+            f32x4 x0 = v * 1.0001f, x1 = v * 1.0002f, x2 = v * 1.0003f;
+            v = x2;
+            // prologue: position 0 -> set A (loads + split, no MFMA)
+            asm volatile(
+                "ds_read_b128 v[202:205], %[ad] offset:%[o]\n\t ds_read_b64 v[200:201], %[ad2] offset:%[o]+2048\n\t"
+                "ds_read_b128 v[208:211], %[ad] offset:%[o]+1024\n\t ds_read_b64 v[206:207], %[ad2] offset:%[o]+2560\n\t"
+                WB_NOSPLIT_ASM("v212", "v213", "v_mov_b32 v214, v212\n\t v_mov_b32 v215, v213\n\t", "v218", "v219", "v_mov_b32 v220, v218\n\t v_mov_b32 v221, v219\n\t", "v216", "v217", "", "", "", "", "", "")
+                "s_waitcnt lgkmcnt(0)"
+                : "={v[200:205]}"(a0), "={v[206:211]}"(a1), "={v[212:217]}"(w), "={v[218:221]}"(mm), "+{v[244:247]}"(x0)
+                : [ad] "v"(ad), [ad2] "v"(ad2), [o] "n"(P * 9216) : "v248", "v249", "v250", "v251", "memory");
+            // step 0: MFMAs of position 0 (set A) + loads / split of position 1 -> set B
+#define MF(acc_, a_, b_) "v_mfma_f32_16x16x32_bf16 %[" acc_ "], " a_ ", " b_ ", %[" acc_ "]\n\t"
+            asm volatile(
+                "ds_read_b128 v[224:227], %[ad] offset:%[o]\n\t ds_read_b64 v[222:223], %[ad2] offset:%[o]+2048\n\t"
+                "ds_read_b128 v[230:233], %[ad] offset:%[o]+1024\n\t ds_read_b64 v[228:229], %[ad2] offset:%[o]+2560\n\t"
+                WB_NOSPLIT_ASM("v234", "v235", "v_mov_b32 v236, v234\n\t v_mov_b32 v237, v235\n\t", "v240", "v241", "v_mov_b32 v242, v240\n\t v_mov_b32 v243, v241\n\t", "v238", "v239",
+                             MF("c0", "v[200:203]", "v[214:217]"), MF("c1", "v[206:209]", "v[214:217]"), MF("c0", "v[202:205]", "v[218:221]"),
+                             MF("c1", "v[208:211]", "v[218:221]"), MF("c0", "v[202:205]", "v[212:215]"), MF("c1", "v[208:211]", "v[212:215]"))
+                "s_waitcnt lgkmcnt(0)"
+                : [c0] "+v"(acc[3 * P][0]), [c1] "+v"(acc[3 * P][1]), "={v[222:227]}"(b0), "={v[228:233]}"(b1), "={v[234:239]}"(wb), "={v[240:243]}"(mmb), "+{v[244:247]}"(x1)
+                : [ad] "v"(ad), [ad2] "v"(ad2), [o] "n"(P * 9216 + 3072), "{v[200:205]}"(a0), "{v[206:211]}"(a1), "{v[212:217]}"(w), "{v[218:221]}"(mm)
+                : "v248", "v249", "v250", "v251", "memory");
+            // step 1: MFMAs of position 1 (set B) + loads / split of position 2 -> set A
+            asm volatile(
+                "ds_read_b128 v[202:205], %[ad] offset:%[o]\n\t ds_read_b64 v[200:201], %[ad2] offset:%[o]+2048\n\t"
+                "ds_read_b128 v[208:211], %[ad] offset:%[o]+1024\n\t ds_read_b64 v[206:207], %[ad2] offset:%[o]+2560\n\t"
+                WB_NOSPLIT_ASM("v212", "v213", "v_mov_b32 v214, v212\n\t v_mov_b32 v215, v213\n\t", "v218", "v219", "v_mov_b32 v220, v218\n\t v_mov_b32 v221, v219\n\t", "v216", "v217",
+                             MF("c0", "v[222:225]", "v[236:239]"), MF("c1", "v[228:231]", "v[236:239]"), MF("c0", "v[224:227]", "v[240:243]"),
+                             MF("c1", "v[230:233]", "v[240:243]"), MF("c0", "v[224:227]", "v[234:237]"), MF("c1", "v[230:233]", "v[234:237]"))
+                "s_waitcnt lgkmcnt(0)"
+                : [c0] "+v"(acc[3 * P + 1][0]), [c1] "+v"(acc[3 * P + 1][1]), "={v[200:205]}"(a0), "={v[206:211]}"(a1), "={v[212:217]}"(w), "={v[218:221]}"(mm), "+{v[244:247]}"(x2)
+                : [ad] "v"(ad), [ad2] "v"(ad2), [o] "n"(P * 9216 + 6144), "{v[222:227]}"(b0), "{v[228:233]}"(b1), "{v[234:239]}"(wb), "{v[240:243]}"(mmb)
+                : "v248", "v249", "v250", "v251", "memory");
+            // step 2: MFMAs of position 2 (set A)
+            asm volatile(
+                MF("c0", "v[200:203]", "v[214:217]") MF("c1", "v[206:209]", "v[214:217]") MF("c0", "v[202:205]", "v[218:221]")
+                MF("c1", "v[208:211]", "v[218:221]") MF("c0", "v[202:205]", "v[212:215]") MF("c1", "v[208:211]", "v[212:215]")
+                : [c0] "+v"(acc[3 * P + 2][0]), [c1] "+v"(acc[3 * P + 2][1])
+                : "{v[200:205]}"(a0), "{v[206:211]}"(a1), "{v[212:217]}"(w), "{v[218:221]}"(mm));
+        }
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int x = 0; x < 9; ++x) s += acc[x][0] + acc[x][1];
+    if (s[0] == 12345.f) out[t] = s[0] + s[1] + s[2] + s[3];
+}
+#undef MF
+__global__ __launch_bounds__(512, 2) void k6_nolds(float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < 27 * 1024 / 4; i += 512) reinterpret_cast<unsigned*>(sm)[i] = 0x3f803f80u;
+    __syncthreads();
+    const unsigned ad = lane * 16, ad2 = lane * 8;
+    f32x4 acc[9][2];
+    for (int x = 0; x < 9; ++x) acc[x][0] = acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 v = {1.f + t * 1e-3f, 2.f, 3.f + t * 1e-4f, 4.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int P = 0; P < 3; ++P) {
+            u32x6b a0, a1, w, b0, b1, wb; u32x4 mm, mmb;
+            f32x4 x0 = v * 1.0001f, x1 = v * 1.0002f, x2 = v * 1.0003f;
+            v = x2;
+            // prologue: position 0 -> set A (loads + split, no MFMA)
+            asm volatile(
+                ""
+                WB_SPLIT_ASM("v212", "v213", "v_mov_b32 v214, v212\n\t v_mov_b32 v215, v213\n\t", "v218", "v219", "v_mov_b32 v220, v218\n\t v_mov_b32 v221, v219\n\t", "v216", "v217", "", "", "", "", "", "")
+                ""
+                : "={v[200:205]}"(a0), "={v[206:211]}"(a1), "={v[212:217]}"(w), "={v[218:221]}"(mm), "+{v[244:247]}"(x0)
+                : [ad] "v"(ad), [ad2] "v"(ad2), [o] "n"(P * 9216) : "v248", "v249", "v250", "v251", "memory");
+            // step 0: MFMAs of position 0 (set A) + loads / split of position 1 -> set B
+#define MF(acc_, a_, b_) "v_mfma_f32_16x16x32_bf16 %[" acc_ "], " a_ ", " b_ ", %[" acc_ "]\n\t"
+            asm volatile(
+                ""
+                WB_SPLIT_ASM("v234", "v235", "v_mov_b32 v236, v234\n\t v_mov_b32 v237, v235\n\t", "v240", "v241", "v_mov_b32 v242, v240\n\t v_mov_b32 v243, v241\n\t", "v238", "v239",
+                             MF("c0", "v[200:203]", "v[214:217]"), MF("c1", "v[206:209]", "v[214:217]"), MF("c0", "v[202:205]", "v[218:221]"),
+                             MF("c1", "v[208:211]", "v[218:221]"), MF("c0", "v[202:205]", "v[212:215]"), MF("c1", "v[208:211]", "v[212:215]"))
+                ""
+                : [c0] "+v"(acc[3 * P][0]), [c1] "+v"(acc[3 * P][1]), "={v[222:227]}"(b0), "={v[228:233]}"(b1), "={v[234:239]}"(wb), "={v[240:243]}"(mmb), "+{v[244:247]}"(x1)
+                : [ad] "v"(ad), [ad2] "v"(ad2), [o] "n"(P * 9216 + 3072), "{v[200:205]}"(a0), "{v[206:211]}"(a1), "{v[212:217]}"(w), "{v[218:221]}"(mm)
+                : "v248", "v249", "v250", "v251", "memory");
+            // step 1: MFMAs of position 1 (set B) + loads / split of position 2 -> set A
+            asm volatile(
+                ""
+                WB_SPLIT_ASM("v212", "v213", "v_mov_b32 v214, v212\n\t v_mov_b32 v215, v213\n\t", "v218", "v219", "v_mov_b32 v220, v218\n\t v_mov_b32 v221, v219\n\t", "v216", "v217",
+                             MF("c0", "v[222:225]", "v[236:239]"), MF("c1", "v[228:231]", "v[236:239]"), MF("c0", "v[224:227]", "v[240:243]"),
+                             MF("c1", "v[230:233]", "v[240:243]"), MF("c0", "v[224:227]", "v[234:237]"), MF("c1", "v[230:233]", "v[234:237]"))
+                ""
+                : [c0] "+v"(acc[3 * P + 1][0]), [c1] "+v"(acc[3 * P + 1][1]), "={v[200:205]}"(a0), "={v[206:211]}"(a1), "={v[212:217]}"(w), "={v[218:221]}"(mm), "+{v[244:247]}"(x2)
+                : [ad] "v"(ad), [ad2] "v"(ad2), [o] "n"(P * 9216 + 6144), "{v[222:227]}"(b0), "{v[228:233]}"(b1), "{v[234:239]}"(wb), "{v[240:243]}"(mmb)
+                : "v248", "v249", "v250", "v251", "memory");
+            // step 2: MFMAs of position 2 (set A)
+            asm volatile(
+                MF("c0", "v[200:203]", "v[214:217]") MF("c1", "v[206:209]", "v[214:217]") MF("c0", "v[202:205]", "v[218:221]")
+                MF("c1", "v[208:211]", "v[218:221]") MF("c0", "v[202:205]", "v[212:215]") MF("c1", "v[208:211]", "v[212:215]")
+                : [c0] "+v"(acc[3 * P + 2][0]), [c1] "+v"(acc[3 * P + 2][1])
+                : "{v[200:205]}"(a0), "{v[206:211]}"(a1), "{v[212:217]}"(w), "{v[218:221]}"(mm));
+        }
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int x = 0; x < 9; ++x) s += acc[x][0] + acc[x][1];
+    if (s[0] == 12345.f) out[t] = s[0] + s[1] + s[2] + s[3];
+}
+#undef MF
+__global__ __launch_bounds__(512, 2) void k6_mfmaonly(float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < 27 * 1024 / 4; i += 512) reinterpret_cast<unsigned*>(sm)[i] = 0x3f803f80u;
+    __syncthreads();
+    const unsigned ad = lane * 16, ad2 = lane * 8;
+    f32x4 acc[9][2];
+    for (int x = 0; x < 9; ++x) acc[x][0] = acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 v = {1.f + t * 1e-3f, 2.f, 3.f + t * 1e-4f, 4.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int P = 0; P < 3; ++P) {
+            u32x6b a0, a1, w, b0, b1, wb; u32x4 mm, mmb;
+            f32x4 x0 = v * 1.0001f, x1 = v * 1.0002f, x2 = v * 1.0003f;
+            v = x2;
+            // prologue: position 0 -> set A (loads + split, no MFMA)
+            asm volatile(
+                ""
+                WB_NOSPLIT_ASM("v212", "v213", "v_mov_b32 v214, v212\n\t v_mov_b32 v215, v213\n\t", "v218", "v219", "v_mov_b32 v220, v218\n\t v_mov_b32 v221, v219\n\t", "v216", "v217", "", "", "", "", "", "")
+                ""
+                : "={v[200:205]}"(a0), "={v[206:211]}"(a1), "={v[212:217]}"(w), "={v[218:221]}"(mm), "+{v[244:247]}"(x0)
+                : [ad] "v"(ad), [ad2] "v"(ad2), [o] "n"(P * 9216) : "v248", "v249", "v250", "v251", "memory");
+            // step 0: MFMAs of position 0 (set A) + loads / split of position 1 -> set B
+#define MF(acc_, a_, b_) "v_mfma_f32_16x16x32_bf16 %[" acc_ "], " a_ ", " b_ ", %[" acc_ "]\n\t"
+            asm volatile(
+                ""
+                WB_NOSPLIT_ASM("v234", "v235", "v_mov_b32 v236, v234\n\t v_mov_b32 v237, v235\n\t", "v240", "v241", "v_mov_b32 v242, v240\n\t v_mov_b32 v243, v241\n\t", "v238", "v239",
+                             MF("c0", "v[200:203]", "v[214:217]"), MF("c1", "v[206:209]", "v[214:217]"), MF("c0", "v[202:205]", "v[218:221]"),
+                             MF("c1", "v[208:211]", "v[218:221]"), MF("c0", "v[202:205]", "v[212:215]"), MF("c1", "v[208:211]", "v[212:215]"))
+                ""
+                : [c0] "+v"(acc[3 * P][0]), [c1] "+v"(acc[3 * P][1]), "={v[222:227]}"(b0), "={v[228:233]}"(b1), "={v[234:239]}"(wb), "={v[240:243]}"(mmb), "+{v[244:247]}"(x1)
+                : [ad] "v"(ad), [ad2] "v"(ad2), [o] "n"(P * 9216 + 3072), "{v[200:205]}"(a0), "{v[206:211]}"(a1), "{v[212:217]}"(w), "{v[218:221]}"(mm)
+                : "v248", "v249", "v250", "v251", "memory");
+            // step 1: MFMAs of position 1 (set B) + loads / split of position 2 -> set A
+            asm volatile(
+                ""
+                WB_NOSPLIT_ASM("v212", "v213", "v_mov_b32 v214, v212\n\t v_mov_b32 v215, v213\n\t", "v218", "v219", "v_mov_b32 v220, v218\n\t v_mov_b32 v221, v219\n\t", "v216", "v217",
+                             MF("c0", "v[222:225]", "v[236:239]"), MF("c1", "v[228:231]", "v[236:239]"), MF("c0", "v[224:227]", "v[240:243]"),
+                             MF("c1", "v[230:233]", "v[240:243]"), MF("c0", "v[224:227]", "v[234:237]"), MF("c1", "v[230:233]", "v[234:237]"))
+                ""
+                : [c0] "+v"(acc[3 * P + 1][0]), [c1] "+v"(acc[3 * P + 1][1]), "={v[200:205]}"(a0), "={v[206:211]}"(a1), "={v[212:217]}"(w), "={v[218:221]}"(mm), "+{v[244:247]}"(x2)
+                : [ad] "v"(ad), [ad2] "v"(ad2), [o] "n"(P * 9216 + 6144), "{v[222:227]}"(b0), "{v[228:233]}"(b1), "{v[234:239]}"(wb), "{v[240:243]}"(mmb)
+                : "v248", "v249", "v250", "v251", "memory");
+            // step 2: MFMAs of position 2 (set A)
+            asm volatile(
+                MF("c0", "v[200:203]", "v[214:217]") MF("c1", "v[206:209]", "v[214:217]") MF("c0", "v[202:205]", "v[218:221]")
+                MF("c1", "v[208:211]", "v[218:221]") MF("c0", "v[202:205]", "v[212:215]") MF("c1", "v[208:211]", "v[212:215]")
+                : [c0] "+v"(acc[3 * P + 2][0]), [c1] "+v"(acc[3 * P + 2][1])
+                : "{v[200:205]}"(a0), "{v[206:211]}"(a1), "{v[212:217]}"(w), "{v[218:221]}"(mm));
+        }
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int x = 0; x < 9; ++x) s += acc[x][0] + acc[x][1];
+    if (s[0] == 12345.f) out[t] = s[0] + s[1] + s[2] + s[3];
+}
+#undef MF
+template <typename K> float run6(K kern, float* out, int iters) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 30 * 1024);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), 30 * 1024, 0, out, iters);
+    (void)hipDeviceSynchronize();
+    float best = 1e9;
+    for (int r = 0; r < 3; ++r) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(512), 30 * 1024, 0, out, iters);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
+    }
+    return best * 1e3f;
+}
+
 template <int VAR> float run(float* out, int iters) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
@@ -470,6 +805,9 @@ int main() {
            run4<0, 0>(out, iters) * 2400.f / (9.f * iters), run4<1, 4>(out, iters) * 2400.f / (9.f * iters), run4<1, 5>(out, iters) * 2400.f / (9.f * iters));
     printf("software-pipelined, tuples by v_pk_mov_b32 / residuals by v_dot2_f32_bf16: neither %.1f | pk_mov %.1f | dot2 %.1f | both %.1f cycles per position and wave pair\n",
            run5<0, 0>(out, iters) * 2400.f / (9.f * iters), run5<0, 1>(out, iters) * 2400.f / (9.f * iters), run5<1, 0>(out, iters) * 2400.f / (9.f * iters), run5<1, 1>(out, iters) * 2400.f / (9.f * iters));
+    printf("hand-scheduled asm on pinned register windows (3 positions per part: prologue split + 2 pipelined steps + tail): full %.1f | no MFMA %.1f | no VALU %.1f | no LDS reads / waits %.1f | MFMAs only %.1f cycles per position and wave pair\n",
+           run6(k6_full, out, iters) * 2400.f / (9.f * iters), run6(k6_nomfma, out, iters) * 2400.f / (9.f * iters), run6(k6_novalu, out, iters) * 2400.f / (9.f * iters),
+           run6(k6_nolds, out, iters) * 2400.f / (9.f * iters), run6(k6_mfmaonly, out, iters) * 2400.f / (9.f * iters));
     {   // one wave per SIMD; cycles per position (2 tile groups x NCT cout tiles x 3 MFMAs of 16 cycles)
         const float c4 = 2400.f / (9.f * iters);
         printf("one wave per SIMD, 2 tile groups x 4 cout tiles (24 MFMAs = 384 cycles per position): no transform %.1f | 16 packed ops per tile group %.1f | 16 packed, 1 MFMA : 3 VALU %.1f | : 4 %.1f | : 5 %.1f\n",

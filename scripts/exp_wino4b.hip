@@ -4,7 +4,7 @@
 // split bf16 forms, errors against float64.  Not part of the library.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize scripts/exp_wino4b.hip -o scripts/exp_wino4b.bin
 #include "../pwcnet_amd/csrc/conv3x3_wino.hip"
-#include "../pwcnet_amd/csrc/conv3x3_wino4b.hip"
+#include "experiments/conv3x3_wino4b.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

@@ -38,7 +38,7 @@
 //   buffer_load_dwordx4 ... lds; single-buffered, the weights in three parts that are re-fetched for the next stage as
 //   soon as every wave has read them (the pipeline of conv3x3_wino4.hip).
 #pragma once
-#include "pwc_common.h"
+#include "../../pwcnet_amd/csrc/pwc_common.h"
 #include <type_traits>
 
 typedef __bf16 pwc_bf16x8 __attribute__((ext_vector_type(8)));
