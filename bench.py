@@ -238,10 +238,7 @@ def main():
     net = pwcnet_amd.PWCDCNet(use_dc=args.use_dc, persistent_outputs=args.persistent_outputs,
                               streams=args.streams if args.streams > 0 else None)
     net.load_weights(wts)
-    eff_streams = net.streams if net.streams is not None else (2 if (args.batch % 2 == 0 and (args.batch >= 4 or (args.batch == 2 and args.height * args.width >= 256 * 512))) else 1)
-    if args.persistent_outputs:
-        eff_streams = 1
-    overlapped = eff_streams > 1      # HIP events on the caller's stream do not bracket side-stream kernels
+    eff_streams = 1 if args.persistent_outputs else net.effective_streams((args.batch, args.height, args.width, 3))
 
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
@@ -252,6 +249,11 @@ def main():
     for _ in range(args.warmup):
         net(im0, im1)
     torch.cuda.synchronize()
+    # the model's own verdict on its side streams (device-timed queue probe); no vetted stream -> it ran single-stream
+    ss_report = net.side_stream_report
+    if eff_streams > 1 and (ss_report is None or ss_report.get("verdict") != "vetted"):
+        eff_streams = 1
+    overlapped = eff_streams > 1      # HIP events on the caller's stream do not bracket side-stream kernels
 
     def sync_all():
         torch.cuda.synchronize()
@@ -342,6 +344,9 @@ def main():
                            + ("; RCCL all-gather of per-rank stats" if used_rccl else ""),
             "outputs": "persistent (plan-owned)" if args.persistent_outputs else "fresh tensors per call",
             "streams": eff_streams,
+            "side_streams": (None if ss_report is None else
+                             {"verdict": ss_report.get("verdict"), "picked": len(ss_report.get("picked", [])),
+                              "rejected": ss_report.get("rejected"), "probes": len(ss_report.get("probes", []))}),
         },
     }
 

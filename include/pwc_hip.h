@@ -233,6 +233,13 @@ int pwc_resize_bilinear_pair_f32(const float* xa, int xa_cs, float* ya, int ya_c
                                  const float* xb, int xb_cs, float* yb, int yb_cs,
                                  int N, int H, int W, int CB, int OH, int OW, pwc_stream_t stream);
 
+/* ---- stream placement probe (no reference counterpart: the reference times repeated sess.run calls, test.py:48-53, and
+ * must not depend on the process's stream history).  pwc_device_spin keeps `stream` busy for about `ticks` cycles of the
+ * device clock counter without touching memory; pwc_device_touch adds 1 to p[0].  pwcnet_amd/model.py brackets the pair
+ * with timing events to learn whether two HIP streams share a hardware queue; never part of a forward. */
+int pwc_device_spin(long long ticks, pwc_stream_t stream);
+int pwc_device_touch(float* p, pwc_stream_t stream);
+
 /* ---- tf.concat helper (modules.py:264,305): dst[p, 0:C] = src[p, 0:C] for npix pixels. */
 int pwc_copy_channels_f32(const float* src, int src_cs, float* dst, int dst_cs,
                           long npix, int C, pwc_stream_t stream);

@@ -55,6 +55,8 @@ SIGNATURES = {
     "pwc_conv3x3_direct_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_resize_bilinear_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_copy_channels_f32": (_i, [_vp, _i, _vp, _i, _l, _i, _vp]),
+    "pwc_device_spin": (_i, [ctypes.c_longlong, _vp]),
+    "pwc_device_touch": (_i, [_vp, _vp]),
     "pwc_lrelu_grad_f32": (_i, [_vp, _i, _vp, _i, _l, _i, _f, _vp]),
     "pwc_add_f32": (_i, [_vp, _i, _vp, _i, _l, _i, _f, _i, _vp]),
     "pwc_channel_sums_workspace_floats": (_sz, [_l, _i]),

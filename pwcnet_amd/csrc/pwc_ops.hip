@@ -397,3 +397,28 @@ extern "C" int pwc_flow_norm_sums_f32(const float* pred, int pred_cs, const floa
                        (const float*)workspace, parts, N, out_sums);
     return pwc_launch_status();
 }
+
+// ---------------------------------------------------------------- stream placement probe (host side: pwcnet_amd/model.py)
+// Keeps `stream` busy for about `ticks` cycles of the device's s_memtime counter without touching memory.  Used ONLY to find
+// out whether two HIP streams are served by one hardware queue (a kernel on the second stream then cannot start before this
+// one ends); never part of a forward.
+__global__ void pwc_spin_kernel(long long ticks) {
+    const long long t0 = (long long)__builtin_readcyclecounter();
+    while ((long long)__builtin_readcyclecounter() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+__global__ void pwc_touch_kernel(float* p) {
+    if (p && threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1.0f;
+}
+
+extern "C" int pwc_device_spin(long long ticks, pwc_stream_t stream) {
+    if (ticks < 0 || ticks > (1LL << 34)) return PWC_EINVAL;
+    hipLaunchKernelGGL(pwc_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks);
+    return pwc_launch_status();
+}
+
+extern "C" int pwc_device_touch(float* p, pwc_stream_t stream) {
+    if (!p) return PWC_EINVAL;
+    hipLaunchKernelGGL(pwc_touch_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p);
+    return pwc_launch_status();
+}
+

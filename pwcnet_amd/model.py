@@ -28,43 +28,65 @@ from .modules import (ContextNetwork, CostVolumeLayer, FeaturePyramidExtractor_c
 from .weights import ChannelLayout, SCALES, conv_specs
 
 
+def _shares_queue(dev, a, b, probe, spin_ticks=400_000):
+    """True if HIP serves streams `a` and `b` from one hardware queue, decided on DEVICE timestamps: a spin kernel on `a`
+    bracketed by timing events gives the spin's own duration; a one-thread kernel issued on `b` right behind it finishes
+    either at once (own queue) or only after the spin (shared queue).  No host clock is involved, so a pre-empted host
+    thread cannot fake a shared queue."""
+    L = _lib.lib()
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record(a)
+    _lib.check(L.pwc_device_spin(spin_ticks, _lib.ctypes.c_void_p(a.cuda_stream)), "stream probe spin")
+    e1.record(a)
+    _lib.check(L.pwc_device_touch(_lib.ctypes.c_void_p(probe.data_ptr()), _lib.ctypes.c_void_p(b.cuda_stream)),
+               "stream probe touch")
+    e2.record(b)
+    e1.synchronize()
+    e2.synchronize()
+    spin_ms = e0.elapsed_time(e1)
+    touch_ms = e0.elapsed_time(e2)          # when the kernel on b was done, measured from the start of the spin on a
+    return touch_ms > 0.5 * spin_ms, spin_ms, touch_ms
+
+
 def _pick_side_streams(dev, main, count):
-    """`count` torch streams for the sub-batches that do not run on the caller's stream.  HIP maps streams onto a few
-    hardware queues (4 by default); a side stream that shares the caller's queue -- or another side stream's -- runs
-    behind it instead of beside it (measured: 4.08 against 3.26 ms per forward, profiles/r03_exp_side_stream_queues.txt).
-    Candidates are probed once: a device-side sleep on one stream, a tiny kernel on the other; if the tiny kernel only
-    completes after the sleep, the two share a queue."""
-    import time
-    cands = [torch.cuda.Stream(device=dev) for _ in range(max(6, 2 * count + 2))]
-    try:
-        probe = torch.zeros(64, device=dev)
-        for s in cands:
-            with torch.cuda.stream(s):
-                probe.add_(1)
-        torch.cuda.synchronize(dev)
+    """(streams, report): `count` torch streams for the sub-batches that do not run on the caller's stream, or
+    (None, report) if no vetted set exists -- the caller then runs single-stream (-7 %) instead of risking a side stream
+    behind the caller's queue (-25 %: 4.08 against 3.26 ms per forward, profiles/r03_exp_side_stream_queues.txt).
+    HIP maps streams onto a few hardware queues (4 by default); every candidate is checked against the caller's stream
+    and against the streams already picked (_shares_queue), twice if the first verdict says "shared"."""
+    report = {"device": str(dev), "main_stream": int(main.cuda_stream), "picked": [], "rejected": 0, "probes": []}
+    if torch.cuda.is_current_stream_capturing():
+        report["verdict"] = "capturing: no probe, single stream"
+        return None, report
+    cands = [torch.cuda.Stream(device=dev) for _ in range(max(8, 2 * count + 4))]
+    probe = torch.zeros(64, device=dev)
+    torch.cuda.synchronize(dev)
 
-        def shares(a, b):
-            with torch.cuda.stream(a):
-                torch.cuda._sleep(1_000_000)                 # ~0.5 ms of spinning on the device
-            t0 = time.perf_counter()
-            with torch.cuda.stream(b):
-                probe.add_(1)
-            b.synchronize()
-            dt = time.perf_counter() - t0
-            torch.cuda.synchronize(dev)
-            return dt > 0.2e-3
+    def shared(a, b):
+        for _ in range(2):                               # a "shared" verdict is confirmed once
+            sh, spin_ms, touch_ms = _shares_queue(dev, a, b, probe)
+            report["probes"].append((int(a.cuda_stream), int(b.cuda_stream), round(spin_ms, 4), round(touch_ms, 4), bool(sh)))
+            if spin_ms < 0.02:                           # the spin did not spin (clock counter stuck?): no verdict
+                return True
+            if not sh:
+                return False
+        return True
 
-        picked = []
-        for s in cands:
-            if len(picked) == count:
-                break
-            if not shares(main, s) and not any(shares(p, s) for p in picked):
-                picked.append(s)
+    picked = []
+    for s in cands:
         if len(picked) == count:
-            return picked
-    except Exception:                                       # no probe: take what comes
-        pass
-    return cands[:count]
+            break
+        if not shared(main, s) and not any(shared(q, s) for q in picked):
+            picked.append(s)
+        else:
+            report["rejected"] += 1
+    torch.cuda.synchronize(dev)
+    if len(picked) == count:
+        report["picked"] = [int(s.cuda_stream) for s in picked]
+        report["verdict"] = "vetted"
+        return picked, report
+    report["verdict"] = f"only {len(picked)} of {count} vetted: single stream"
+    return None, report
 
 
 class PWCDCNet(object):
@@ -119,6 +141,8 @@ class PWCDCNet(object):
         # (per-kernel timings -- profilers, HIP events on the caller's stream -- need the single-stream form).
         self.streams = None if streams is None else max(1, int(streams))
         self._side_streams = {}
+        self.side_stream_report = None      # what _pick_side_streams decided the last time it ran (dict), for logs / bench
+        self._warm = set()                  # (sub-batch shape, device, weight version) whose weights are packed
 
     # ------------------------------------------------------------------ variables
     @property
@@ -171,17 +195,28 @@ class PWCDCNet(object):
         """(flows_final, flows_pyramid[, pyramid_0]) as reference model.py:95-134.  The returned
         tensors are new on every call unless the model was built with persistent_outputs=True
         (then they are the launch plan's own tensors, overwritten by the next call of that shape)."""
-        n_batch = getattr(images_0, "shape", (0,))[0]
-        k = self.streams
-        if k is None:       # even batches; a batch of 2 only at sizes where a single pair fills the GPU (+5 % at 448x1024)
-            hw = (images_0.shape[1] * images_0.shape[2]) if getattr(images_0, "ndim", 0) == 4 else 0
-            k = 2 if (n_batch % 2 == 0 and (n_batch >= 4 or (n_batch == 2 and hw >= 256 * 512))) else 1
+        k = self.effective_streams(getattr(images_0, "shape", (0, 0, 0, 0)))
         if k > 1:
             self.max_plans = max(self.max_plans, k + 1)     # a plan per sub-batch stream + the whole-batch one
         if (k > 1 and self.use_plans and not self.persistent_outputs and not with_features and _m._RECORDER is None
-                and getattr(images_0, "shape", (0,))[0] % k == 0 and images_0.shape[0] >= k):
-            return self._call_on_side_streams(images_0, images_1, k)
+                and not torch.cuda.is_current_stream_capturing()):
+            out = self._call_on_side_streams(images_0, images_1, k)
+            if out is not None:
+                return out
         return self._call_one(images_0, images_1, with_features)
+
+    def effective_streams(self, shape):
+        """Number of sub-batches a batch of this (N, H, W, 3) shape is run as: `streams` if given (and dividing N), else
+        2 for even batches of at least 4 pairs (and for 2 pairs of at least 256x512 pixels), else 1.  (The forward still
+        falls back to 1 when no side stream on a hardware queue of its own exists: side_stream_report.)"""
+        n_batch = int(shape[0]) if len(shape) >= 1 else 0
+        k = self.streams
+        if k is None:       # a batch of 2 only at sizes where a single pair fills the GPU (+5 % at 448x1024)
+            hw = int(shape[1]) * int(shape[2]) if len(shape) == 4 else 0
+            k = 2 if (n_batch % 2 == 0 and (n_batch >= 4 or (n_batch == 2 and hw >= 256 * 512))) else 1
+        if k > 1 and (n_batch % k != 0 or n_batch < k):
+            k = 1
+        return k
 
     def _call_on_side_streams(self, images_0, images_1, k):
         _, images_0 = as_view(images_0, "images_0")
@@ -191,14 +226,28 @@ class PWCDCNet(object):
         n = N // k
         main = torch.cuda.current_stream(dev)
         skey = (str(dev), main.cuda_stream)
-        streams = self._side_streams.get(skey)
-        if streams is None or len(streams) != k - 1:
+        if skey not in self._side_streams:
             while len(self._side_streams) >= 4:              # callers that come with a new stream every time
                 self._side_streams.pop(next(iter(self._side_streams)))
-            streams = self._side_streams[skey] = _pick_side_streams(dev, main, k - 1)
+            picked, self.side_stream_report = _pick_side_streams(dev, main, k - 1)
+            self._side_streams[skey] = picked
+        streams = self._side_streams[skey]
+        if streams is None or len(streams) != k - 1:
+            return None                                      # no vetted side stream: the caller runs single-stream
         final = torch.empty((N, H, W, 2), dtype=torch.float32, device=dev)
         pyr = [torch.empty((N, H >> (self.num_levels - l), W >> (self.num_levels - l), 2), dtype=torch.float32, device=dev)
                for l in range(self.output_level + 1)]
+        # First call of a (sub-batch shape, weight version): sub-batch 0 runs FIRST and alone, on the caller's stream.  It packs
+        # every layer's weights there (the per-module caches are filled by whoever launches a layer first, with no event
+        # between the pack kernel and a consumer on another stream) and owns the packed tensors' allocator blocks; the
+        # side streams start behind it.
+        wkey = ((n, H, W), str(dev), self.store.version)
+        first = wkey not in self._warm
+        if first:
+            self._call_one(images_0[:n], images_1[:n], False, into=(final[:n], [p[:n] for p in pyr]))
+            if len(self._warm) > 64:
+                self._warm.clear()
+            self._warm.add(wkey)
         # sub-batch 0 runs on the caller's stream itself (no event in its way), the others on side streams that start when
         # the caller's stream has reached this point and that the caller's stream waits for at the end.  The side streams'
         # launches are issued first: they are the ones that still have an event to wait for.
@@ -213,7 +262,8 @@ class PWCDCNet(object):
             done = torch.cuda.Event()
             done.record(st)
             dones.append(done)
-        self._call_one(images_0[:n], images_1[:n], False, into=(final[:n], [p[:n] for p in pyr]))
+        if not first:
+            self._call_one(images_0[:n], images_1[:n], False, into=(final[:n], [p[:n] for p in pyr]))
         for done in dones:
             main.wait_event(done)
         return final, pyr

@@ -3,8 +3,10 @@ import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import pwcnet_amd
 from pwcnet_amd import weights as W
-net = pwcnet_amd.PWCDCNet(); net.load_weights(W.init_weights(W.conv_specs(), seed=0))
-im0 = torch.rand((8, 448, 1024, 3), device="cuda"); im1 = torch.rand((8, 448, 1024, 3), device="cuda")
+net = pwcnet_amd.PWCDCNet(streams=1); net.load_weights(W.init_weights(W.conv_specs(), seed=0))
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+im0 = torch.rand((B, 448, 1024, 3), device="cuda"); im1 = torch.rand((B, 448, 1024, 3), device="cuda")
+print("batch", B)
 for _ in range(3): net(im0, im1)
 torch.cuda.synchronize()
 plan = list(net._plans.values())[0]
@@ -19,7 +21,7 @@ g = torch.cuda.CUDAGraph()
 s = torch.cuda.Stream()
 try:
     with torch.cuda.stream(s):
-        net2 = pwcnet_amd.PWCDCNet(); net2.load_weights(W.init_weights(W.conv_specs(), seed=0))
+        net2 = pwcnet_amd.PWCDCNet(streams=1, persistent_outputs=True); net2.load_weights(W.init_weights(W.conv_specs(), seed=0))
         for _ in range(2): net2(im0, im1)
         torch.cuda.synchronize()
         with torch.cuda.graph(g, stream=s):

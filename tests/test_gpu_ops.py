@@ -207,6 +207,22 @@ def test_conv_winograd_f4x4_vs_oracle(pa, N, H, W, cin, cout, dil):
     assert float(y[..., cout:].min()) == -7.0 and float(y[..., cout:].max()) == -7.0
 
 
+@pytest.mark.parametrize("cin,cout,dil", [(160, 128, 1), (128, 128, 4)])
+def test_conv_winograd_f4x4_full_size_vs_oracle(pa, cin, cout, dil):
+    """pwc_conv3x3_wino4_f32 at the PRODUCTION shape (8 x 112 x 256: 7168 - 8192 workgroups, XCD remap,
+    two workgroups per CU) against the oracle's convolution on two sampled images of the batch (first and last), every
+    entry.  The other six images are checked for finiteness and for the untouched channels behind Cout."""
+    N, H, W = 8, 112, 256
+    x = rnd((N, H, W, cin), 181)
+    k = rnd((3, 3, cin, cout), 182) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 183) * 0.1
+    y = run_conv_wino4(x, k, b, 0.1, y_cs=cout + 16, dil=dil)
+    for i in (0, N - 1):
+        close(y[i:i + 1, ..., :cout], orc.conv3x3(x[i:i + 1], k, b, 1, dil, 0.1), rel=2e-5)
+    assert bool(torch.isfinite(y).all())
+    assert float(y[..., cout:].min()) == -7.0 and float(y[..., cout:].max()) == -7.0
+
+
 def test_conv_winograd_f4x4_physical_layout_and_plan(pa):
     """Padded / permuted physical input channels through cin_map (the estimator buffers), and the shapes the model routes
     to F(4x4): the big level-4 layers of a batch, not single pairs or the small levels."""
@@ -765,6 +781,22 @@ def test_concat_cost_volume_full_size_vs_separate_launches(pa):
     assert float((E[..., :81] - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
     assert torch.equal(E[..., 84:116], f0) and float(E[..., 81:84].abs().max()) == 0.0
     assert float(E[..., 116:].abs().max()) == 0.0
+
+
+def test_concat_cost_volume_full_size_vs_oracle(pa):
+    """the one-launch kernel at BASELINE configs[1]'s level-4 geometry (8 x 112 x 256 x 32) against
+    orc.cost_volume(orc.warp(...)) DIRECTLY (not against other HIP launches), images 0 and 7, every entry; flows ~ N(0, 3^2)
+    px with far outliers."""
+    N, H, W, C = 8, 112, 256, 32
+    f0, f1 = rnd((N, H, W, C), 91), rnd((N, H, W, C), 92)
+    flow = (np.random.RandomState(93).randn(N, H, W, 2) * (3.0 / 5.0)).astype(np.float32)
+    flow[0, 0, 0], flow[7, 111, 255, 0], flow[7, 50, 100] = (60.0, -60.0), -45.0, (11.3, 7.7)
+    E, g0 = _run_concat(pa, f0, f1, flow, 5.0, 160, True, True, fill=0.0)
+    for i in (0, N - 1):
+        f1w = orc.warp(f1[i:i + 1], flow[i:i + 1], "bilinear", flow_scale=5.0)
+        close(E[i:i + 1, ..., :81], orc.cost_volume(f0[i:i + 1], f1w, 4), rel=4e-6, floor=4e-7)
+    assert torch.equal(E[..., 84:84 + C], g0) and float(E[..., 81:84].abs().max()) == 0.0
+    assert float(E[..., 84 + C:].abs().max()) == 0.0 and bool(torch.isfinite(E).all())
 
 
 def test_concat_cost_volume_rejects_what_it_does_not_support(pa):
