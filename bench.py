@@ -400,7 +400,11 @@ def main():
             fam = t["kernels"].get(dominant.split("<")[0])
             if fam:
                 roof["traffic"] = fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"]
-                roof["traffic_unit"] = "bytes per launch (mean over the kernel's launches)"
+                roof["traffic_unit"] = "bytes per launch (mean over the kernel's launches, each a whole batch)"
+                roof["traffic_read"] = fam["hbm_read_bytes_per_launch"]
+                roof["traffic_write"] = fam["hbm_write_bytes_per_launch"]
+                roof["algorithmic_bytes_per_launch"] = dd["bytes"] / dd["launches"]     # input + weights + output, once each
+                roof["traffic_over_algorithmic"] = roof["traffic"] / max(1.0, roof["algorithmic_bytes_per_launch"])
                 roof["traffic_source"] = "profiles/pmc_traffic.json: " + t["source"]
             busy = t.get("mfma_busy", {}).get(dominant.split("<")[0])
             if busy:
