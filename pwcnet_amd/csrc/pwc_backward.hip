@@ -311,8 +311,16 @@ __global__ __launch_bounds__(256) void warp_grad_kernel(const WarpGradArgs a) {
             for (int i = 0; i < 4; ++i) { gx_sum += g[i] * dfx[i]; gy_sum += g[i] * dfy[i]; }
             if (a.fix) {
                 // 2^36 steps per unit: |sum| < 1.3e8 representable, 1.5e-11 resolution (fp32 gradients carry ~1e-7 relative)
+                // Range of the fixed point: contributions below 1.5e-11 vanish, sums beyond +-1.3e8 would wrap, and
+                // __float2ll_rn maps NaN to 0 / saturates Inf -- a diverging step must not come out finite: a
+                // contribution that is not finite or reaches 2^26 raises the poison word behind the sums, and the finish
+                // kernel then writes NaN to every dx it owns (what fp32 atomics would have produced downstream).
                 constexpr float FIX = 68719476736.f;
                 unsigned long long* f = reinterpret_cast<unsigned long long*>(a.fix);
+                {
+                    const float gm = fmaxf(fmaxf(fabsf(g[0]), fabsf(g[1])), fmaxf(fabsf(g[2]), fabsf(g[3])));
+                    if (!(gm < 67108864.f)) atomicOr(f + (long)a.N * a.H * a.W * a.C, 1ull);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     atomicAdd(f + o00 * a.C + c + i, (unsigned long long)__float2ll_rn(wy0 * wx0 * g[i] * FIX));
@@ -349,10 +357,11 @@ __global__ __launch_bounds__(256) void warp_grad_kernel(const WarpGradArgs a) {
 __global__ __launch_bounds__(256) void warp_grad_fix_finish_kernel(const long long* __restrict__ fix, float* __restrict__ dx,
                                                                    int dx_cs, long npix, int C) {
     const long total = npix * C;
+    const bool poisoned = fix[total] != 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long p = i / C;
         const int c = (int)(i - p * C);
-        dx[p * dx_cs + c] += (float)((double)fix[i] * (1.0 / 68719476736.0));
+        dx[p * dx_cs + c] += poisoned ? __builtin_nanf("") : (float)((double)fix[i] * (1.0 / 68719476736.0));
     }
 }
 
@@ -362,7 +371,7 @@ static int warp_grad_run(const float* x, int x_cs, const float* flow, int flow_c
 
 extern "C" size_t pwc_warp_bilinear_grad_workspace_bytes(int N, int H, int W, int C) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
-    return (size_t)N * H * W * C * sizeof(long long);
+    return ((size_t)N * H * W * C + 1) * sizeof(long long);     // + one word: "a contribution was not representable"
 }
 
 extern "C" int pwc_warp_bilinear_grad_det_f32(const float* x, int x_cs, const float* flow, int flow_cs, float flow_scale,
@@ -396,7 +405,10 @@ static int warp_grad_run(const float* x, int x_cs, const float* flow, int flow_c
     const long npix = (long)N * H * W;
     const long blocks = (npix + 31) / 32;
     if (blocks >= (1L << 31)) return PWC_ERANGE;
-    if (fix && hipMemsetAsync(fix, 0, (size_t)npix * C * sizeof(long long), (hipStream_t)stream) != hipSuccess) return pwc_launch_status();
+    if (fix) {
+        const hipError_t me = hipMemsetAsync(fix, 0, ((size_t)npix * C + 1) * sizeof(long long), (hipStream_t)stream);
+        if (me != hipSuccess) { (void)hipGetLastError(); return (int)me; }      // the memset's OWN error, never PWC_OK
+    }
     hipLaunchKernelGGL(warp_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     if (fix) {
         long fb = (npix * C + 255) / 256;

@@ -81,15 +81,20 @@ _WARP_WS = {}
 
 def warp_grad(x, flow, flow_scale, dy, dx=None, dflow=None, dflow_accumulate=False, deterministic=True):
     """Gradient of the bilinear warp: dx += corner scatter, dflow (+)= ... (both optional Views).
-    deterministic (default): the scatter adds 64-bit fixed-point integers in a per-(device, stream) workspace, so the
-    result does not depend on the order of the atomics (bit-reproducible training steps); False: fp32 atomics."""
+    deterministic (default): the scatter adds 64-bit fixed-point integers (2^-36 steps: contributions below 1.5e-11 vanish,
+    |sums| up to 1.3e8) in a per-(device, stream) workspace, so the result does not depend on the order of the atomics
+    (bit-reproducible training steps); a non-finite or out-of-range contribution makes the whole dx NaN instead of
+    silently finite.  False: fp32 atomics (relative precision, order-dependent)."""
     L = _L()
     if deterministic and dx is not None:
         need = L.pwc_warp_bilinear_grad_workspace_bytes(x.N, x.H, x.W, x.C)
-        key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+        dev = torch.cuda.current_device()        # Views carry raw pointers: the tensors live on the current device by contract
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
         ws = _WARP_WS.get(key)
         if ws is None or ws.numel() * 8 < need:
-            ws = _WARP_WS[key] = torch.empty(((need + 7) // 8,), dtype=torch.int64, device="cuda")
+            while len(_WARP_WS) >= 8:            # bounded: callers that come with a new stream every time
+                _WARP_WS.pop(next(iter(_WARP_WS)))
+            ws = _WARP_WS[key] = torch.empty(((need + 7) // 8,), dtype=torch.int64, device=torch.device("cuda", dev))
         _lib.check(L.pwc_warp_bilinear_grad_det_f32(
             _p(x.ptr), x.cs, _p(flow.ptr), flow.cs, float(flow_scale), _p(dy.ptr), dy.cs, _p(dx.ptr), dx.cs,
             _p(dflow.ptr) if dflow is not None else None, dflow.cs if dflow is not None else 0,

@@ -130,6 +130,26 @@ def test_warp_grad_is_bit_reproducible(go):
     close(dxa, xt.grad, rel=1e-5)
 
 
+def test_warp_grad_deterministic_form_does_not_hide_divergence(go):
+    """the fixed-point scatter maps NaN to 0 and saturates Inf -- a non-finite (or > 2^26) upstream gradient
+    must come out as NaN in dx, not as finite numbers."""
+    N, H, W, C = 1, 12, 20, 8
+    rs = np.random.RandomState(3)
+    x, dy = rs.randn(N, H, W, C).astype(np.float32), rs.randn(N, H, W, C).astype(np.float32)
+    fl = (rs.randn(N, H, W, 2) * 2).astype(np.float32)
+    for bad in (np.nan, np.inf, 1e9):
+        d = dy.copy(); d[0, 5, 7, 3] = bad
+        gx, gfl, gdy = gpu(x), gpu(fl), gpu(d)
+        dx = torch.zeros((N, H, W, C), device="cuda")
+        go.warp_grad(V(gx), V(gfl), 1.0, V(gdy), V(dx), None)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(dx).all()), bad
+    gx, gfl, gdy = gpu(x), gpu(fl), gpu(dy)
+    dx = torch.zeros((N, H, W, C), device="cuda")
+    go.warp_grad(V(gx), V(gfl), 1.0, V(gdy), V(dx), None)
+    assert bool(torch.isfinite(dx).all())
+
+
 def test_train_step_is_bit_reproducible():
     """Two trainers from the same weights on the same batch: identical losses and identical parameters after 3 steps
     (fixed-order reductions everywhere, integer atomics in the warp gradient)."""
