@@ -318,8 +318,9 @@ __global__ __launch_bounds__(256) void warp_grad_kernel(const WarpGradArgs a) {
                 constexpr float FIX = 68719476736.f;
                 unsigned long long* f = reinterpret_cast<unsigned long long*>(a.fix);
                 {
-                    const float gm = fmaxf(fmaxf(fabsf(g[0]), fabsf(g[1])), fmaxf(fabsf(g[2]), fabsf(g[3])));
-                    if (!(gm < 67108864.f)) atomicOr(f + (long)a.N * a.H * a.W * a.C, 1ull);
+                    const bool ok = (fabsf(g[0]) < 67108864.f) & (fabsf(g[1]) < 67108864.f) & (fabsf(g[2]) < 67108864.f) &
+                                    (fabsf(g[3]) < 67108864.f);            // (every comparison is false for a NaN)
+                    if (!ok) atomicOr(f + (long)a.N * a.H * a.W * a.C, 1ull);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
