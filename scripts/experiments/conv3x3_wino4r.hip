@@ -11,18 +11,20 @@
 // profiles/r04_exp_cross_simd.txt: MFMA waves on SIMDs 1-3 beside a VALU / ds_write wave on SIMD 0 take the MAX).  So:
 //
 //   workgroup = 512 threads = 8 waves, one per CU: 4 x 8 Winograd tiles (16 x 32 output pixels) x 32 output channels.
-//   Waves 0 and 4 (one SIMD: a workgroup's waves go round the four SIMDs) are PRODUCERS: wave g = tile rows 2g, 2g+1;
-//     lane (tile j = lane & 15, k-slot q = lane >> 4) reads the 6 x 6 input pixels of its tile for channels 4q..4q+3 from
-//     the raw patch in LDS (conv3x3_wino4.hip's image), transforms all 36 positions in registers ONCE per workgroup
-//     (the 16-cout kernel: 8 times per 128 couts) and publishes V[position][tile group] -- 1 KB each, already in
-//     B-fragment order -- to LDS, 12 positions (two rows a) per phase, one phase ahead of their use.  They also issue
+//   Every SIMD hosts ONE producer and ONE consumer wave (a workgroup's waves go round the four SIMDs: waves w and w + 4
+//   share one):
+//   Waves 0..3 are PRODUCERS: wave = (tile group g = tile rows 2g, 2g+1; row half ah = rows a = 3ah .. 3ah+2 of the 6 x 6
+//     transformed tile).  Lane (tile j = lane & 15, k-slot q = lane >> 4) reads the 6 x 6 input pixels of its tile for
+//     channels 4q..4q+3 from the raw patch in LDS (conv3x3_wino4.hip's image), forms its three rows of  B^T d B  (row
+//     pass for 3 rows, column pass for all 6 columns: 84 f32x4 operations -- ONCE per workgroup = per 32 couts; the
+//     16-cout kernel does it once per 16 couts on every wave) and publishes V[position][tile group] -- 1 KB each, already in
+//     B-fragment order -- to LDS, one row (6 positions) per phase, one phase ahead of its use.  The producers also issue
 //     every fetch (buffer_load ... lds) of the workgroup.
-//   The six other waves (SIMDs of waves 1, 2, 3) are CONSUMERS: wave c owns positions 12 p + 2c, 12 p + 2c + 1 of each
-//     part p (6 of the 36) for both tile groups and both 16-cout tiles: 24 accumulator tiles = 96 registers.  Per position
-//     and 16-channel stage: 4 ds_read_b128 (two weight fragments, two V fragments: 4 k-steps each) feed 16
-//     v_mfma_f32_16x16x4_f32 -- nothing else is issued on these SIMDs.
-//   A phase = one part (12 positions) of a 16-channel stage; one s_barrier per phase.  LDS: patch 42 KB (single buffer,
-//   read by the producers only), weights 2 x 24 KB and V 2 x 24 KB rings of parts.
+//   Waves 4..7 are CONSUMERS: wave c owns 3 of the 12 positions of each part (9 of the 36) for both tile groups and both
+//     16-cout tiles: 36 accumulator tiles = 144 registers.  Per position and 16-channel stage: 4 ds_read_b128 (two weight
+//     fragments, two V fragments: 4 k-steps each) feed 16 v_mfma_f32_16x16x4_f32 -- nothing else is issued by these waves.
+//   A phase = one part p (rows a = p and p + 3: 12 positions) of a 16-channel stage; one s_barrier per phase.  LDS: patch
+//   42 KB (single buffer, read by the producers only), weights 2 x 24 KB and V 2 x 24 KB rings of parts.
 //   Epilogue: the accumulators go through LDS once (144 KB, M[position][tile group][cout tile]), then all 8 waves apply
 //   A^T M A, bias and leaky-relu to (tile, 4 couts) units and store.
 #pragma once
@@ -48,11 +50,11 @@ constexpr unsigned WR_OOB = 0x7FFF0000u;
 constexpr int WR_NW = 8, WR_T = 64 * WR_NW;
 constexpr int WR_PS = 36;                    // patch records per patch row (conv3x3_wino4.hip's image)
 constexpr int WR_PH = 18, WR_PW = 34;
-constexpr int WR_PPW = 21;                   // patch DMA pieces per PRODUCER wave and stage: 42 requests for the 41 blocks
+constexpr int WR_PPW = 11;                   // patch DMA pieces per PRODUCER wave and stage: 44 requests for the 41 blocks
 constexpr int WR_NBP = 42;                   // 41 blocks + block 41 that swallows the surplus (out-of-range) request
 constexpr int WR_PATCH_BYTES = WR_NBP * 1024;
 constexpr int WR_PART = 12 * 2048;           // bytes of a part of the weights (12 positions x 2 cout tiles x 1 KB) = of a part of V
-constexpr int WR_UPW = 12;                   // weight DMA pieces per producer wave and part
+constexpr int WR_UPW = 6;                    // weight DMA pieces per producer wave and part
 constexpr int WR_U0 = WR_PATCH_BYTES;        // two weight slots
 constexpr int WR_V0 = WR_U0 + 2 * WR_PART;   // two V slots
 constexpr int WR_MAIN = WR_V0 + 2 * WR_PART; // 141 312 B
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(WR_T, 2) void conv3x3_wino4r_kernel(const Wino4rArg
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const bool producer = (wave & 3) == 0;
+    const bool producer = wave < 4;
     const int fr = lane & 15, fq = lane >> 4;
     float m1s;
     asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(m1s));   // -1.0f the optimiser cannot see through (see conv3x3_wino.hip)
@@ -113,31 +115,34 @@ __global__ __launch_bounds__(WR_T, 2) void conv3x3_wino4r_kernel(const Wino4rArg
     };
 
     if (producer) {
-        // =========================================================== producers: waves 0 and 4 = tile groups 0 and 1
-        const int g = wave >> 2;
+        // =========================================================== producers: waves 0..3 = (tile group, row half), one per SIMD
+        const int g = wave & 1, ah = wave >> 1;
         const int trl = fr >> 3, tc = fr & 7;       // tile (2g + trl, tc)
         const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.x + (size_t)n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)a.up, 0, nc16 * a.ncb * 36 * 2048, 0x00020000);
-        // patch fetch: blocks g, g + 2, ... of 16 records x 64 bytes.  The per-lane byte offsets are recomputed at every issue
-        // (21 registers the transform needs; this SIMD has the time)
+        // patch fetch: blocks wave, wave + 4, ... of 16 records x 64 bytes; per-lane byte offsets fixed over the channel loop
+        unsigned p_voff[WR_PPW];
+#pragma unroll
+        for (int i = 0; i < WR_PPW; ++i) {
+            const int rec = (wave + 4 * i) * 16 + (lane >> 2);
+            const int py = rec / WR_PS, rem = rec - py * WR_PS;
+            const int q = rem / 9, ci = rem - q * 9;
+            const int px = 4 * ci + q;
+            const int yy = ry + d * (y0 - 1 + py), xx = rx + d * (x0 - 1 + px);
+            const int ch = (lane & 3) ^ wr_pswz(py);                       // source chunk for this LDS slot
+            const bool ok = py < WR_PH && px < WR_PW && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            p_voff[i] = ok ? (unsigned)(((yy * a.W + xx) * a.x_cs + ch * 4) * 4) : WR_OOB;
+        }
         auto issue_patch = [&](int c16) {
 #pragma unroll
-            for (int i = 0; i < WR_PPW; ++i) {
-                const int rec = (g + 2 * i) * 16 + (lane >> 2);
-                const int py = rec / WR_PS, rem = rec - py * WR_PS;
-                const int q = rem / 9, ci = rem - q * 9;
-                const int px = 4 * ci + q;
-                const int yy = ry + d * (y0 - 1 + py), xx = rx + d * (x0 - 1 + px);
-                const int ch = (lane & 3) ^ wr_pswz(py);                       // source chunk for this LDS slot
-                const bool ok = py < WR_PH && px < WR_PW && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-                const unsigned voff = ok ? (unsigned)(((yy * a.W + xx) * a.x_cs + ch * 4) * 4) : WR_OOB;
+            for (int i = 0; i < WR_PPW; ++i)
                 if (!(ABL & 1))
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(sm + (g + 2 * i) * 1024), 16, (int)voff, c16 * 64, 0, 0);
-            }
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        xrsrc, (lptr_t)(sm + (wave + 4 * i < WR_NBP - 1 ? wave + 4 * i : WR_NBP - 1) * 1024), 16, (int)p_voff[i], c16 * 64, 0, 0);
         };
-        // weights: part k = 3 c + p is 24 KB contiguous in the packed image; pieces g, g + 2, ...; everything but the
+        // weights: part k = 3 c + p is 24 KB contiguous in the packed image; pieces wave, wave + 4, ...; everything but the
         // lane's 16 bytes is wave-uniform (scalar offset)
         const unsigned u_lane = (unsigned)lane * 16u;
         auto issue_u = [&](int k) {
@@ -147,8 +152,8 @@ __global__ __launch_bounds__(WR_T, 2) void conv3x3_wino4r_kernel(const Wino4rArg
 #pragma unroll
             for (int j = 0; j < WR_UPW; ++j)
                 if (!(ABL & 2))
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lptr_t)(dst + (g + 2 * j) * 1024), 16, (int)u_lane,
-                                                             sbase + (g + 2 * j) * 1024, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lptr_t)(dst + (wave + 4 * j) * 1024), 16, (int)u_lane,
+                                                             sbase + (wave + 4 * j) * 1024, 0, 0);
         };
         // this lane's patch reads (conv3x3_wino4.hip): record (4 trow + i) * 36 + (j & 3) * 9 + (j >> 2) + tc, chunk
         // fq ^ pswz(py); pswz flips between window rows i < 4 and i >= 4
@@ -156,87 +161,113 @@ __global__ __launch_bounds__(WR_T, 2) void conv3x3_wino4r_kernel(const Wino4rArg
         const float* pb_lo = smem + ((4 * trow) * WR_PS + tc) * 16 + ((fq ^ wr_pswz(4 * trow)) << 2);
         const float* pb_hi = smem + ((4 * trow) * WR_PS + tc) * 16 + ((fq ^ wr_pswz(4 * trow + 4)) << 2);
 
-        f32x4 V[6][6];
+        f32x4 V[3][6];
         // B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-        auto six = [&](const f32x4 e0, const f32x4 e1, const f32x4 e2, const f32x4 e3, const f32x4 e4, const f32x4 e5, f32x4 (&o)[6]) {
-            if (ABL & 64) { o[0] = e0; o[1] = e1; o[2] = e2; o[3] = e3; o[4] = e4; o[5] = e5; return; }
-            const f32x4 s = e1 + e2, tt = e3 + e4, u = WRSUB(e1, e2), v = WRSUB(e4, e3);
-            const f32x4 p = WRSUB(e4, e2), q = WRSUB(e3, e1);
-            o[0] = WRFMA(e0, 4.f, WRFMA(e2, -5.f, e4));
-            o[1] = WRFMA(s, -4.f, tt);
-            o[2] = WRFMA(u, 4.f, v);
-            o[3] = WRFMA(q, 2.f, p);
-            o[4] = WRFMA(q, -2.f, p);
-            o[5] = WRFMA(e1, 4.f, WRFMA(e3, -5.f, e5));
-        };
-        auto transform = [&]() {
+        f32x4 Wn[3][6];                              // row-pass results of the NEXT stage (V still holds this stage's rows)
+        auto rowpass = [&](int j0, int j1) {         // columns j0 .. j1-1 of the window: this wave's rows a = 3ah .. 3ah+2 of B^T d
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {            // row pass, column j of the window
-                f32x4 dd[6], o[6];
+            for (int j = 0; j < 6; ++j) {
+                if (j < j0 || j >= j1) continue;
+                f32x4 dd[6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
                     dd[i] = *reinterpret_cast<const f32x4*>((i < 4 ? pb_lo : pb_hi) + (i * WR_PS + (j & 3) * 9 + (j >> 2)) * 16);
-                six(dd[0], dd[1], dd[2], dd[3], dd[4], dd[5], o);
+                if (ABL & 64) {
+                    Wn[0][j] = dd[0] + dd[3]; Wn[1][j] = dd[1] + dd[4]; Wn[2][j] = dd[2] + dd[5];
+                } else if (ah == 0) {
+                    Wn[0][j] = WRFMA(dd[0], 4.f, WRFMA(dd[2], -5.f, dd[4]));
+                    const f32x4 s = dd[1] + dd[2], tt = dd[3] + dd[4], u = WRSUB(dd[1], dd[2]), v = WRSUB(dd[4], dd[3]);
+                    Wn[1][j] = WRFMA(s, -4.f, tt);
+                    Wn[2][j] = WRFMA(u, 4.f, v);
+                } else {
+                    const f32x4 p = WRSUB(dd[4], dd[2]), q = WRSUB(dd[3], dd[1]);
+                    Wn[0][j] = WRFMA(q, 2.f, p);
+                    Wn[1][j] = WRFMA(q, -2.f, p);
+                    Wn[2][j] = WRFMA(dd[1], 4.f, WRFMA(dd[3], -5.f, dd[5]));
+                }
 #pragma unroll
-                for (int r = 0; r < 6; ++r) { V[r][j] = o[r]; asm("" : "+v"(V[r][j])); }   // keep the packed ops
-            }
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {            // column pass, in place
-                f32x4 o[6];
-                six(V[r][0], V[r][1], V[r][2], V[r][3], V[r][4], V[r][5], o);
-#pragma unroll
-                for (int j = 0; j < 6; ++j) { V[r][j] = o[j]; asm("" : "+v"(V[r][j])); }
+                for (int r = 0; r < 3; ++r) asm("" : "+v"(Wn[r][j]));         // keep the packed ops (see conv3x3_wino.hip)
             }
         };
-        auto publish = [&](int k) {                  // part k = 3 c + p: rows a = 2p, 2p+1 -> V slot k & 1, [position][tile group]
-            const int p = k % 3;
-            char* const dst = sm + WR_V0 + (k & 1) * WR_PART + g * 1024 + lane * 16;
+        auto colpass = [&]() {                       // V = (rows of B^T d) B, all six columns b
 #pragma unroll
-            for (int pp = 0; pp < 3; ++pp)
-                if (pp == p) {
-#pragma unroll
-                    for (int e = 0; e < 12; ++e) *reinterpret_cast<f32x4*>(dst + e * 2048) = V[2 * pp + e / 6][e % 6];
+            for (int r = 0; r < 3; ++r) {
+                const f32x4 e0 = Wn[r][0], e1 = Wn[r][1], e2 = Wn[r][2], e3 = Wn[r][3], e4 = Wn[r][4], e5 = Wn[r][5];
+                if (ABL & 64) {
+                    V[r][0] = e0; V[r][1] = e1; V[r][2] = e2; V[r][3] = e3; V[r][4] = e4; V[r][5] = e5;
+                } else {
+                    const f32x4 s = e1 + e2, tt = e3 + e4, u = WRSUB(e1, e2), v = WRSUB(e4, e3);
+                    const f32x4 p = WRSUB(e4, e2), q = WRSUB(e3, e1);
+                    V[r][0] = WRFMA(e0, 4.f, WRFMA(e2, -5.f, e4));
+                    V[r][1] = WRFMA(s, -4.f, tt);
+                    V[r][2] = WRFMA(u, 4.f, v);
+                    V[r][3] = WRFMA(q, 2.f, p);
+                    V[r][4] = WRFMA(q, -2.f, p);
+                    V[r][5] = WRFMA(e1, 4.f, WRFMA(e3, -5.f, e5));
                 }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) asm("" : "+v"(V[r][j]));
+            }
+        };
+        auto publish_row = [&](auto pc, int k) {     // part k = 3 c + p: this wave's row a = 3ah + p -> V slot k & 1, entries 6ah + b
+            constexpr int PP = decltype(pc)::value;  // (compile-time row: V must stay in registers)
+            char* const dst = sm + WR_V0 + (k & 1) * WR_PART + (6 * ah) * 2048 + g * 1024 + lane * 16;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) *reinterpret_cast<f32x4*>(dst + b * 2048) = V[PP][b];
         };
         // ---- prologue: patch(0), weight part 0 -> transform stage 0, publish part 0
         issue_patch(0);
         issue_u(0);
         WR_WAIT_VM(WR_UPW);                          // patch(0) landed (this wave's pieces)
-        WR_BAR();                                    // B0: ... both producers' pieces
-        transform();
-        publish(0);
+        WR_BAR();                                    // B0: ... every producer's pieces
+        rowpass(0, 6);
+        colpass();
+        publish_row(std::integral_constant<int, 0>{}, 0);
         WR_WAIT_VM(0);                               // weight part 0 landed
-        for (int k = 0; k < nphase; ++k) {
-            const int c16 = k / 3, p = k - 3 * c16;
+        // A phase with its part index as a compile-time constant (V stays in registers: a run-time row selection made hipcc
+        // keep V in SCRATCH memory -- 512 us instead of 238).  Schedules measured on the 128 -> 128 layer at 8 x 112 x 256
+        // (profiles/r04_exp_wino4r_role_specialised.txt): whole transform in part 2 (this form) 237.8 us; row pass in part 1 and
+        // column pass in part 2: 242.7 us; row pass split over parts 0 and 1 with a second register image: 254.2 us -- a
+        // producer instruction issued while its SIMD's consumer has MFMAs queued waits for the 32-cycle MFMA in front of it,
+        // so spreading the producer's work makes every phase longer instead of shortening the long one.
+        auto phase = [&](auto pc, int c16) {
+            constexpr int P = decltype(pc)::value;
+            const int k = 3 * c16 + P;
             const bool has_next = c16 + 1 < nc16;
             stamp();
             WR_BAR();                                // top of phase k: part k of weights and V published; slots of part k-1 free
             stamp();
-            if (k + 1 < nphase) issue_u(k + 1);
-            if (p == 0 && has_next) issue_patch(c16 + 1);      // (the patch buffer was last read in phase (c-1, 2))
+            if (P < 2 || has_next) issue_u(k + 1);
+            if (P == 0 && has_next) issue_patch(c16 + 1);      // (the patch buffer was last read in phase (c-1, 2))
             stamp();
-            if (p < 2) {
-                publish(k + 1);
-                // fetches in flight (oldest first): p == 0: weights k+1, patch(c+1); p == 1: patch(c+1), weights k+1
-                if (p == 0) { if (has_next) WR_WAIT_VM(WR_PPW); else WR_WAIT_VM(0); }
+            if (P < 2) {
+                publish_row(std::integral_constant<int, (P + 1) % 3>{}, k + 1);
+                // fetches in flight (oldest first): P == 0: weights k+1, patch(c+1); P == 1: patch(c+1), weights k+1
+                if (P == 0) { if (has_next) WR_WAIT_VM(WR_PPW); else WR_WAIT_VM(0); }
                 else WR_WAIT_VM(0);                  // weights k+1 AND the next patch landed: the next phase transforms
             } else if (has_next) {
-                transform();                         // stage c+1 (patch(c+1) was published by the barrier above)
-                publish(k + 1);
+                rowpass(0, 6);                       // stage c+1 (patch(c+1) was published by the barrier above)
+                colpass();
+                publish_row(std::integral_constant<int, 0>{}, k + 1);
                 WR_WAIT_VM(0);
             }
             stamp();
+        };
+        for (int c16 = 0; c16 < nc16; ++c16) {
+            phase(std::integral_constant<int, 0>{}, c16);
+            phase(std::integral_constant<int, 1>{}, c16);
+            phase(std::integral_constant<int, 2>{}, c16);
         }
         stamp();
         WR_BAR();                                    // last phase read by every consumer
     } else {
-        // =========================================================== consumers: the six waves of the other three SIMDs
-        const int cj = (wave & 3) - 1 + 3 * (wave >> 2);        // 0..5
-        const char* const ubase = sm + WR_U0 + (2 * cj) * 2048 + lane * 16;
-        const char* const vbase = sm + WR_V0 + (2 * cj) * 2048 + lane * 16;
-        f32x4 acc[6][2][2];                          // [part p, position e][tile group][cout tile]
+        // =========================================================== consumers: waves 4..7, one per SIMD
+        const int cj = wave - 4;                     // positions e = 3 cj .. 3 cj + 2 of every part
+        const char* const ubase = sm + WR_U0 + (3 * cj) * 2048 + lane * 16;
+        const char* const vbase = sm + WR_V0 + (3 * cj) * 2048 + lane * 16;
+        f32x4 acc[9][2][2];                          // [3 p + i: part p, position 3 cj + i][tile group][cout tile]
 #pragma unroll
-        for (int pe = 0; pe < 6; ++pe)
+        for (int pe = 0; pe < 9; ++pe)
 #pragma unroll
             for (int tg = 0; tg < 2; ++tg) acc[pe][tg][0] = acc[pe][tg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         WR_BAR();                                    // B0
@@ -251,24 +282,27 @@ __global__ __launch_bounds__(WR_T, 2) void conv3x3_wino4r_kernel(const Wino4rArg
 #pragma unroll
             for (int pp = 0; pp < 3; ++pp)
                 if (pp == p) {
+                    f32x4 A0[3], A1[3], B0[3], B1[3];
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const f32x4 A0 = *reinterpret_cast<const f32x4*>(us + e * 2048);
-                        const f32x4 A1 = *reinterpret_cast<const f32x4*>(us + e * 2048 + 1024);
-                        const f32x4 B0 = *reinterpret_cast<const f32x4*>(vs + e * 2048);
-                        const f32x4 B1 = *reinterpret_cast<const f32x4*>(vs + e * 2048 + 1024);
+                    for (int e = 0; e < 3; ++e) {    // the twelve reads of the phase first: a consumer has no partner wave to hide them
+                        A0[e] = *reinterpret_cast<const f32x4*>(us + e * 2048);
+                        A1[e] = *reinterpret_cast<const f32x4*>(us + e * 2048 + 1024);
+                        B0[e] = *reinterpret_cast<const f32x4*>(vs + e * 2048);
+                        B1[e] = *reinterpret_cast<const f32x4*>(vs + e * 2048 + 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);       // (the scheduler would sink the reads behind the MFMAs of the position before)
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) {
+                    for (int e = 0; e < 3; ++e)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
 #pragma unroll
                             for (int tg = 0; tg < 2; ++tg)
 #pragma unroll
                                 for (int ct = 0; ct < 2; ++ct) {
-                                    f32x4& c = acc[2 * pp + e][tg][ct];
-                                    if (ABL & 4) { asm volatile("" ::"v"(A0), "v"(A1), "v"(B0), "v"(B1)); continue; }
-                                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(ct ? A1[s] : A0[s], tg ? B1[s] : B0[s], c, 0, 0, 0);
+                                    f32x4& c = acc[3 * pp + e][tg][ct];
+                                    if (ABL & 4) { asm volatile("" ::"v"(A0[e]), "v"(A1[e]), "v"(B0[e]), "v"(B1[e])); continue; }
+                                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(ct ? A1[e][s] : A0[e][s], tg ? B1[e][s] : B0[e][s], c, 0, 0, 0);
                                 }
-                        }
-                    }
                 }
             stamp();
         }
@@ -276,8 +310,9 @@ __global__ __launch_bounds__(WR_T, 2) void conv3x3_wino4r_kernel(const Wino4rArg
         WR_BAR();                                    // every wave is past its last read of the rings
         // ---- accumulators -> LDS: M[position 36][tile group 2][cout tile 2] x 1 KB (lane-contiguous 16 bytes)
 #pragma unroll
-        for (int pe = 0; pe < 6; ++pe) {
-            const int xi = 12 * (pe >> 1) + 2 * cj + (pe & 1);
+        for (int pe = 0; pe < 9; ++pe) {
+            const int e = 3 * cj + (pe % 3);         // entry of part p = pe / 3: rows a = p (e < 6) and p + 3
+            const int xi = e < 6 ? 6 * (pe / 3) + e : 6 * (pe / 3 + 3) + (e - 6);
 #pragma unroll
             for (int tg = 0; tg < 2; ++tg)
 #pragma unroll
@@ -345,8 +380,9 @@ __global__ __launch_bounds__(WR_T, 2) void conv3x3_wino4r_kernel(const Wino4rArg
 #undef WRFMA
 
 // ---------------------------------------------------------------- weight transform + packing
-// packed[c16][cout group][xi 36][cout tile 2][k-slot q 4][cout 16][4 channels 4q..4q+3]: U_xi = (G g G^T)[a][b], xi = 6a + b
-// (G as conv3x3_wino4.hip, double, rounded once); a part of 12 positions is 24 KB contiguous = the LDS image of a ring slot.
+// packed[c16][cout group][part 3][entry 12][cout tile 2][k-slot q 4][cout 16][4 channels 4q..4q+3]: part p holds the rows
+// a = p (entries 0..5: b) and a = p + 3 (entries 6..11) of U = G g G^T (G as conv3x3_wino4.hip, double, rounded once); a part is
+// 24 KB contiguous = the LDS image of a ring slot.
 __global__ void conv3x3_wino4r_pack_kernel(const float* __restrict__ w, const int32_t* __restrict__ cin_map, int Cin,
                                            int Cin_phys, int Cout, int ncb, float* __restrict__ packed) {
     const size_t total = (size_t)(Cin_phys >> 4) * ncb * 36 * 512;
@@ -359,10 +395,12 @@ __global__ void conv3x3_wino4r_pack_kernel(const float* __restrict__ w, const in
         const int q = (int)((idx >> 6) & 3);
         const int ct = (int)((idx >> 8) & 1);
         size_t r = idx >> 9;
-        const int xi = (int)(r % 36);
+        const int slot = (int)(r % 36);              // 12 * part + entry
         r /= 36;
         const int cg = (int)(r % ncb);
         const int c16 = (int)(r / ncb);
+        const int part = slot / 12, ent = slot % 12;
+        const int xi = ent < 6 ? 6 * part + ent : 6 * (part + 3) + (ent - 6);
         const int cphys = c16 * 16 + 4 * q + e;
         const int clog = cin_map ? cin_map[cphys] : (cphys < Cin ? cphys : -1);
         const int co = cg * 32 + ct * 16 + i;
