@@ -44,6 +44,22 @@ def test_library_exports_every_declared_symbol():
     assert L.pwc_conv3x3_f32(None, 16, None, None, None, 16, 1, 4, 4, 16, 16, 1, 1, 1, 0.1, -1, 0, None, 0, None) == -1
 
 
+def test_effective_streams_rule():
+    """PWCDCNet.effective_streams: the one place that decides into how many sub-batches a batch is cut (bench.py asks the model
+    instead of restating the rule).  Constructing the model needs the library, not a GPU... but its VariableStore allocates
+    on the device, so the rule is exercised on the unbound method with a stand-in object."""
+    import types
+    from pwcnet_amd.model import PWCDCNet
+    rule = PWCDCNet.effective_streams
+    auto = types.SimpleNamespace(streams=None)
+    assert rule(auto, (8, 448, 1024, 3)) == 2 and rule(auto, (4, 64, 128, 3)) == 2
+    assert rule(auto, (2, 448, 1024, 3)) == 2 and rule(auto, (2, 128, 192, 3)) == 1       # 2 pairs only when a pair fills the GPU
+    assert rule(auto, (1, 448, 1024, 3)) == 1 and rule(auto, (3, 448, 1024, 3)) == 1 and rule(auto, (7, 448, 1024, 3)) == 1
+    two, one, four = (types.SimpleNamespace(streams=k) for k in (2, 1, 4))
+    assert rule(two, (6, 64, 64, 3)) == 2 and rule(two, (5, 64, 64, 3)) == 1 and rule(one, (8, 448, 1024, 3)) == 1
+    assert rule(four, (8, 64, 64, 3)) == 4 and rule(four, (6, 64, 64, 3)) == 1 and rule(four, (2, 64, 64, 3)) == 1
+
+
 def test_product_never_imports_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "pwcnet_amd")):
         for f in files:
