@@ -343,6 +343,8 @@ def main():
             "parallelism": f"dp{world}: pairs sharded across ranks, no data-path collective"
                            + ("; RCCL all-gather of per-rank stats" if used_rccl else ""),
             "outputs": "persistent (plan-owned)" if args.persistent_outputs else "fresh tensors per call",
+            "gpus_from": ("--gpus" if getattr(args, "gpus_given", True) or not args.config
+                          else f"implied by --config {args.config}"),
             "streams": eff_streams,
             "side_streams": (None if ss_report is None else
                              {"verdict": ss_report.get("verdict"), "picked": len(ss_report.get("picked", [])),

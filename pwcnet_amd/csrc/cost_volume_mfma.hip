@@ -1,7 +1,7 @@
 // cost_volume_mfma.hip -- warp + cost volume (+ the f0 part of the estimator input's concat) in ONE launch,
-// correlation on the matrix pipe, for gfx950.  Search range 4, C = 32 / 64 / 96 / 128.
+// correlation on the matrix pipe, for gfx950.  Search range 4, C = 32 / 64 / 96 (C = 128 / 192, the two coarsest levels, stay on cost_volume_coarse_kernel: pwc_warp_cost_volume_concat_supported).
 //
-// Replaces, for pyramid levels with C % 32 == 0 (reference model.py:105-112, modules.py:99-137,158-204,264):
+// Replaces, for pyramid levels with C in {32, 64, 96} (reference model.py:105-112, modules.py:99-137,158-204,264):
 //
 //   f1w[n,y,x,:]             = bilinear_warp(f1, flow * flow_scale)          (never written to memory)
 //   out[n,y,x,(v+4)*9+(h+4)] = lrelu( (1/C) * sum_c f0[n,y,x,c] * f1w[n,y+v,x+h,c] ),  f1w zero outside
