@@ -1,0 +1,140 @@
+// Microbenchmark + correctness harness for scripts/experiments/conv3x3_h2.hip (direct 3x3 convolution on the F16 matrix pipe
+// with scaled two-term operand splits) against the shipped fp32 kernels (conv3x3_wino4.hip, conv3x3_wino.hip) and a
+// double-precision CPU convolution on sampled outputs.  Not part of the library.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize scripts/exp_h2.hip -o scripts/exp_h2.bin
+#include "../pwcnet_amd/csrc/conv3x3_wino.hip"
+#include "experiments/conv3x3_h2.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include <cstring>
+
+template <typename F>
+static float time_us(F&& f, int iters) {
+    hipEvent_t s, e; (void)hipEventCreate(&s); (void)hipEventCreate(&e);
+    for (int i = 0; i < 3; ++i) f(i);
+    (void)hipEventRecord(s);
+    for (int i = 0; i < iters; ++i) f(i);
+    (void)hipEventRecord(e); (void)hipEventSynchronize(e);
+    float ms; (void)hipEventElapsedTime(&ms, s, e);
+    return ms / iters * 1e3f;
+}
+
+int main(int argc, char** argv) {
+    const int only = argc > 1 ? atoi(argv[1]) : -1;
+    struct Shape { int N, H, W, Cin, Cout, dil, xcs; float in_scale; };
+    Shape shapes[] = {{8, 112, 256, 128, 128, 1, 128, 1.f}, {8, 112, 256, 160, 128, 1, 160, 1.f}, {8, 112, 256, 128, 96, 1, 128, 1.f},
+                      {8, 112, 256, 96, 64, 1, 96, 1.f}, {8, 112, 256, 64, 32, 1, 64, 1.f}, {8, 112, 256, 128, 128, 2, 128, 1.f},
+                      {8, 112, 256, 128, 128, 4, 128, 1.f}, {8, 112, 256, 128, 96, 8, 128, 1.f}, {8, 56, 128, 192, 128, 1, 192, 1.f},
+                      {2, 50, 70, 64, 64, 1, 80, 1.f}, {1, 16, 32, 64, 64, 1, 64, 1.f}, {2, 112, 256, 128, 128, 1, 128, 300.f}};
+    int idx = -1;
+    for (auto sh : shapes) {
+        ++idx;
+        if (only >= 0 && idx != only) continue;
+        const size_t npix = (size_t)sh.N * sh.H * sh.W;
+        const int ycs = sh.Cout + 16;
+        std::vector<float> hx(npix * sh.xcs), hw((size_t)9 * sh.Cin * sh.Cout), hb(sh.Cout);
+        unsigned r = 4242 + idx;
+        auto rnd = [&]() { r = r * 1664525u + 1013904223u; return ((r >> 8) & 0xFFFF) / 65536.f - 0.5f; };
+        // post-activation statistics: leaky-relu of a centred variable
+        for (auto& v : hx) { const float g = 2.f * rnd(); v = sh.in_scale * (g > 0.f ? g : 0.1f * g); }
+        const float wl = sqrtf(6.f / (9.f * (sh.Cin + sh.Cout)));
+        for (auto& v : hw) v = 2.f * wl * rnd();
+        for (auto& v : hb) v = 0.2f * rnd();
+        float *x, *w, *b, *y2, *y4, *yb, *u2, *u4, *ub;
+        (void)hipMalloc(&x, hx.size() * 4); (void)hipMalloc(&w, hw.size() * 4); (void)hipMalloc(&b, hb.size() * 4);
+        (void)hipMalloc(&y2, npix * ycs * 4); (void)hipMalloc(&y4, npix * ycs * 4); (void)hipMalloc(&yb, npix * ycs * 4);
+        (void)hipMalloc(&u2, pwc_conv3x3_wino_packed_floats(sh.Cin, sh.Cout) * 4);
+        (void)hipMalloc(&u4, pwc_conv3x3_wino4_packed_floats(sh.Cin, sh.Cout) * 4);
+        (void)hipMalloc(&ub, pwc_conv3x3_h2_packed_floats(sh.Cin, sh.Cout) * 4);
+        (void)hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemset(y2, 0, npix * ycs * 4); (void)hipMemset(y4, 0, npix * ycs * 4); (void)hipMemset(yb, 0, npix * ycs * 4);
+        int rc = pwc_conv3x3_wino_pack_f32(w, nullptr, sh.Cin, sh.Cin, sh.Cout, u2, 0);
+        rc |= pwc_conv3x3_wino4_pack_f32(w, nullptr, sh.Cin, sh.Cin, sh.Cout, u4, 0);
+        rc |= pwc_conv3x3_h2_pack_f32(w, nullptr, sh.Cin, sh.Cin, sh.Cout, ub, 0);
+        const double gf = 2.0 * npix * 9.0 * sh.Cin * sh.Cout / 1e9;
+        printf("== [%d] N=%d %dx%d Cin=%d (cs %d) Cout=%d d=%d input scale %.0f: %.1f GFLOP (direct), wino4 supported=%d h2 supported=%d, pack rc %d\n",
+               idx, sh.N, sh.H, sh.W, sh.Cin, sh.xcs, sh.Cout, sh.dil, sh.in_scale, gf,
+               pwc_conv3x3_wino4_supported(sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil),
+               pwc_conv3x3_h2_supported(sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil), rc);
+        if (!pwc_conv3x3_h2_supported(sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil)) { printf("  (skipped)\n"); continue; }
+        rc = pwc_conv3x3_wino_f32(x, sh.xcs, u2, b, y2, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0);
+        int rc4 = pwc_conv3x3_wino4_f32(x, sh.xcs, u4, b, y4, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0);
+        int rcb = pwc_conv3x3_h2_f32(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0);
+        (void)hipDeviceSynchronize();
+        printf("  launch rc: F(2x2) %d, F(4x4) %d, F(4x4) f16x2 direct %d; hip: %s\n", rc, rc4, rcb, hipGetErrorString(hipGetLastError()));
+        std::vector<float> h2(npix * ycs), h4(npix * ycs), hbb(npix * ycs);
+        (void)hipMemcpy(h2.data(), y2, h2.size() * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h4.data(), y4, h4.size() * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hbb.data(), yb, hbb.size() * 4, hipMemcpyDeviceToHost);
+        double md = 0, mx = 0, mpad = 0; size_t bad = 0, nan = 0;
+        size_t hy[16] = {0}, hxm[32] = {0}, hc[8] = {0};
+        const double tol = 2e-4 * sh.in_scale;
+        for (size_t p = 0; p < npix; ++p) {
+            for (int c = 0; c < sh.Cout; ++c) {
+                const double a = hbb[p * ycs + c], e = h4[p * ycs + c];
+                if (a != a) { ++nan; continue; }
+                md = fmax(md, fabs(a - e)); mx = fmax(mx, fabs(e));
+                if (fabs(a - e) > tol) {
+                    if (bad < 6) printf("    mismatch n %zu y %zu x %zu c %d: f16x2 direct %.6f fp32 F(4x4) %.6f\n", p / ((size_t)sh.H * sh.W), (p / sh.W) % sh.H, p % sh.W, c, a, e);
+                    ++bad; ++hy[((p / sh.W) % sh.H) & 15]; ++hxm[(p % sh.W) & 31]; ++hc[(c >> 2) & 7];
+                }
+            }
+            for (int c = sh.Cout; c < ycs; ++c) mpad = fmax(mpad, fabs((double)hbb[p * ycs + c]));
+        }
+        if (bad) {
+            printf("    bad by y%%16: "); for (int i = 0; i < 16; ++i) printf("%zu ", hy[i]);
+            printf("\n    bad by x%%32: "); for (int i = 0; i < 32; ++i) printf("%zu ", hxm[i]);
+            printf("\n    bad by (c/4)%%8: "); for (int i = 0; i < 8; ++i) printf("%zu ", hc[i]);
+            printf("\n");
+        }
+        // double-precision direct convolution on sampled outputs: errors of the three kernels
+        double e2 = 0, e4 = 0, eb = 0, s2 = 0, s4 = 0, sb = 0, sv = 0;
+        unsigned rs = 99;
+        const int NS = 3000;
+        for (int s = 0; s < NS; ++s) {
+            rs = rs * 1664525u + 1013904223u; const size_t p = (rs >> 4) % npix;
+            rs = rs * 1664525u + 1013904223u; const int co = (rs >> 4) % sh.Cout;
+            const int n = (int)(p / ((size_t)sh.H * sh.W)), yy = (int)((p / sh.W) % sh.H), xx = (int)(p % sh.W);
+            double acc = hb[co];
+            for (int ty = 0; ty < 3; ++ty) for (int tx = 0; tx < 3; ++tx) {
+                const int sy = yy + (ty - 1) * sh.dil, sx = xx + (tx - 1) * sh.dil;
+                if (sy < 0 || sy >= sh.H || sx < 0 || sx >= sh.W) continue;
+                const float* xp = &hx[(((size_t)n * sh.H + sy) * sh.W + sx) * sh.xcs];
+                for (int ci = 0; ci < sh.Cin; ++ci) acc += (double)xp[ci] * hw[((size_t)(ty * 3 + tx) * sh.Cin + ci) * sh.Cout + co];
+            }
+            acc = fmax(acc, 0.1 * acc);
+            const double d2 = h2[p * ycs + co] - acc, d4 = h4[p * ycs + co] - acc, db = hbb[p * ycs + co] - acc;
+            e2 = fmax(e2, fabs(d2)); e4 = fmax(e4, fabs(d4)); eb = fmax(eb, fabs(db));
+            s2 += d2 * d2; s4 += d4 * d4; sb += db * db; sv += acc * acc;
+        }
+        printf("  f16x2 direct vs fp32 F(4x4): max |diff| %.3e (max |value| %.3f), %zu entries > %.0e, %zu NaN; channels beyond Cout max %.1e\n", md, mx, bad, tol, nan, mpad);
+        printf("  NUMERICS vs float64 direct conv (%d samples, rms |y| %.3e): F(2x2) fp32 max %.3e rms %.3e | F(4x4) fp32 max %.3e rms %.3e | F(4x4) f16x2 direct max %.3e rms %.3e  (f16x2 direct / fp32 F(4x4): max x%.2f rms x%.2f)\n",
+               NS, sqrt(sv / NS), e2, sqrt(s2 / NS), e4, sqrt(s4 / NS), eb, sqrt(sb / NS), eb / e4, sqrt(sb / s4));
+        fflush(stdout);
+        for (int round = 0; round < 2; ++round) {
+            const float t2 = time_us([&](int) { pwc_conv3x3_wino_f32(x, sh.xcs, u2, b, y2, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10);
+            const float t4 = time_us([&](int) { pwc_conv3x3_wino4_f32(x, sh.xcs, u4, b, y4, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10);
+            const float tb = time_us([&](int) { pwc_conv3x3_h2_f32(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10);
+            printf("  F(2x2) %8.1f us %6.1f TF | F(4x4) fp32 %8.1f us %6.1f TF | F(4x4) f16x2 direct %8.1f us %6.1f TF (direct-conv flops)  x%.2f vs fp32 F(4x4)\n",
+                   t2, gf / t2 * 1e3, t4, gf / t4 * 1e3, tb, gf / tb * 1e3, t4 / tb);
+            fflush(stdout);
+        }
+        if (idx == 0) {
+            printf("  ablations: no patch DMA %.1f | no weight DMA %.1f | no DMA %.1f | no MFMA %.1f | no split (m' = 0) %.1f | no DMA, no MFMA %.1f us\n",
+                   time_us([&](int) { h2_run<1>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10),
+                   time_us([&](int) { h2_run<2>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10),
+                   time_us([&](int) { h2_run<3>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10),
+                   time_us([&](int) { h2_run<4>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10),
+                   time_us([&](int) { h2_run<8>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10),
+                   time_us([&](int) { h2_run<7>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10));
+            fflush(stdout);
+        }
+        (void)hipFree(x); (void)hipFree(w); (void)hipFree(b); (void)hipFree(y2); (void)hipFree(y4); (void)hipFree(yb);
+        (void)hipFree(u2); (void)hipFree(u4); (void)hipFree(ub);
+    }
+    return 0;
+}
