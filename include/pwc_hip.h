@@ -199,6 +199,35 @@ int pwc_conv3x3_wino4_f32(const float* x, int x_cs, const float* packed_u, const
                           float* y, int y_cs, int N, int H, int W, int Cin_phys, int Cout,
                           int dilation, int apply_act, float slope, pwc_stream_t stream);
 int pwc_conv3x3_wino4_supported(int N, int H, int W, int Cin_phys, int Cout, int dilation);
+/* The same convolution DIRECTLY (no Winograd transform) on the F16 matrix pipe with exact-to-22-bit operand splits
+ * (csrc/conv3x3_h2.hip; reference modules.py:266-268 `optflow_l/conv2d*`, modules.py:306-323 `context/conv2d*`,
+ * modules.py:221-236 `fp_extractor/conv2d*` where they are stride 1).  fp32 in, fp32 out, fp32 accumulation.  Every
+ * operand is used as x = h + 2^-11 m' with h = fp16(x), m' = fp16((x - h) 2^11); of the four cross products the three
+ * above 2^-22 are formed (uh vh, uh vm', um' vh; v_mfma_f32_32x32x16_f16) in two fp32 accumulators.  Measured error
+ * against a float64 convolution: 0.1x that of pwc_conv3x3_wino4_f32 and 0.7x that of pwc_conv3x3_wino_f32 on every
+ * layer shape (profiles/r04_exp_h2.txt), 0.4x that of a v_mfma_f32_16x16x4_f32 chain (profiles/
+ * r04_exp_f16x2_numerics.txt).  RANGE: inputs and weights must be below 65504 in magnitude (fp16's largest finite
+ * value); a larger input makes the outputs that depend on it NaN (inf - inf in the split), never a silently wrong
+ * number.  packed_w comes from pwc_conv3x3_h2_pack_f32 (split weights, pwc_conv3x3_h2_packed_floats floats; same
+ * cin_map semantics as pwc_conv3x3_pack_f32).  Needs Cout % 32 == 0, Cin_phys % 16 == 0, x and y 16-byte aligned with
+ * x_cs % 4 == 0 and y_cs % 4 == 0.  pwc_conv3x3_h2_supported: 1 where it is the fastest kernel of this library for the
+ * shape (Cin_phys >= 48, sub-lattices of at least 8 x 24 pixels, at least 192 workgroups), 0 otherwise; the entry point
+ * itself accepts every shape that meets the requirements above. */
+size_t pwc_conv3x3_h2_packed_floats(int Cin_phys, int Cout);
+int pwc_conv3x3_h2_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin, int Cin_phys,
+                            int Cout, float* packed_w, pwc_stream_t stream);
+int pwc_conv3x3_h2_f32(const float* x, int x_cs, const float* packed_w, const float* bias,
+                       float* y, int y_cs, int N, int H, int W, int Cin_phys, int Cout,
+                       int dilation, int apply_act, float slope, pwc_stream_t stream);
+int pwc_conv3x3_h2_supported(int N, int H, int W, int Cin_phys, int Cout, int dilation);
+/* Tile variants of the kernel above (workgroup = couts x rows x 32 columns): 1 = 128 x 8, 2 = 64 x 16, 3 = 96 x 8,
+ * 4 = 32 x 16, 5 = 64 x 8.  pwc_conv3x3_h2_plan: the one pwc_conv3x3_h2_f32 launches for a shape (fewest estimated
+ * rounds of 256 workgroups x matrix instructions per tap; 0 = the shape is not accepted).  pwc_conv3x3_h2_variant_f32:
+ * the same convolution with the variant given (Cout must be a multiple of its couts) -- for tests and tuning. */
+int pwc_conv3x3_h2_plan(int N, int H, int W, int Cin_phys, int Cout, int dilation);
+int pwc_conv3x3_h2_variant_f32(const float* x, int x_cs, const float* packed_w, const float* bias,
+                               float* y, int y_cs, int N, int H, int W, int Cin_phys, int Cout,
+                               int dilation, int apply_act, float slope, int variant, pwc_stream_t stream);
 /* The same convolution with the input-channel stages dealt to `csplit` workgroups per tile (launches that would leave
  * most of the GPU's workgroup slots empty: the 14x32 / 28x64 pyramid levels).  Partial outputs go to `workspace`
  * (pwc_conv3x3_wino_split_workspace_floats floats, 16-byte aligned) and are summed in a fixed order, with the bias and the

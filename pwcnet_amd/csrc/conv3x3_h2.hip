@@ -1,0 +1,482 @@
+// conv3x3_h2.hip -- 3x3 stride-1 'SAME' convolution, DIRECT, on the F16 matrix pipe of gfx950 with scaled two-term operand
+// splits (round 4).  fp32 in, fp32 out, fp32 accumulation; more accurate than an fp32 MFMA chain (below).
+//
+// Replaces the same tf.layers.Conv2D(...,(3,3),(1,1),'same',dilation_rate=d) + tf.nn.leaky_relu calls as conv3x3_wino4.hip
+// (reference modules.py:266-268 `optflow_l/conv2d*`, modules.py:306-323 `context/conv2d*`).
+//
+// Arithmetic: every fp32 operand is written  x = h + 2^-11 m',  h = fp16(x),  m' = fp16((x - h) * 2^11)  (x - h is exact in
+// fp32; 11 + 11 significant bits; the scaling keeps m' out of fp16's subnormal range) and
+//     u v ~= uh vh + 2^-11 (uh vm' + um' vh)            three products, TWO fp32 accumulators (hh and cross), combined once.
+// Measured (scripts/exp_f16x2.hip, profiles/r04_exp_f16x2_numerics.txt): error against float64 = x0.37 - 0.47 of the
+// v_mfma_f32_16x16x4_f32 chain's on every distribution tried (the matrix pipe rounds once per 16 products).  No Winograd
+// transform: no transform rounding (F(4x4) rounds ~6x coarser than F(2x2)), no per-position operand split, no 36-position
+// accumulator set -- the kernel is an implicit GEMM whose tiles are bounded by LDS and registers like any GEMM.
+// Range: |x| must stay below 65504 (fp16); the fp32 kernels remain for anything else.
+// The matrix work: 9 taps x 3 products at the F16 rate (16x the fp32 MFMA rate) = 27/16 fp32-MFMA-equivalents per
+// multiply-add against F(4x4)'s 36/16 -- 0.75x the matrix time of the fp32 Winograd kernel, with nothing else on the SIMD that
+// serialises with it (no packed fp32 VALU: the split is plain v_cvt / v_sub / v_mul, once per workgroup and 16-channel stage).
+//
+// Work decomposition (512 threads = 8 waves, one workgroup per CU), template <CT, PT, WCG>:
+//   wave      = CT cout tiles of 32 x PT pixel tiles of 32 (one image row each) of v_mfma_f32_32x32x16_f16: 2 CT PT
+//               accumulator tiles (hh, cross) of 16 registers;
+//   workgroup = WCG cout groups x WPG = 8 / WCG pixel groups: 32 CT WCG couts x (PT WPG rows x 32 columns).
+//               (2,2,2): 128 couts x 8 rows   (2,2,1): 64 couts x 16 rows   (3,1,1): 96 couts x 8 rows   (1,2,1): 32 couts x 16 rows
+//               (1,2,2): 64 couts x 8 rows (more, smaller workgroups for the small pyramid levels)
+//   Per 16-channel stage: the raw fp32 patch ((rows + 2) x 34 pixels x 64 bytes) arrives by buffer_load ... lds into a staging
+//   image S; all threads split it (4 channels per item) into the operand image B[stage & 1] = [patch row][chunk: vh 0-7, vh 8-15,
+//   vm' 0-7, vm' 8-15][pixel 34][16 bytes] -- 32 consecutive pixels of a chunk are 512 contiguous bytes = conflict-free
+//   fragments at any tap shift; the pre-split weights of a TAP ROW r, A[r] = [cout tile][dx 3][chunk: uh 0-7, uh 8-15, um' 0-7,
+//   um' 8-15][cout 32][16 bytes], are a linear copy of the packed global image.  K of an MFMA = [8 channels | 8 channels] over the
+//   two lane halves, four fragments per (cout tile, pixel tile) pair:
+//     hh = UH x VH      cross = UH x VM' + UM' x VH          UH = [uh 0-7 | uh 8-15], UM' = [um' 0-7 | um' 8-15], VH, VM' alike.
+//   Pipeline: a stage is three PARTS (tap rows).  Barrier of part (c, r): every wave is done with A[r - 1] -> the weights of
+//   (c + 1, r - 1) are fetched into it (r = 0: (c, 2) into A[2]); the barrier also publishes that part (c, r + 1) has landed, so
+//   the fragments of the next tap are always fetched one tap ahead, across part and stage boundaries (two fragment sets in
+//   registers).  The split of stage c + 1 runs inside part (c, 1) (half the waves during tap 1, the other half during tap 2, so
+//   that the matrix pipe of every SIMD always has one wave feeding it) from S into B[(c + 1) & 1]; the patch of stage c + 2
+//   is fetched into S from the barrier of part (c, 2).  Three barriers per stage, none of them waits for a fetch issued less
+//   than one part (~2300 cycles) earlier.
+#pragma once
+#include "pwc_common.h"
+#include <type_traits>
+
+typedef _Float16 pwc_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pwc_f16x4 __attribute__((ext_vector_type(4)));
+typedef float pwc_f32x16 __attribute__((ext_vector_type(16)));
+
+struct H2Args {
+    const float* x;
+    const void* wp;      // packed split weights [c16][tap row 3][cout tile of 32][dx 3][chunk 4][cout 32][8 fp16]
+    const float* bias;
+    float* y;
+    int x_cs, y_cs;
+    int N, H, W;
+    int Cin_phys, Cout;
+    int apply_act;
+    float slope;
+    int tiles_x, tiles_y, ncb;   // pixel tiles per (sub-)image, cout blocks of the workgroup's 32 CT WCG couts
+    int dil;
+    int ntiles;
+};
+
+constexpr unsigned H2_OOB = 0x7FFF0000u;
+constexpr int H2_PW = 34;                    // patch width in pixels
+constexpr int H2_CHK = H2_PW * 16;           // bytes of a chunk row in the operand image: 544
+constexpr int H2_ROWB = 4 * H2_CHK;          // bytes of a patch row in the operand image: 4 chunks x 34 pixels x 16 B = 2176
+constexpr int H2_TAPB = 4 * 32 * 16;         // bytes of the weights of one (cout tile, tap): 2048
+
+template <int CT, int PT, int WCG> struct H2Cfg {
+    static constexpr int WPG = 8 / WCG;          // pixel groups (PT rows each)
+    static constexpr int NCT = CT * WCG;         // cout tiles of the workgroup
+    static constexpr int TR = PT * WPG;          // tile rows: 8 or 16
+    static constexpr int PH = TR + 2;            // patch rows
+    static constexpr int NREC = PH * H2_PW;      // patch pixels: 340 / 612
+    static constexpr int NBP = (NREC + 15) / 16; // 1 KB pieces of the staging image (16 records of 64 B): 22 / 39
+    static constexpr int PPW = (NBP + 7) / 8;    // patch pieces per wave: 3 / 5
+    static constexpr int S_BYTES = (PPW * 8) * 1024;                 // staging (incl. the surplus pieces)
+    static constexpr int B_BYTES = PH * H2_ROWB;                     // one operand image: 21 760 / 39 168
+    static constexpr int AP = NCT * 3 * H2_TAPB;                     // weights of a part (tap row): 24 576 / 12 288 / 18 432 / 6144
+    static constexpr int NAP = AP / 1024;                            // ... in 1 KB pieces
+    static constexpr int APW = (NAP + 7) / 8;                        // pieces per wave (the last round may be partial)
+    static constexpr int S0 = 0, B0 = S_BYTES, A0 = B0 + ((2 * B_BYTES + 1023) / 1024) * 1024;
+    static constexpr int LDS = A0 + 3 * AP;
+    static_assert(LDS <= 160 * 1024, "LDS");
+};
+
+// ABL (harness only): 1 = no patch DMA, 2 = no weight DMA, 4 = no MFMA, 8 = m' = 0, 16 = no split at all, 32 = no fragment reads
+template <int CT, int PT, int WCG, int ABL = 0>
+__global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
+    typedef H2Cfg<CT, PT, WCG> C;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const sm = reinterpret_cast<char*>(smem);
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int pg = wave % C::WPG, cgw = wave / C::WPG;     // pixel group (rows PT pg ..), cout group (CT tiles)
+    const int ln = lane & 31, kh = lane >> 5;
+
+    const int d = a.dil;
+    const int nc16 = a.Cin_phys >> 4;
+    // ---- block decode: cout block fastest, XCD-aware
+    int lb = pwc_xcd_remap(blockIdx.x, a.ntiles);
+    const int cb = lb % a.ncb;
+    int rest = lb / a.ncb;
+    const int bx = rest % a.tiles_x;
+    rest /= a.tiles_x;
+    const int by = rest % a.tiles_y;
+    rest /= a.tiles_y;
+    const int sub = rest % (d * d);
+    const int n = rest / (d * d);
+    const int ry = sub / d, rx = sub - ry * d;      // pixel sub-lattice (y mod d, x mod d) of a dilated conv
+    const int y0 = by * C::TR, x0 = bx * 32;        // output origin of the tile, in sub-lattice coordinates
+    const int n0 = cb * 32 * C::NCT;
+    const int nct_all = a.Cout >> 5;                // cout tiles of 32 in the packed image
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + (size_t)n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.wp, 0, nc16 * nct_all * 9 * H2_TAPB, 0x00020000);
+
+    // ---- patch fetch: piece b = wave + 8 i holds records 16 b .. 16 b + 15 (record = patch pixel, 64 bytes = 16 channels)
+    unsigned p_voff[C::PPW];
+#pragma unroll
+    for (int i = 0; i < C::PPW; ++i) {
+        const int rec = (wave + 8 * i) * 16 + (lane >> 2);
+        const int py = rec / H2_PW, px = rec - py * H2_PW;
+        const int yy = ry + d * (y0 - 1 + py), xx = rx + d * (x0 - 1 + px);
+        const bool ok = rec < C::NREC && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        p_voff[i] = ok ? (unsigned)(((yy * a.W + xx) * a.x_cs + (lane & 3) * 4) * 4) : H2_OOB;
+    }
+    auto issue_patch_piece = [&](int i, int c16) {
+        if (!(ABL & 1))
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(sm + C::S0 + (wave + 8 * i) * 1024), 16, (int)p_voff[i], c16 * 64, 0, 0);
+    };
+    // ---- weights of part (c16, r): NCT cout tiles x 3 taps x 2 KB, contiguous in the packed image; pieces wave, wave + 8, ...
+    const unsigned w_lane = (unsigned)lane * 16u;
+    const int w_blk = (n0 >> 5) * 3 * H2_TAPB;
+    auto issue_w_piece = [&](int j, int c16, int r) {
+        const int pc = wave + 8 * j;                   // uniform
+        if (pc < C::NAP && !(ABL & 2))
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lptr_t)(sm + C::A0 + r * C::AP + pc * 1024), 16, (int)w_lane,
+                                                     (c16 * 3 + r) * nct_all * 3 * H2_TAPB + w_blk + pc * 1024, 0, 0);
+    };
+#define H2_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+    // ---- split of the staging image into an operand image: item = (patch pixel, 4-channel group); item j of a thread is
+    // t + 512 j.  cv_read / cv_write are the two halves of an item so that they can sit in different issue slots of a tap.
+    constexpr int NIT = C::NREC * 4;
+    constexpr int NITJ = (NIT + 511) / 512;          // 3 / 5
+    auto cv_read = [&](int j) -> f32x4 {
+        const int it = t + 512 * j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (it < NIT) v = *reinterpret_cast<const f32x4*>(sm + C::S0 + it * 16);
+        return v;
+    };
+    auto cv_write = [&](int j, int buf, const f32x4 v) {
+        const int it = t + 512 * j;
+        if (it < NIT) {
+            const int rec = it >> 2, g = it & 3;
+            pwc_f16x4 h, m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = (_Float16)v[e];
+                m[e] = (ABL & 8) ? (_Float16)0.f : (_Float16)((v[e] - (float)h[e]) * 2048.f);
+            }
+            const int py = rec / H2_PW, px = rec - py * H2_PW;
+            char* dst = sm + C::B0 + buf * C::B_BYTES + py * H2_ROWB + (g >> 1) * H2_CHK + px * 16 + (g & 1) * 8;
+            *reinterpret_cast<pwc_f16x4*>(dst) = h;
+            *reinterpret_cast<pwc_f16x4*>(dst + 2 * H2_CHK) = m;
+        }
+    };
+    auto convert = [&](int buf) {
+        if (ABL & 16) return;
+#pragma unroll
+        for (int j = 0; j < NITJ; ++j) cv_write(j, buf, cv_read(j));
+    };
+
+    // ---- fragments.  B: patch row (PT pg + pt + r), pixel ln + dx, chunk kh (h) / 2 + kh (m');  A: slot r, cout tile (CT cgw + ct),
+    // tap dx, chunk kh / 2 + kh, cout ln.  Fetch order = the order the matrix instructions of the next tap want them in.
+    struct Frags { pwc_f16x8 ah[CT], am[CT], bh[PT], bm[PT]; };
+    constexpr int NL = 2 * (CT + PT);
+    constexpr int NM = 3 * CT * PT;
+    const char* const bbase = sm + C::B0 + (PT * pg) * H2_ROWB + kh * H2_CHK + ln * 16;
+    const char* const abase = sm + C::A0 + (CT * cgw) * 3 * H2_TAPB + kh * 512 + ln * 16;
+    auto load_i = [&](Frags& f, int i, int buf, int r, int dx) {
+        if (ABL & 32) return;
+        const char* const bb = bbase + buf * C::B_BYTES + r * H2_ROWB + dx * 16;
+        const char* const ab = abase + r * C::AP + dx * H2_TAPB;
+        // order: AH0, BH0 .. BH(PT-1), AH1 .. AH(CT-1), BM0 .., AM0 ..
+        if (i == 0) f.ah[0] = *reinterpret_cast<const pwc_f16x8*>(ab);
+        else if (i <= PT) f.bh[i - 1] = *reinterpret_cast<const pwc_f16x8*>(bb + (i - 1) * H2_ROWB);
+        else if (i < PT + CT) f.ah[i - PT] = *reinterpret_cast<const pwc_f16x8*>(ab + (i - PT) * 3 * H2_TAPB);
+        else if (i < 2 * PT + CT) f.bm[i - PT - CT] = *reinterpret_cast<const pwc_f16x8*>(bb + (i - PT - CT) * H2_ROWB + 2 * H2_CHK);
+        else f.am[i - 2 * PT - CT] = *reinterpret_cast<const pwc_f16x8*>(ab + (i - 2 * PT - CT) * 3 * H2_TAPB + 1024);
+    };
+
+    pwc_f32x16 acc[CT][PT], accx[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][pt][r] = accx[ct][pt][r] = 0.f;
+    // matrix instruction i of a tap: group i / (CT PT) (hh, UH x VM', UM' x VH), tile i % (CT PT) -- MFMAs on one accumulator
+    // stay CT PT apart
+    auto mfma_i = [&](const Frags& f, int i) {
+        const int grp = i / (CT * PT), tl = i % (CT * PT), ct = tl / PT, pt = tl % PT;
+        if (ABL & 4) {
+            if (i == 0) asm volatile("" ::"v"(f.ah[0]), "v"(f.am[CT - 1]), "v"(f.bh[0]), "v"(f.bm[PT - 1]));
+            return;
+        }
+        if (grp == 0) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[ct], f.bh[pt], acc[ct][pt], 0, 0, 0);
+        if (grp == 1) accx[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[ct], f.bm[pt], accx[ct][pt], 0, 0, 0);
+        if (grp == 2) accx[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.am[ct], f.bh[pt], accx[ct][pt], 0, 0, 0);
+    };
+
+    // ---- prologue: patch 0, parts (0,0) and (0,1); split patch 0; patch 1
+#pragma unroll
+    for (int i = 0; i < C::PPW; ++i) issue_patch_piece(i, 0);
+#pragma unroll
+    for (int j = 0; j < C::APW; ++j) issue_w_piece(j, 0, 0);
+#pragma unroll
+    for (int j = 0; j < C::APW; ++j) issue_w_piece(j, 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    H2_BAR();
+    convert(0);
+    H2_BAR();
+    if (nc16 > 1) {
+#pragma unroll
+        for (int i = 0; i < C::PPW; ++i) issue_patch_piece(i, 1);
+    }
+    Frags cur, nxt;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) load_i(cur, i, 0, 0, 0);
+    const bool cv_first = wave < 4;          // which of the taps 1 / 2 of part (c, 1) carries this wave's share of the split
+
+    // One tap = NM issue slots: matrix instruction i, then ONE other instruction group (a fragment fetch of the next tap, a
+    // fetch piece, a piece of the split) that issues while the matrix pipe works.
+    auto tap = [&](auto Rc, auto DXc, int c16, int buf, bool more) {
+        constexpr int R = decltype(Rc)::value, DX = decltype(DXc)::value;
+        constexpr int NR = DX < 2 ? R : (R + 1) % 3, NDX = (DX + 1) % 3;
+        const int nbuf = (R == 2 && DX == 2) ? (buf ^ 1) : buf;
+        const bool do_load = !(R == 2 && DX == 2) || more;
+        const bool do_cv = R == 1 && DX >= 1 && more && !(ABL & 16) && ((DX == 1) == cv_first);
+        constexpr int NEX = (R == 1 && DX >= 1) ? NITJ + 1 : (DX == 0) ? C::APW : (R == 2 && DX == 1) ? C::PPW : 0;
+        constexpr int NSLOT = NM > NL + NEX ? NM : NL + NEX;
+        f32x4 cvv[2];
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            if (i < NM) mfma_i(cur, i);
+            if (i < NL) {
+                if (do_load) load_i(nxt, i, nbuf, NR, NDX);
+            } else {
+                const int e = i - NL;
+                if (DX == 0 && e < C::APW) {
+                    if (R == 0) issue_w_piece(e, c16, 2);
+                    else if (more) issue_w_piece(e, c16 + 1, R - 1);
+                } else if (R == 2 && DX == 1 && e < C::PPW) {
+                    if (c16 + 2 < nc16) issue_patch_piece(e, c16 + 2);
+                } else if (R == 1 && DX >= 1 && e <= NITJ) {
+                    if (do_cv) {
+                        if (e >= 1) cv_write(e - 1, buf ^ 1, cvv[(e - 1) & 1]);
+                        if (e < NITJ) cvv[e & 1] = cv_read(e);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur = nxt;
+    };
+
+    for (int c16 = 0; c16 < nc16; ++c16) {
+        const int buf = c16 & 1;
+        const bool more = c16 + 1 < nc16;
+        // part (c16, 0): this wave's pieces of part (c16, 1) have landed (the patch pieces behind them may be in flight) ...
+        if (more) {
+            if (C::PPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            static_assert(C::PPW == 3 || C::PPW == 5, "vmcnt immediates");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        H2_BAR();                          // ... everybody's; every wave is done with slot 2
+        tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, c16, buf, more);
+        tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, c16, buf, more);
+        tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, c16, buf, more);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // part (c16, 2) and the patch of c16 + 1
+        H2_BAR();
+        tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, c16, buf, more);
+        tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, c16, buf, more);
+        tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, c16, buf, more);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // part (c16 + 1, 0)
+        H2_BAR();
+        tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, c16, buf, more);
+        tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, c16, buf, more);
+        tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, c16, buf, more);
+    }
+    // ---- epilogue: y = hh + 2^-11 cross + bias, leaky-relu; lane = (pixel column ln, couts (r & 3) + 8 (r >> 2) + 4 kh of a tile)
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.y + (size_t)n * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int py = ry + d * (y0 + PT * pg + pt), px = rx + d * (x0 + ln);
+        const bool inside = py < a.H && px < a.W;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = n0 + (CT * cgw + ct) * 32 + 8 * q + 4 * kh;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + co);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = acc[ct][pt][4 * q + e] + accx[ct][pt][4 * q + e] * (1.f / 2048.f) + b4[e];
+                if (a.apply_act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], o[e] * a.slope);
+                }
+                const unsigned vo = inside ? (unsigned)(((py * a.W + px) * a.y_cs + co) * 4) : H2_OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, (int)vo, 0, 0);
+            }
+    }
+#undef H2_BAR
+}
+
+// ---------------------------------------------------------------- weight split + packing
+// packed[c16][tap row 3][cout tile of 32][dx 3][chunk 4: uh ch 0-7, uh 8-15, um' 0-7, um' 8-15][cout 32][8 fp16];
+// uh = fp16(w), um' = fp16((w - uh) * 2^11), both round-to-nearest; cin_map as in pwc_conv3x3_pack_f32.
+__global__ void conv3x3_h2_pack_kernel(const float* __restrict__ w, const int32_t* __restrict__ cin_map, int Cin,
+                                       int Cin_phys, int Cout, int nct, unsigned short* __restrict__ packed) {
+    const size_t total = (size_t)(Cin_phys >> 4) * nct * 9 * 32 * 16;     // one thread per (c16, ct, tap, cout, channel)
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx & 15);
+        size_t r = idx >> 4;
+        const int i = (int)(r & 31);
+        r >>= 5;
+        const int tap = (int)(r % 9);
+        r /= 9;
+        const int ct = (int)(r % nct);
+        const int c16 = (int)(r / nct);
+        const int cphys = c16 * 16 + ch;
+        const int clog = cin_map ? cin_map[cphys] : (cphys < Cin ? cphys : -1);
+        const int co = ct * 32 + i;
+        float u = 0.f;
+        if (clog >= 0 && clog < Cin && co < Cout) u = w[((size_t)tap * Cin + clog) * Cout + co];
+        const _Float16 h = (_Float16)u;
+        const _Float16 m = (_Float16)((u - (float)h) * 2048.f);
+        const int tr = tap / 3, dx = tap - 3 * tr;
+        unsigned short* base = packed + (((((size_t)c16 * 3 + tr) * nct + ct) * 3 + dx) * 4) * 256;      // 4 chunks x 32 couts x 8
+        base[(ch >> 3) * 256 + i * 8 + (ch & 7)] = __builtin_bit_cast(unsigned short, h);
+        base[(2 + (ch >> 3)) * 256 + i * 8 + (ch & 7)] = __builtin_bit_cast(unsigned short, m);
+    }
+}
+
+extern "C" size_t pwc_conv3x3_h2_packed_floats(int Cin_phys, int Cout) {
+    if (Cin_phys <= 0 || Cout <= 0) return 0;
+    return (size_t)(Cin_phys >> 4) * ((Cout + 31) / 32) * 9 * (H2_TAPB / 4);
+}
+
+extern "C" int pwc_conv3x3_h2_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin, int Cin_phys,
+                                       int Cout, float* packed, pwc_stream_t stream) {
+    if (!w_hwio || !packed || Cin <= 0 || Cout <= 0 || Cin_phys < Cin) return PWC_EINVAL;
+    if (Cin_phys % 16) return PWC_EALIGN;
+    const int nct = (Cout + 31) / 32;
+    const size_t total = (size_t)(Cin_phys >> 4) * nct * 9 * 32 * 16;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv3x3_h2_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, cin_map,
+                       Cin, Cin_phys, Cout, nct, reinterpret_cast<unsigned short*>(packed));
+    return pwc_launch_status();
+}
+
+// ---------------------------------------------------------------- tile variants and the launch plan
+// variant: 1 = (2,2,2) 128 couts x 8 rows, 2 = (2,2,1) 64 couts x 16 rows, 3 = (3,1,1) 96 couts x 8 rows,
+//          4 = (1,2,1) 32 couts x 16 rows, 5 = (1,2,2) 64 couts x 8 rows            (all x 32 columns)
+struct H2Variant { int couts, rows, nm; };
+static inline H2Variant h2_variant(int v) {
+    switch (v) {
+        case 1: return {128, 8, 12};
+        case 2: return {64, 16, 12};
+        case 3: return {96, 8, 9};
+        case 4: return {32, 16, 6};
+        default: return {64, 8, 6};
+    }
+}
+static inline long h2_blocks(int v, int N, int hs, int ws, int Cout, int dilation) {
+    const H2Variant t = h2_variant(v);
+    return (long)N * dilation * dilation * ((ws + 31) / 32) * ((hs + t.rows - 1) / t.rows) * (Cout / t.couts);
+}
+// The variant whose launch is estimated shortest: rounds of 256 workgroups x (matrix instructions per tap and wave + 3.6), the
+// 3.6 being the measured fixed part of a tap (profiles/r04_exp_h2.txt: 52 / 40.5 / 34 us per round of 8 stages for 12 / 9 / 6).
+static int h2_plan(int N, int H, int W, int Cin_phys, int Cout, int dilation, long* blocks_out) {
+    if (N <= 0 || H <= 0 || W <= 0 || dilation < 1 || Cin_phys < 16 || (Cin_phys % 16) || Cout < 32 || (Cout % 32)) return 0;
+    const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
+    int best = 0;
+    double best_cost = 0.;
+    long best_blocks = 0;
+    for (int v = 1; v <= 5; ++v) {
+        const H2Variant t = h2_variant(v);
+        if (Cout % t.couts) continue;
+        const long nb = h2_blocks(v, N, hs, ws, Cout, dilation);
+        if (nb >= (1L << 31)) continue;
+        const double cost = (double)((nb + 255) / 256) * (t.nm + 3.6);
+        if (!best || cost < best_cost) { best = v; best_cost = cost; best_blocks = nb; }
+    }
+    if (blocks_out) *blocks_out = best_blocks;
+    return best;
+}
+
+// 1 where this kernel is the faster one for the shape (measured against conv3x3_wino4.hip / conv3x3_wino.hip on isolated layers:
+// profiles/r04_exp_h2.txt): sub-lattices of at least 8 x 24 pixels, a launch that fills at least three quarters of the CUs, three or more channel stages
+// (32 -> 32 channels is a tie with F(2x2)).
+extern "C" int pwc_conv3x3_h2_supported(int N, int H, int W, int Cin_phys, int Cout, int dilation) {
+    long nb = 0;
+    if (!h2_plan(N, H, W, Cin_phys, Cout, dilation, &nb)) return 0;
+    const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
+    return hs >= 8 && ws >= 24 && nb >= 192 && Cin_phys >= 48 ? 1 : 0;
+}
+
+template <int CT, int PT, int WCG, int ABL>
+static int h2_launch(H2Args& a, int hs, int ws, hipStream_t stream) {
+    typedef H2Cfg<CT, PT, WCG> C;
+    a.tiles_x = (ws + 31) / 32; a.tiles_y = (hs + C::TR - 1) / C::TR; a.ncb = a.Cout / (32 * C::NCT);
+    const long nblk = (long)a.N * a.dil * a.dil * a.tiles_x * a.tiles_y * a.ncb;
+    if (nblk >= (1L << 31)) return PWC_ERANGE;
+    a.ntiles = (int)nblk;
+    static PwcDevOnce attr_once;
+    if (pwc_first_on_device(&attr_once)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2_kernel<CT, PT, WCG, ABL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    }
+    hipLaunchKernelGGL((conv3x3_h2_kernel<CT, PT, WCG, ABL>), dim3((unsigned)a.ntiles), dim3(512), C::LDS, stream, a);
+    return pwc_launch_status();
+}
+
+// variant 0 = h2_plan's choice
+template <int ABL = 0>
+static int h2_run(const float* x, int x_cs, const float* packed_w, const float* bias, float* y, int y_cs, int N, int H, int W,
+                  int Cin_phys, int Cout, int dilation, int apply_act, float slope, pwc_stream_t stream, int variant = 0) {
+    if (!x || !packed_w || !bias || !y) return PWC_EINVAL;
+    if (N <= 0 || H <= 0 || W <= 0 || Cin_phys <= 0 || Cout <= 0 || dilation < 1) return PWC_EINVAL;
+    if (Cin_phys % 16 || Cout % 32) return PWC_EUNSUPPORTED;
+    if (x_cs < Cin_phys || y_cs < Cout) return PWC_EINVAL;
+    if ((x_cs & 3) || (y_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(y) || !pwc_aligned16(packed_w) || !pwc_aligned16(bias))
+        return PWC_EALIGN;
+    if ((long)H * W * x_cs * 4 >= (long)H2_OOB || (long)H * W * y_cs * 4 >= (long)H2_OOB) return PWC_ERANGE;
+    H2Args a;
+    a.x = x; a.wp = packed_w; a.bias = bias; a.y = y; a.x_cs = x_cs; a.y_cs = y_cs;
+    a.N = N; a.H = H; a.W = W; a.Cin_phys = Cin_phys; a.Cout = Cout; a.apply_act = apply_act; a.slope = slope;
+    a.dil = dilation;
+    const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
+    if (variant == 0) variant = h2_plan(N, H, W, Cin_phys, Cout, dilation, nullptr);
+    if (variant < 1 || variant > 5) return PWC_EUNSUPPORTED;
+    if (Cout % h2_variant(variant).couts) return PWC_EUNSUPPORTED;
+    switch (variant) {
+        case 1: return h2_launch<2, 2, 2, ABL>(a, hs, ws, (hipStream_t)stream);
+        case 2: return h2_launch<2, 2, 1, ABL>(a, hs, ws, (hipStream_t)stream);
+        case 3: return h2_launch<3, 1, 1, ABL>(a, hs, ws, (hipStream_t)stream);
+        case 4: return h2_launch<1, 2, 1, ABL>(a, hs, ws, (hipStream_t)stream);
+        default: return h2_launch<1, 2, 2, ABL>(a, hs, ws, (hipStream_t)stream);
+    }
+}
+
+extern "C" int pwc_conv3x3_h2_f32(const float* x, int x_cs, const float* packed_w, const float* bias, float* y,
+                                  int y_cs, int N, int H, int W, int Cin_phys, int Cout, int dilation,
+                                  int apply_act, float slope, pwc_stream_t stream) {
+    return h2_run<0>(x, x_cs, packed_w, bias, y, y_cs, N, H, W, Cin_phys, Cout, dilation, apply_act, slope, stream);
+}
+
+// The tile variant pwc_conv3x3_h2_f32 uses for a shape (1 - 5, see h2_variant; 0 = none fits), and the same convolution with
+// the variant given (tests and tuning: every variant must give the same result on every shape whose Cout it divides).
+extern "C" int pwc_conv3x3_h2_plan(int N, int H, int W, int Cin_phys, int Cout, int dilation) {
+    return h2_plan(N, H, W, Cin_phys, Cout, dilation, nullptr);
+}
+
+extern "C" int pwc_conv3x3_h2_variant_f32(const float* x, int x_cs, const float* packed_w, const float* bias, float* y,
+                                          int y_cs, int N, int H, int W, int Cin_phys, int Cout, int dilation,
+                                          int apply_act, float slope, int variant, pwc_stream_t stream) {
+    if (variant < 1 || variant > 5) return PWC_EINVAL;
+    return h2_run<0>(x, x_cs, packed_w, bias, y, y_cs, N, H, W, Cin_phys, Cout, dilation, apply_act, slope, stream, variant);
+}

@@ -92,7 +92,7 @@ def _pick_side_streams(dev, main, count):
 class PWCDCNet(object):
     def __init__(self, num_levels=6, search_range=4, warp_type="bilinear", use_dc=False,
                  output_level=4, name="pwcdcnet", seed=0, fuse_warp=False, use_plans=True, winograd=True,
-                 coarse_cv=True, persistent_outputs=False, max_plans=4, streams=None, concat_cv=True, winograd4=True):
+                 coarse_cv=True, persistent_outputs=False, max_plans=4, streams=None, concat_cv=True, winograd4=True, f16x2=True):
         self.num_levels = num_levels
         self.s_range = search_range
         self.warp_type = warp_type
@@ -116,6 +116,7 @@ class PWCDCNet(object):
         for mod in [self.fp_extractor, self.context] + self.of_estimators:
             mod.winograd = bool(winograd)
             mod.winograd4 = bool(winograd4)
+            mod.f16x2 = bool(f16x2)
         _lib.lib()  # fail now, loudly, if the HIP library is missing
         self.store = VariableStore(seed=seed)
         # launch plans (one per input shape, device, stream): the forward is recorded once and

@@ -243,7 +243,33 @@ class _ConvRunner:
                     and tile < 0 and split == 0 and _wino_pays(L, x.N, x.H, x.W, cout, dilation))
         use_wino4 = (use_wino and getattr(self.owner, "winograd4", True) and y.cs % 4 == 0 and y.ptr % 16 == 0
                      and L.pwc_conv3x3_wino4_supported(x.N, x.H, x.W, x.C, cout, dilation))
-        if use_wino4:
+        use_h2 = (use_mfma and getattr(self.owner, "f16x2", True) and stride == 1 and tile < 0 and split == 0
+                  and cout % 32 == 0 and y.cs % 4 == 0 and y.ptr % 16 == 0
+                  and L.pwc_conv3x3_h2_supported(x.N, x.H, x.W, x.C, cout, dilation))
+        if use_h2:
+            # direct convolution on the F16 matrix pipe, fp32 operands as two-term fp16 splits (conv3x3_h2.hip)
+            key = (name, "h2", x.C, None if cin_map is None else cin_map.tobytes(), self.store.version)
+            packed = cache.get(key)
+            if packed is None:
+                nfl = L.pwc_conv3x3_h2_packed_floats(x.C, cout)
+                packed = torch.empty((nfl,), dtype=torch.float32, device=kern.value.device)
+                cm = None
+                if cin_map is not None:
+                    assert len(cin_map) == x.C
+                    cm = torch.from_numpy(np.ascontiguousarray(cin_map, np.int32)).to(kern.value.device)
+                _lib.check(L.pwc_conv3x3_h2_pack_f32(_p(kern.value.data_ptr()),
+                                                     _p(cm.data_ptr()) if cm is not None else None,
+                                                     cin, x.C, cout, _p(packed.data_ptr()), s), "conv3x3 h2 pack")
+                cache[key] = packed
+            _keep(packed, y_t)
+            _launch(L.pwc_conv3x3_h2_f32,
+                    (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
+                     x.N, x.H, x.W, x.C, cout, dilation, act, sl, s),
+                    f"conv3x3_h2 {name}", "conv3x3_h2_kernel",
+                    2.0 * x.N * Ho * Wo * 9 * cin * cout, 4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout),
+                    # executed: three fp16 products per multiply-add, per physical input channel
+                    exec_flops=3.0 * 2.0 * x.N * Ho * Wo * 9 * x.C * cout)
+        elif use_wino4:
             # F(4x4,3x3): 36 multiplies per 4x4 outputs (the big full-resolution layers)
             key = (name, "wino4", x.C, None if cin_map is None else cin_map.tobytes(), self.store.version)
             packed = cache.get(key)
@@ -403,6 +429,8 @@ def _mfma_kernel_name(L, M, cout, cin_phys, tile, split):
 class _Module:
     winograd = False     # route eligible convs (stride 1, dilation 1, Cout % 32 == 0) to the Winograd kernel
     winograd4 = True     # ... and the big ones among them to the F(4x4,3x3) kernel (pwc_conv3x3_wino4_supported)
+    f16x2 = True         # the layers pwc_conv3x3_h2_supported names go to the direct F16-matrix-pipe kernel (fp32 operands as
+                         # exact-to-22-bit fp16 pairs, fp32 accumulation; inputs must stay below 65504)
 
     def __init__(self, name):
         self.name = name

@@ -3,7 +3,7 @@
 // double-precision CPU convolution on sampled outputs.  Not part of the library.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize scripts/exp_h2.hip -o scripts/exp_h2.bin
 #include "../pwcnet_amd/csrc/conv3x3_wino.hip"
-#include "experiments/conv3x3_h2.hip"
+#include "../pwcnet_amd/csrc/conv3x3_h2.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -27,7 +27,10 @@ int main(int argc, char** argv) {
     Shape shapes[] = {{8, 112, 256, 128, 128, 1, 128, 1.f}, {8, 112, 256, 160, 128, 1, 160, 1.f}, {8, 112, 256, 128, 96, 1, 128, 1.f},
                       {8, 112, 256, 96, 64, 1, 96, 1.f}, {8, 112, 256, 64, 32, 1, 64, 1.f}, {8, 112, 256, 128, 128, 2, 128, 1.f},
                       {8, 112, 256, 128, 128, 4, 128, 1.f}, {8, 112, 256, 128, 96, 8, 128, 1.f}, {8, 56, 128, 192, 128, 1, 192, 1.f},
-                      {2, 50, 70, 64, 64, 1, 80, 1.f}, {1, 16, 32, 64, 64, 1, 64, 1.f}, {2, 112, 256, 128, 128, 1, 128, 300.f}};
+                      {2, 50, 70, 64, 64, 1, 80, 1.f}, {1, 16, 32, 64, 64, 1, 64, 1.f}, {2, 112, 256, 128, 128, 1, 128, 300.f},
+                      {16, 112, 256, 32, 32, 1, 32, 1.f}, {16, 56, 128, 64, 64, 1, 64, 1.f}, {16, 28, 64, 96, 96, 1, 96, 1.f}, {8, 56, 128, 128, 96, 1, 128, 1.f},
+                      {8, 56, 128, 96, 64, 1, 96, 1.f}, {8, 56, 128, 64, 32, 1, 64, 1.f}, {8, 112, 256, 48, 128, 1, 48, 1.f}, {8, 28, 64, 192, 128, 1, 192, 1.f},
+                      {8, 112, 256, 96, 64, 16, 96, 1.f}};
     int idx = -1;
     for (auto sh : shapes) {
         ++idx;
@@ -60,7 +63,7 @@ int main(int argc, char** argv) {
                idx, sh.N, sh.H, sh.W, sh.Cin, sh.xcs, sh.Cout, sh.dil, sh.in_scale, gf,
                pwc_conv3x3_wino4_supported(sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil),
                pwc_conv3x3_h2_supported(sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil), rc);
-        if (!pwc_conv3x3_h2_supported(sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil)) { printf("  (skipped)\n"); continue; }
+        { long nb = 0; const int pv = h2_plan(sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, &nb); printf("  plan: variant %d, %ld workgroups\n", pv, nb); if (!pv) continue; }
         rc = pwc_conv3x3_wino_f32(x, sh.xcs, u2, b, y2, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0);
         int rc4 = pwc_conv3x3_wino4_f32(x, sh.xcs, u4, b, y4, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0);
         int rcb = pwc_conv3x3_h2_f32(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0);
@@ -123,14 +126,30 @@ int main(int argc, char** argv) {
                    t2, gf / t2 * 1e3, t4, gf / t4 * 1e3, tb, gf / tb * 1e3, t4 / tb);
             fflush(stdout);
         }
-        if (idx == 0) {
-            printf("  ablations: no patch DMA %.1f | no weight DMA %.1f | no DMA %.1f | no MFMA %.1f | no split (m' = 0) %.1f | no DMA, no MFMA %.1f us\n",
-                   time_us([&](int) { h2_run<1>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10),
-                   time_us([&](int) { h2_run<2>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10),
-                   time_us([&](int) { h2_run<3>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10),
-                   time_us([&](int) { h2_run<4>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10),
-                   time_us([&](int) { h2_run<8>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10),
-                   time_us([&](int) { h2_run<7>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10));
+        for (int v = 1; v <= 5; ++v) {
+            (void)hipMemset(yb, 0, npix * ycs * 4);
+            const int rv = h2_run<0>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0, v);
+            if (rv) continue;
+            (void)hipMemcpy(hbb.data(), yb, hbb.size() * 4, hipMemcpyDeviceToHost);
+            double mdv = 0; size_t nanv = 0;
+            for (size_t p = 0; p < npix; ++p)
+                for (int c = 0; c < ycs; ++c) {
+                    const double a = hbb[p * ycs + c], e = c < sh.Cout ? h2[p * ycs + c] : 0.0;
+                    if (a != a) { ++nanv; continue; }
+                    mdv = fmax(mdv, fabs(a - e));
+                }
+            const float tv = time_us([&](int) { h2_run<0>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0, v); }, 10);
+            printf("  variant %d: max |diff| vs fp32 F(2x2) %.3e, %zu NaN, %8.1f us %6.1f TF\n", v, mdv, nanv, tv, gf / tv * 1e3);
+            fflush(stdout);
+        }
+        if (idx == 0 || idx == 2) {
+            auto ab = [&](auto tag) { return time_us([&](int) { h2_run<decltype(tag)::value>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10); };
+            printf("  ablations: no patch DMA %.1f | no weight DMA %.1f | no DMA %.1f | no MFMA %.1f | m' = 0 %.1f | no split %.1f | no fragment reads %.1f |"
+                   " no DMA, no MFMA %.1f | no MFMA, no fragment reads %.1f | MFMA only %.1f | nothing %.1f us\n",
+                   ab(std::integral_constant<int, 1>{}), ab(std::integral_constant<int, 2>{}), ab(std::integral_constant<int, 3>{}),
+                   ab(std::integral_constant<int, 4>{}), ab(std::integral_constant<int, 8>{}), ab(std::integral_constant<int, 16>{}),
+                   ab(std::integral_constant<int, 32>{}), ab(std::integral_constant<int, 7>{}), ab(std::integral_constant<int, 36>{}),
+                   ab(std::integral_constant<int, 51>{}), ab(std::integral_constant<int, 55>{}));
             fflush(stdout);
         }
         (void)hipFree(x); (void)hipFree(w); (void)hipFree(b); (void)hipFree(y2); (void)hipFree(y4); (void)hipFree(yb);

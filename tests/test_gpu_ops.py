@@ -253,6 +253,114 @@ def test_conv_winograd_f4x4_physical_layout_and_plan(pa):
     assert L.pwc_conv3x3_wino4_supported(8, 14, 32, 128, 128, 1) == 0       # ... nor does a coarse level
 
 
+H2_COUTS = {1: 128, 2: 64, 3: 96, 4: 32, 5: 64}
+
+
+def run_conv_h2(x, k, b, slope, cin_map=None, y_cs=None, dil=1, variant=0):
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    N, H, W, cs = x.shape
+    cin, cout = k.shape[2], k.shape[3]
+    xg, kg, bg = gpu(x), gpu(k), gpu(b)
+    packed = torch.empty(L.pwc_conv3x3_h2_packed_floats(cs, cout), device="cuda")
+    cm = None if cin_map is None else torch.from_numpy(np.asarray(cin_map, np.int32)).cuda()
+    _lib.check(L.pwc_conv3x3_h2_pack_f32(_p(kg), _p(cm) if cm is not None else None, cin, cs, cout, _p(packed), None))
+    y_cs = cout if y_cs is None else y_cs
+    y = torch.full((N, H, W, y_cs), -7.0, device="cuda")
+    act, sl = (0 if slope is None else 1), (0.0 if slope is None else slope)
+    if variant:
+        _lib.check(L.pwc_conv3x3_h2_variant_f32(_p(xg), cs, _p(packed), _p(bg), _p(y), y_cs, N, H, W, cs, cout, dil, act, sl,
+                                                variant, None))
+    else:
+        _lib.check(L.pwc_conv3x3_h2_f32(_p(xg), cs, _p(packed), _p(bg), _p(y), y_cs, N, H, W, cs, cout, dil, act, sl, None))
+    torch.cuda.synchronize()
+    return y
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,dil", [
+    (1, 32, 64, 128, 128, 1), (2, 16, 32, 64, 32, 1), (1, 33, 47, 32, 64, 1), (1, 5, 3, 16, 32, 1), (2, 50, 70, 160, 96, 1),
+    (1, 56, 64, 128, 96, 2), (1, 40, 48, 64, 64, 4), (1, 112, 96, 32, 32, 8), (2, 19, 23, 48, 64, 3), (1, 20, 40, 16, 128, 1),
+    (2, 30, 33, 80, 192, 1), (1, 17, 100, 48, 256, 1)])
+def test_conv_f16x2_direct_vs_oracle(pa, N, H, W, cin, cout, dil):
+    """pwc_conv3x3_h2_f32 (direct convolution on the F16 matrix pipe, fp32 operands as two-term fp16 splits) in EVERY tile
+    variant whose couts divide Cout: ragged 8/16-row x 32-column tiles, dilations (sub-lattices), one to ten channel stages
+    (the fetch pipeline's prologue and its tail), strided output with untouched neighbours.  Tolerance: the fp32 default
+    (1e-5 of max |y|) -- the split arithmetic is MORE accurate than an fp32 MFMA chain, it gets no allowance."""
+    x = rnd((N, H, W, cin), 271)
+    k = rnd((3, 3, cin, cout), 272) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 273) * 0.1
+    exp = orc.conv3x3(x, k, b, 1, dil, 0.1)
+    exp_lin = orc.conv3x3(x, k, b, 1, dil, None)
+    ran = 0
+    for v in (0, 1, 2, 3, 4, 5):
+        if v and cout % H2_COUTS[v]:
+            continue
+        close(run_conv_h2(x, k, b, 0.1, dil=dil, variant=v), exp)
+        y = run_conv_h2(x, k, b, None, y_cs=cout + 8, dil=dil, variant=v)
+        close(y[..., :cout], exp_lin)
+        assert float(y[..., cout:].min()) == -7.0 and float(y[..., cout:].max()) == -7.0
+        ran += 1
+    assert ran >= 2
+
+
+@pytest.mark.parametrize("cin,cout,dil", [(160, 128, 1), (128, 96, 2), (64, 32, 1)])
+def test_conv_f16x2_direct_full_size_vs_oracle(pa, cin, cout, dil):
+    """pwc_conv3x3_h2_f32 at the PRODUCTION shape (8 x 112 x 256: 896 - 1792 workgroups of 512 threads, XCD remap) against
+    the oracle's convolution on the first and the last image of the batch, every entry; the other six are checked for
+    finiteness and for the untouched channels behind Cout."""
+    N, H, W = 8, 112, 256
+    x = rnd((N, H, W, cin), 281)
+    k = rnd((3, 3, cin, cout), 282) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 283) * 0.1
+    y = run_conv_h2(x, k, b, 0.1, y_cs=cout + 16, dil=dil)
+    for i in (0, N - 1):
+        close(y[i:i + 1, ..., :cout], orc.conv3x3(x[i:i + 1], k, b, 1, dil, 0.1))
+    assert bool(torch.isfinite(y).all())
+    assert float(y[..., cout:].min()) == -7.0 and float(y[..., cout:].max()) == -7.0
+
+
+def test_conv_f16x2_direct_physical_layout_range_and_plan(pa):
+    """Padded / permuted physical input channels through cin_map (the estimator buffers); operands of very different
+    magnitudes (the split is relative, not absolute); an input beyond fp16's range poisons exactly the outputs that
+    read it (NaN, never a silently wrong number); and the shapes the model routes to this kernel."""
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(5)
+    N, H, W, cin, cout, cs = 1, 32, 64, 147, 128, 160
+    cmap = np.full((cs,), -1, np.int32)
+    pos = np.sort(rs.choice(cs, cin, replace=False))
+    cmap[pos] = np.arange(cin, dtype=np.int32)
+    xl = rnd((N, H, W, cin), 181)
+    xp = rnd((N, H, W, cs), 182)                       # padding channels hold finite values the zero weights must erase
+    xp[..., pos] = xl
+    k = rnd((3, 3, cin, cout), 183) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 184) * 0.1
+    close(run_conv_h2(xp, k, b, 0.1, cin_map=cmap), orc.conv3x3(xl, k, b, 1, 1, 0.1))
+    # magnitudes: activations x 1e3 and x 1e-4 (the second product sits in fp16's normal range only because m' is scaled)
+    for scale in (1e3, 1e-4):
+        bs = (b * scale).astype(np.float32)
+        close(run_conv_h2((xp * scale).astype(np.float32), k, bs, 0.1, cin_map=cmap),
+              orc.conv3x3((xl * scale).astype(np.float32), k, bs, 1, 1, 0.1))
+    # range: one input of 1e5 at (10, 20), logical channel 3
+    xb = xp.copy()
+    xb[0, 10, 20, pos[3]] = 1.0e5
+    yb = run_conv_h2(xb, k, b, 0.1, cin_map=cmap).cpu().numpy()
+    good = orc.conv3x3(xl, k, b, 1, 1, 0.1)
+    nan = np.isnan(yb)
+    assert nan[0, 9:12, 19:22, :].all() and int(nan.sum()) == 9 * cout
+    assert float(np.abs(np.where(nan, 0.0, yb - good)).max()) <= 1e-5 * float(np.abs(good).max())
+    assert L.pwc_conv3x3_h2_supported(8, 112, 256, 160, 128, 1) == 1
+    assert L.pwc_conv3x3_h2_supported(8, 112, 256, 128, 96, 8) == 1
+    assert L.pwc_conv3x3_h2_supported(8, 112, 256, 64, 32, 1) == 1
+    assert L.pwc_conv3x3_h2_supported(8, 56, 128, 192, 128, 1) == 1
+    assert L.pwc_conv3x3_h2_supported(8, 112, 256, 128, 64, 16) == 0        # 7-row sub-lattices
+    assert L.pwc_conv3x3_h2_supported(8, 14, 32, 128, 128, 1) == 0          # a coarse level does not fill the GPU
+    assert L.pwc_conv3x3_h2_supported(8, 112, 256, 128, 48, 1) == 0         # Cout % 32
+    assert L.pwc_conv3x3_h2_plan(8, 112, 256, 128, 96, 1) == 3
+    assert L.pwc_conv3x3_h2_plan(8, 112, 256, 64, 32, 1) == 4
+    assert L.pwc_conv3x3_h2_plan(8, 112, 256, 128, 128, 1) in (1, 2)
+
+
 @pytest.mark.parametrize("N,H,W,cin,cout,dil,csplit", [
     (2, 14, 32, 256, 128, 1, 4), (1, 28, 64, 224, 96, 1, 2), (2, 14, 32, 112, 48, 1, 3), (1, 28, 64, 64, 32, 1, 2),
     (1, 20, 36, 128, 64, 2, 4), (8, 14, 32, 128, 128, 1, 0), (1, 16, 16, 80, 16, 1, 5)])
