@@ -218,7 +218,16 @@ int pwc_conv3x3_h2_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin
                             int Cout, float* packed_w, pwc_stream_t stream);
 int pwc_conv3x3_h2_f32(const float* x, int x_cs, const float* packed_w, const float* bias,
                        float* y, int y_cs, int N, int H, int W, int Cin_phys, int Cout,
-                       int dilation, int apply_act, float slope, pwc_stream_t stream);
+                       int dilation, int apply_act, float slope, float* workspace, size_t workspace_floats,
+                       pwc_stream_t stream);
+/* `workspace` (caller-owned, 16-byte aligned, pwc_conv3x3_h2_workspace_floats floats, every byte 0xFF before the first
+ * launch that uses the buffer -- every launch leaves it so -- and not shared by launches that may run concurrently)
+ * turns a launch with more tiles than CUs into one workgroup per CU, each computing an equal share of the launch's
+ * (tile, 16-channel stage) sequence: no partly filled last round, one prologue per workgroup instead of one per tile.
+ * A tile cut in two is finished by the workgroup holding its first piece, which adds the other's published fp32 sums to
+ * its own (one addition of two finished sums: the result does not depend on timing) -- within fp32 rounding of the
+ * uncut sum.  workspace = NULL: one workgroup per tile. */
+size_t pwc_conv3x3_h2_workspace_floats(int N, int H, int W, int Cin_phys, int Cout, int dilation);
 int pwc_conv3x3_h2_supported(int N, int H, int W, int Cin_phys, int Cout, int dilation);
 /* Tile variants of the kernel above (workgroup = couts x rows x 32 columns): 1 = 128 x 8, 2 = 64 x 16, 3 = 96 x 8,
  * 4 = 32 x 16, 5 = 64 x 8.  pwc_conv3x3_h2_plan: the one pwc_conv3x3_h2_f32 launches for a shape (fewest estimated
@@ -227,7 +236,8 @@ int pwc_conv3x3_h2_supported(int N, int H, int W, int Cin_phys, int Cout, int di
 int pwc_conv3x3_h2_plan(int N, int H, int W, int Cin_phys, int Cout, int dilation);
 int pwc_conv3x3_h2_variant_f32(const float* x, int x_cs, const float* packed_w, const float* bias,
                                float* y, int y_cs, int N, int H, int W, int Cin_phys, int Cout,
-                               int dilation, int apply_act, float slope, int variant, pwc_stream_t stream);
+                               int dilation, int apply_act, float slope, int variant, float* workspace,
+                               size_t workspace_floats, pwc_stream_t stream);
 /* The same convolution with the input-channel stages dealt to `csplit` workgroups per tile (launches that would leave
  * most of the GPU's workgroup slots empty: the 14x32 / 28x64 pyramid levels).  Partial outputs go to `workspace`
  * (pwc_conv3x3_wino_split_workspace_floats floats, 16-byte aligned) and are summed in a fixed order, with the bias and the

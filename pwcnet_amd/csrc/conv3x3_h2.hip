@@ -57,9 +57,14 @@ struct H2Args {
     int tiles_x, tiles_y, ncb;   // pixel tiles per (sub-)image, cout blocks of the workgroup's 32 CT WCG couts
     int dil;
     int ntiles;
+    float* ws_partial;   // stream-K: one partial tile (32 CT WCG couts x PT WPG x 32 pixels, fp32) per workgroup, words 0xFFFFFFFF
+                         // while nothing is published; null = every workgroup owns whole tiles
+    unsigned* dbg;       // harness only
 };
 
 constexpr unsigned H2_OOB = 0x7FFF0000u;
+constexpr int H2_SC1 = 16;                   // aux bit of the buffer intrinsics: device-scope access (gfx940+)
+constexpr unsigned H2_EMPTY = 0xFFFFFFFFu;    // workspace word that holds no published sum
 constexpr int H2_PW = 34;                    // patch width in pixels
 constexpr int H2_CHK = H2_PW * 16;           // bytes of a chunk row in the operand image: 544
 constexpr int H2_ROWB = 4 * H2_CHK;          // bytes of a patch row in the operand image: 4 chunks x 34 pixels x 16 B = 2176
@@ -83,7 +88,9 @@ template <int CT, int PT, int WCG> struct H2Cfg {
     static_assert(LDS <= 160 * 1024, "LDS");
 };
 
-// ABL (harness only): 1 = no patch DMA, 2 = no weight DMA, 4 = no MFMA, 8 = m' = 0, 16 = no split at all, 32 = no fragment reads
+// ABL (harness only): 1 = no patch DMA, 2 = no weight DMA, 4 = no MFMA, 8 = m' = 0, 16 = no split at all, 32 = no fragment reads,
+// 64 = the published sums are replaced by position tags and checked by the reader (self-test of the exchange), 2048 = s_memtime
+// totals of the waits, barriers and piece ends per wave
 template <int CT, int PT, int WCG, int ABL = 0>
 __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     typedef H2Cfg<CT, PT, WCG> C;
@@ -100,47 +107,64 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
 
     const int d = a.dil;
     const int nc16 = a.Cin_phys >> 4;
-    // ---- block decode: cout block fastest, XCD-aware
-    int lb = pwc_xcd_remap(blockIdx.x, a.ntiles);
-    const int cb = lb % a.ncb;
-    int rest = lb / a.ncb;
-    const int bx = rest % a.tiles_x;
-    rest /= a.tiles_x;
-    const int by = rest % a.tiles_y;
-    rest /= a.tiles_y;
-    const int sub = rest % (d * d);
-    const int n = rest / (d * d);
-    const int ry = sub / d, rx = sub - ry * d;      // pixel sub-lattice (y mod d, x mod d) of a dilated conv
-    const int y0 = by * C::TR, x0 = bx * 32;        // output origin of the tile, in sub-lattice coordinates
-    const int n0 = cb * 32 * C::NCT;
     const int nct_all = a.Cout >> 5;                // cout tiles of 32 in the packed image
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.x + (size_t)n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
+    // ---- the workgroup's range of the launch's (tile, channel stage) sequence.  Tiles: cout block fastest, then the pixel
+    // tiles of a (sub-)image; logical workgroup ids are XCD-aware (neighbouring ranges share an L2).  gridDim.x <= ntiles, so a
+    // range holds at least one whole tile's worth of stages: a tile is cut into at most TWO pieces, the first at the END of
+    // workgroup w's range, the second at the START of workgroup w + 1's.
+    const int G = (int)gridDim.x;
+    const int lw = pwc_xcd_remap(blockIdx.x, G);
+    const long total = (long)a.ntiles * nc16;
+    const int g0 = (int)((long)lw * total / G), g1 = (int)((long)(lw + 1) * total / G);
+    struct Tile { int n, ry, rx, y0, x0, n0; };
+    auto decode = [&](int tile) {
+        Tile tl;
+        const int cb = tile % a.ncb;
+        int rest = tile / a.ncb;
+        const int bx = rest % a.tiles_x;
+        rest /= a.tiles_x;
+        const int by = rest % a.tiles_y;
+        rest /= a.tiles_y;
+        const int sub = rest % (d * d);
+        tl.n = rest / (d * d);
+        tl.ry = sub / d; tl.rx = sub - tl.ry * d;          // pixel sub-lattice (y mod d, x mod d) of a dilated conv
+        tl.y0 = by * C::TR; tl.x0 = bx * 32;                // output origin of the tile, in sub-lattice coordinates
+        tl.n0 = cb * 32 * C::NCT;
+        return tl;
+    };
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.wp, 0, nc16 * nct_all * 9 * H2_TAPB, 0x00020000);
 
-    // ---- patch fetch: piece b = wave + 8 i holds records 16 b .. 16 b + 15 (record = patch pixel, 64 bytes = 16 channels)
+    // ---- patch fetch of a stage (tile, c16): piece b = wave + 8 i holds records 16 b .. 16 b + 15 (record = patch pixel, 64 bytes
+    // = 16 channels).  The lane offsets (and the image's buffer resource) change with the tile only.
     unsigned p_voff[C::PPW];
+    __amdgpu_buffer_rsrc_t xrsrc;
+    auto patch_tile = [&](int tile) {
+        const Tile tl = decode(tile);
+        xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)tl.n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < C::PPW; ++i) {
-        const int rec = (wave + 8 * i) * 16 + (lane >> 2);
-        const int py = rec / H2_PW, px = rec - py * H2_PW;
-        const int yy = ry + d * (y0 - 1 + py), xx = rx + d * (x0 - 1 + px);
-        const bool ok = rec < C::NREC && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-        p_voff[i] = ok ? (unsigned)(((yy * a.W + xx) * a.x_cs + (lane & 3) * 4) * 4) : H2_OOB;
-    }
+        for (int i = 0; i < C::PPW; ++i) {
+            const int rec = (wave + 8 * i) * 16 + (lane >> 2);
+            const int py = rec / H2_PW, px = rec - py * H2_PW;
+            const int yy = tl.ry + d * (tl.y0 - 1 + py), xx = tl.rx + d * (tl.x0 - 1 + px);
+            const bool ok = rec < C::NREC && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            p_voff[i] = ok ? (unsigned)(((yy * a.W + xx) * a.x_cs + (lane & 3) * 4) * 4) : H2_OOB;
+        }
+    };
     auto issue_patch_piece = [&](int i, int c16) {
         if (!(ABL & 1))
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(sm + C::S0 + (wave + 8 * i) * 1024), 16, (int)p_voff[i], c16 * 64, 0, 0);
     };
-    // ---- weights of part (c16, r): NCT cout tiles x 3 taps x 2 KB, contiguous in the packed image; pieces wave, wave + 8, ...
+    // ---- weights of part (c16, r) for cout block cb: NCT cout tiles x 3 taps x 2 KB, contiguous in the packed image; pieces wave,
+    // wave + 8, ...
     const unsigned w_lane = (unsigned)lane * 16u;
-    const int w_blk = (n0 >> 5) * 3 * H2_TAPB;
-    auto issue_w_piece = [&](int j, int c16, int r) {
+    auto issue_w_piece = [&](int j, int c16, int cb, int r) {
         const int pc = wave + 8 * j;                   // uniform
+        // (a local: with the expression inline the HOST pass of hipcc drops the kernel's stub without a diagnostic)
+        const int soff = ((c16 * 3 + r) * nct_all + cb * C::NCT) * 3 * H2_TAPB;
         if (pc < C::NAP && !(ABL & 2))
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lptr_t)(sm + C::A0 + r * C::AP + pc * 1024), 16, (int)w_lane,
-                                                     (c16 * 3 + r) * nct_all * 3 * H2_TAPB + w_blk + pc * 1024, 0, 0);
+                                                     soff + pc * 1024, 0, 0);
     };
 #define H2_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -196,12 +220,15 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     };
 
     pwc_f32x16 acc[CT][PT], accx[CT][PT];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt)
+            for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][pt][r] = accx[ct][pt][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[ct][pt][r] = accx[ct][pt][r] = 0.f;
+    };
+    zero_acc();
     // matrix instruction i of a tap: group i / (CT PT) (hh, UH x VM', UM' x VH), tile i % (CT PT) -- MFMAs on one accumulator
     // stay CT PT apart
     auto mfma_i = [&](const Frags& f, int i) {
@@ -215,37 +242,172 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         if (grp == 2) accx[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.am[ct], f.bh[pt], accx[ct][pt], 0, 0, 0);
     };
 
-    // ---- prologue: patch 0, parts (0,0) and (0,1); split patch 0; patch 1
+    // ---- end of a piece.  kind 0: a whole tile, or the FIRST piece of a tile whose second piece workgroup lw + 1 publishes
+    // (that workgroup computes it at the start of its range, this one reaches its piece at the end of its own):
+    // y = own + other + bias, leaky-relu.  kind 1: the SECOND piece of a tile (start of the range): publish hh + 2^-11 cross
+    // to the workspace.  own + other is one fp32 addition of two finished sums: its result does not depend on who adds.
+    // The exchange needs no flag and no fence: the workspace holds 0xFFFFFFFF words (a NaN no arithmetic produces) wherever
+    // nothing is published; the reader polls each 16 bytes with device-scope loads until none of its words is the sentinel
+    // and then puts the sentinel back.  (A release / acquire pair would write back and invalidate a whole L2 -- every
+    // output line of the launch -- per workgroup; a flag behind plain device-scope stores was seen to overtake them.)
+    // Lane = (pixel column ln, couts (r & 3) + 8 (r >> 2) + 4 kh of a tile).
+    constexpr int PART_FLOATS = C::NCT * 32 * C::TR * 32;
+    auto finish = [&](int tile, int kind, bool with_other) {
+        if (kind == 1) {
+            // buffer addressing (base in SGPRs, one lane offset): flat pointers would cost two VGPRs per access, hoisted
+            const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.ws_partial + (size_t)lw * PART_FLOATS + (size_t)wave * (CT * PT * 16 * 64)), 0, CT * PT * 16 * 64 * 4, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < C::PPW; ++i) issue_patch_piece(i, 0);
+            for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-    for (int j = 0; j < C::APW; ++j) issue_w_piece(j, 0, 0);
+                for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-    for (int j = 0; j < C::APW; ++j) issue_w_piece(j, 0, 1);
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            o[e] = (ABL & 64) ? __builtin_bit_cast(float, 0x40000000u | ((unsigned)(lw & 255) << 16) | ((unsigned)wave << 12) | ((unsigned)((pt * CT + ct) * 4 + q) << 8) | (lane << 2) | e)
+                                              : acc[ct][pt][4 * q + e] + accx[ct][pt][4 * q + e] * (1.f / 2048.f);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), prs, lane * 16, ((pt * CT + ct) * 4 + q) * 1024, H2_SC1);
+                        // Seen on gfx950: with nothing but four VALU instructions between two 16-byte stores, the NEXT iteration's
+                        // first result lands in the store's first data register before the store has read it (first word of the
+                        // chunk wrong in the last lanes of each 16-lane pass).  The compiler knows the hazard only for stores
+                        // without an SGPR offset.
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("s_nop 7" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            return;
+        }
+        __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, 0, 0x00020000);
+        if (with_other)
+            prs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.ws_partial + (size_t)(lw + 1) * PART_FLOATS + (size_t)wave * (CT * PT * 16 * 64)), 0, CT * PT * 16 * 64 * 4, 0x00020000);
+        const Tile tl = decode(tile);
+        const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.y + (size_t)tl.n * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
+        // the bias of the lane's 16 CT couts, fetched at once (the fragment registers of the finished tile are free): one exposed
+        // latency per piece end instead of one per store
+        f32x4 bias4[CT][4];
+        {
+            const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.Cout * 4, 0x00020000);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    bias4[ct][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (tl.n0 + (CT * cgw + ct) * 32 + 8 * q + 4 * kh) * 4, 0, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int py = tl.ry + d * (tl.y0 + PT * pg + pt), px = tl.rx + d * (tl.x0 + ln);
+            const bool inside = py < a.H && px < a.W;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = tl.n0 + (CT * cgw + ct) * 32 + 8 * q + 4 * kh;
+                    const f32x4 b4 = bias4[ct][q];
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[ct][pt][4 * q + e] + accx[ct][pt][4 * q + e] * (1.f / 2048.f);
+                    if (with_other) {
+                        const int po = ((pt * CT + ct) * 4 + q) * 1024;
+                        u32x4 p4 = __builtin_amdgcn_raw_buffer_load_b128(prs, lane * 16, po, H2_SC1);
+                        // bounded (~1 s): a sum that never arrives (it cannot, short of a fault) leaves the sentinel -- a NaN --
+                        // in the output instead of hanging the device
+                        for (int tries = 0; tries < (1 << 20); ++tries) {
+                            const bool missing = p4[0] == H2_EMPTY || p4[1] == H2_EMPTY || p4[2] == H2_EMPTY || p4[3] == H2_EMPTY;
+                            if (!__builtin_amdgcn_ballot_w64(missing)) break;
+                            __builtin_amdgcn_s_sleep(16);
+                            p4 = __builtin_amdgcn_raw_buffer_load_b128(prs, lane * 16, po, H2_SC1);
+                        }
+                        const u32x4 empty = {H2_EMPTY, H2_EMPTY, H2_EMPTY, H2_EMPTY};
+                        __builtin_amdgcn_raw_buffer_store_b128(empty, prs, lane * 16, po, H2_SC1);       // clean for the next launch
+                        const f32x4 pf = __builtin_bit_cast(f32x4, p4);
+                        if ((ABL & 64) && a.dbg) {
+                            for (int e = 0; e < 4; ++e)
+                                if (p4[e] != (0x40000000u | ((unsigned)((lw + 1) & 255) << 16) | ((unsigned)wave << 12) | ((unsigned)((pt * CT + ct) * 4 + q) << 8) | (lane << 2) | e)) {
+                                    atomicAdd(a.dbg + ((lane >> 2) & 3), 1u); a.dbg[4 + ((lane >> 2) & 3)] = p4[e]; a.dbg[8] = pt * 100 + ct * 10 + q;
+                                    a.dbg[9] = (0x40000000u | ((unsigned)((lw + 1) & 255) << 16) | ((unsigned)wave << 12) | ((unsigned)((pt * CT + ct) * 4 + q) << 8) | (lane << 2) | e);
+                                }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += pf[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += b4[e];
+                    if (a.apply_act) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], o[e] * a.slope);
+                    }
+                    const unsigned vo = inside ? (unsigned)(((py * a.W + px) * a.y_cs + co) * 4) : H2_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, (int)vo, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);                    // (also bounds the registers the hoisted loads take)
+                    asm volatile("s_nop 7" ::: "memory");                 // see the published sums above
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+    };
+
+    // ---- stage bookkeeping (uniform): the current stage (tile, c16, cb), the next one (weights are fetched one stage ahead) and
+    // the one after (patches two ahead), advanced incrementally -- a division per stage and wave would cost as much as a tap
+    unsigned long long tk_wait = 0, tk_bar = 0, tk_fin = 0;
+    const unsigned long long tk_start = (ABL & 2048) ? __builtin_readcyclecounter() : 0;
+    int tile = g0 / nc16;
+    int c16 = g0 - tile * nc16;
+    int cb = tile % a.ncb;
+    int tile1 = tile, c1 = c16, cb1 = cb;            // stage g + 1
+    auto step = [&](int& tl, int& c, int* cbp) {
+        if (++c == nc16) {
+            c = 0; ++tl;
+            if (cbp && ++*cbp == a.ncb) *cbp = 0;
+        }
+    };
+    step(tile1, c1, &cb1);
+    int tile2 = tile1, c2 = c1;                       // stage g + 2
+    step(tile2, c2, nullptr);
+
+    // ---- prologue: patch g0, parts (g0, 0) and (g0, 1); split patch g0; patch g0 + 1
+    patch_tile(tile);
+#pragma unroll
+    for (int i = 0; i < C::PPW; ++i) issue_patch_piece(i, c16);
+#pragma unroll
+    for (int j = 0; j < C::APW; ++j) issue_w_piece(j, c16, cb, 0);
+#pragma unroll
+    for (int j = 0; j < C::APW; ++j) issue_w_piece(j, c16, cb, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     H2_BAR();
     convert(0);
     H2_BAR();
-    if (nc16 > 1) {
+    if (g0 + 1 < g1) {
+        if (tile1 != tile) patch_tile(tile1);
 #pragma unroll
-        for (int i = 0; i < C::PPW; ++i) issue_patch_piece(i, 1);
+        for (int i = 0; i < C::PPW; ++i) issue_patch_piece(i, c1);
     }
     Frags cur, nxt;
 #pragma unroll
     for (int i = 0; i < NL; ++i) load_i(cur, i, 0, 0, 0);
-    const bool cv_first = wave < 4;          // which of the taps 1 / 2 of part (c, 1) carries this wave's share of the split
 
     // One tap = NM issue slots: matrix instruction i, then ONE other instruction group (a fragment fetch of the next tap, a
     // fetch piece, a piece of the split) that issues while the matrix pipe works.
-    auto tap = [&](auto Rc, auto DXc, int c16, int buf, bool more) {
+    auto tap = [&](auto Rc, auto DXc, int g, int buf, bool more) {
         constexpr int R = decltype(Rc)::value, DX = decltype(DXc)::value;
         constexpr int NR = DX < 2 ? R : (R + 1) % 3, NDX = (DX + 1) % 3;
         const int nbuf = (R == 2 && DX == 2) ? (buf ^ 1) : buf;
         const bool do_load = !(R == 2 && DX == 2) || more;
-        const bool do_cv = R == 1 && DX >= 1 && more && !(ABL & 16) && ((DX == 1) == cv_first);
-        constexpr int NEX = (R == 1 && DX >= 1) ? NITJ + 1 : (DX == 0) ? C::APW : (R == 2 && DX == 1) ? C::PPW : 0;
+        // (giving the two waves of a SIMD their fetch pieces / share of the split in different taps was measured: 3 % slower)
+        constexpr bool mine0 = DX == 0;      // weight pieces
+        constexpr bool mine1 = DX == 1;      // patch pieces (R = 2), split (R = 1)
+        const bool do_cv = R == 1 && mine1 && more && !(ABL & 16);
+        const bool do_w = DX <= 1 && mine0 && (R == 0 || more);
+        const bool do_p = R == 2 && DX >= 1 && mine1 && g + 2 < g1;
+        constexpr int NEXA = DX == 0 ? C::APW : 0;
+        constexpr int NEXB = DX == 1 ? (R == 1 ? NITJ + 1 : R == 2 ? C::PPW : 0) : 0;
+        constexpr int NEX = NEXA > NEXB ? NEXA : NEXB;
         constexpr int NSLOT = NM > NL + NEX ? NM : NL + NEX;
         f32x4 cvv[2];
+        if (do_p && c2 == 0) patch_tile(tile2);
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
             if (i < NM) mfma_i(cur, i);
@@ -253,16 +415,14 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
                 if (do_load) load_i(nxt, i, nbuf, NR, NDX);
             } else {
                 const int e = i - NL;
-                if (DX == 0 && e < C::APW) {
-                    if (R == 0) issue_w_piece(e, c16, 2);
-                    else if (more) issue_w_piece(e, c16 + 1, R - 1);
-                } else if (R == 2 && DX == 1 && e < C::PPW) {
-                    if (c16 + 2 < nc16) issue_patch_piece(e, c16 + 2);
-                } else if (R == 1 && DX >= 1 && e <= NITJ) {
-                    if (do_cv) {
-                        if (e >= 1) cv_write(e - 1, buf ^ 1, cvv[(e - 1) & 1]);
-                        if (e < NITJ) cvv[e & 1] = cv_read(e);
-                    }
+                if (DX <= 1 && e < C::APW && do_w) {
+                    if (R == 0) issue_w_piece(e, c16, cb, 2);
+                    else issue_w_piece(e, c1, cb1, R - 1);
+                }
+                if (R == 2 && DX >= 1 && e < C::PPW && do_p) issue_patch_piece(e, c2);
+                if (R == 1 && DX >= 1 && e <= NITJ && do_cv) {
+                    if (e >= 1) cv_write(e - 1, buf ^ 1, cvv[(e - 1) & 1]);
+                    if (e < NITJ) cvv[e & 1] = cv_read(e);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -270,55 +430,63 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         cur = nxt;
     };
 
-    for (int c16 = 0; c16 < nc16; ++c16) {
-        const int buf = c16 & 1;
-        const bool more = c16 + 1 < nc16;
-        // part (c16, 0): this wave's pieces of part (c16, 1) have landed (the patch pieces behind them may be in flight) ...
-        if (more) {
+    const bool head_is_second_piece = c16 != 0;      // the range starts inside a tile
+    bool first_piece = true;                          // ... and that tile's piece is still the current one
+    bool drain = false;                               // output stores of the previous piece may be in flight
+    for (int g = g0; g < g1; ++g) {
+        const int buf = (g - g0) & 1;
+        const bool more = g + 1 < g1;
+        // part (g, 0): this wave's pieces of part (g, 1) have landed (the patch pieces behind them may be in flight; stores and
+        // fetches retire out of order with each other, so behind an epilogue everything is waited for) ...
+        unsigned long long tk0 = (ABL & 2048) ? __builtin_readcyclecounter() : 0;
+        if (more && !drain) {
             if (C::PPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             static_assert(C::PPW == 3 || C::PPW == 5, "vmcnt immediates");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        drain = false;
+        if (ABL & 2048) { const unsigned long long tk1 = __builtin_readcyclecounter(); tk_wait += tk1 - tk0; tk0 = tk1; }
         H2_BAR();                          // ... everybody's; every wave is done with slot 2
-        tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, c16, buf, more);
-        tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, c16, buf, more);
-        tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, c16, buf, more);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // part (c16, 2) and the patch of c16 + 1
+        if (ABL & 2048) tk_bar += __builtin_readcyclecounter() - tk0;
+        tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, g, buf, more);
+        tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, g, buf, more);
+        tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, g, buf, more);
+        if (ABL & 2048) tk0 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // part (g, 2) and the patch of g + 1
+        if (ABL & 2048) { const unsigned long long tk1 = __builtin_readcyclecounter(); tk_wait += tk1 - tk0; tk0 = tk1; }
         H2_BAR();
-        tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, c16, buf, more);
-        tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, c16, buf, more);
-        tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, c16, buf, more);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // part (c16 + 1, 0)
+        if (ABL & 2048) tk_bar += __builtin_readcyclecounter() - tk0;
+        tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, g, buf, more);
+        tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, g, buf, more);
+        tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, g, buf, more);
+        if (ABL & 2048) tk0 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // part (g + 1, 0)
+        if (ABL & 2048) { const unsigned long long tk1 = __builtin_readcyclecounter(); tk_wait += tk1 - tk0; tk0 = tk1; }
         H2_BAR();
-        tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, c16, buf, more);
-        tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, c16, buf, more);
-        tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, c16, buf, more);
+        if (ABL & 2048) tk_bar += __builtin_readcyclecounter() - tk0;
+        tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, g, buf, more);
+        tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, g, buf, more);
+        tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, g, buf, more);
+        // end of a piece: the tile's last stage, or the range's
+        const bool tile_end = c16 == nc16 - 1;
+        if (tile_end || !more) {
+            if (ABL & 2048) tk0 = __builtin_readcyclecounter();
+            if (tile_end) finish(tile, (first_piece && head_is_second_piece) ? 1 : 0, false);
+            else finish(tile, 0, true);
+            zero_acc();
+            drain = true;
+            first_piece = false;
+            if (ABL & 2048) tk_fin += __builtin_readcyclecounter() - tk0;
+        }
+        step(tile, c16, &cb);
+        step(tile1, c1, &cb1);
+        step(tile2, c2, nullptr);
     }
-    // ---- epilogue: y = hh + 2^-11 cross + bias, leaky-relu; lane = (pixel column ln, couts (r & 3) + 8 (r >> 2) + 4 kh of a tile)
-    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.y + (size_t)n * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-        const int py = ry + d * (y0 + PT * pg + pt), px = rx + d * (x0 + ln);
-        const bool inside = py < a.H && px < a.W;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int co = n0 + (CT * cgw + ct) * 32 + 8 * q + 4 * kh;
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + co);
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = acc[ct][pt][4 * q + e] + accx[ct][pt][4 * q + e] * (1.f / 2048.f) + b4[e];
-                if (a.apply_act) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], o[e] * a.slope);
-                }
-                const unsigned vo = inside ? (unsigned)(((py * a.W + px) * a.y_cs + co) * 4) : H2_OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, (int)vo, 0, 0);
-            }
+    if ((ABL & 2048) && a.dbg && lane == 0) {
+        unsigned* o = a.dbg + (lw * 8 + wave) * 4;
+        o[0] = (unsigned)(__builtin_readcyclecounter() - tk_start); o[1] = (unsigned)tk_wait; o[2] = (unsigned)tk_bar; o[3] = (unsigned)tk_fin;
     }
 #undef H2_BAR
 }
@@ -388,8 +556,8 @@ static inline long h2_blocks(int v, int N, int hs, int ws, int Cout, int dilatio
     const H2Variant t = h2_variant(v);
     return (long)N * dilation * dilation * ((ws + 31) / 32) * ((hs + t.rows - 1) / t.rows) * (Cout / t.couts);
 }
-// The variant whose launch is estimated shortest: rounds of 256 workgroups x (matrix instructions per tap and wave + 3.6), the
-// 3.6 being the measured fixed part of a tap (profiles/r04_exp_h2.txt: 52 / 40.5 / 34 us per round of 8 stages for 12 / 9 / 6).
+// The variant whose launch is estimated shortest: tiles per CU x (matrix instructions per tap and wave + 3.6), the 3.6 being
+// the measured fixed part of a tap (profiles/r04_exp_h2.txt: 52 / 40.5 / 34 us per round of 8 stages for 12 / 9 / 6).
 static int h2_plan(int N, int H, int W, int Cin_phys, int Cout, int dilation, long* blocks_out) {
     if (N <= 0 || H <= 0 || W <= 0 || dilation < 1 || Cin_phys < 16 || (Cin_phys % 16) || Cout < 32 || (Cout % 32)) return 0;
     const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
@@ -401,7 +569,7 @@ static int h2_plan(int N, int H, int W, int Cin_phys, int Cout, int dilation, lo
         if (Cout % t.couts) continue;
         const long nb = h2_blocks(v, N, hs, ws, Cout, dilation);
         if (nb >= (1L << 31)) continue;
-        const double cost = (double)((nb + 255) / 256) * (t.nm + 3.6);
+        const double cost = (nb <= 256 ? 1.0 : (double)nb / 256.0) * (t.nm + 3.6);      // stream-K: no rounding up to whole rounds
         if (!best || cost < best_cost) { best = v; best_cost = cost; best_blocks = nb; }
     }
     if (blocks_out) *blocks_out = best_blocks;
@@ -418,54 +586,93 @@ extern "C" int pwc_conv3x3_h2_supported(int N, int H, int W, int Cin_phys, int C
     return hs >= 8 && ws >= 24 && nb >= 192 && Cin_phys >= 48 ? 1 : 0;
 }
 
+static unsigned* h2_debug_counters = nullptr;      // harness only
+
+static int h2_cu_count() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
 template <int CT, int PT, int WCG, int ABL>
-static int h2_launch(H2Args& a, int hs, int ws, hipStream_t stream) {
+static int h2_launch(H2Args& a, int hs, int ws, float* workspace, size_t workspace_floats, hipStream_t stream) {
     typedef H2Cfg<CT, PT, WCG> C;
     a.tiles_x = (ws + 31) / 32; a.tiles_y = (hs + C::TR - 1) / C::TR; a.ncb = a.Cout / (32 * C::NCT);
     const long nblk = (long)a.N * a.dil * a.dil * a.tiles_x * a.tiles_y * a.ncb;
-    if (nblk >= (1L << 31)) return PWC_ERANGE;
+    if (nblk * (a.Cin_phys >> 4) >= (1L << 31)) return PWC_ERANGE;
     a.ntiles = (int)nblk;
+    // one workgroup per tile, or -- with a workspace and more tiles than CUs -- one workgroup per CU, each with an equal share
+    // of the (tile, stage) sequence
+    const int cus = h2_cu_count();
+    int grid = a.ntiles;
+    a.ws_partial = nullptr;
+    const size_t part = (size_t)C::NCT * 32 * C::TR * 32;
+    if (workspace && a.ntiles > cus && workspace_floats >= (size_t)cus * part) {
+        grid = cus;
+        a.ws_partial = workspace;
+    }
     static PwcDevOnce attr_once;
     if (pwc_first_on_device(&attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2_kernel<CT, PT, WCG, ABL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     }
-    hipLaunchKernelGGL((conv3x3_h2_kernel<CT, PT, WCG, ABL>), dim3((unsigned)a.ntiles), dim3(512), C::LDS, stream, a);
+    hipLaunchKernelGGL((conv3x3_h2_kernel<CT, PT, WCG, ABL>), dim3((unsigned)grid), dim3(512), C::LDS, stream, a);
     return pwc_launch_status();
 }
 
 // variant 0 = h2_plan's choice
 template <int ABL = 0>
 static int h2_run(const float* x, int x_cs, const float* packed_w, const float* bias, float* y, int y_cs, int N, int H, int W,
-                  int Cin_phys, int Cout, int dilation, int apply_act, float slope, pwc_stream_t stream, int variant = 0) {
+                  int Cin_phys, int Cout, int dilation, int apply_act, float slope, pwc_stream_t stream, int variant = 0,
+                  float* workspace = nullptr, size_t workspace_floats = 0) {
     if (!x || !packed_w || !bias || !y) return PWC_EINVAL;
     if (N <= 0 || H <= 0 || W <= 0 || Cin_phys <= 0 || Cout <= 0 || dilation < 1) return PWC_EINVAL;
     if (Cin_phys % 16 || Cout % 32) return PWC_EUNSUPPORTED;
     if (x_cs < Cin_phys || y_cs < Cout) return PWC_EINVAL;
-    if ((x_cs & 3) || (y_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(y) || !pwc_aligned16(packed_w) || !pwc_aligned16(bias))
+    if ((x_cs & 3) || (y_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(y) || !pwc_aligned16(packed_w) || !pwc_aligned16(bias) ||
+        !pwc_aligned16(workspace))
         return PWC_EALIGN;
     if ((long)H * W * x_cs * 4 >= (long)H2_OOB || (long)H * W * y_cs * 4 >= (long)H2_OOB) return PWC_ERANGE;
     H2Args a;
     a.x = x; a.wp = packed_w; a.bias = bias; a.y = y; a.x_cs = x_cs; a.y_cs = y_cs;
     a.N = N; a.H = H; a.W = W; a.Cin_phys = Cin_phys; a.Cout = Cout; a.apply_act = apply_act; a.slope = slope;
     a.dil = dilation;
+    a.dbg = h2_debug_counters;
     const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
     if (variant == 0) variant = h2_plan(N, H, W, Cin_phys, Cout, dilation, nullptr);
     if (variant < 1 || variant > 5) return PWC_EUNSUPPORTED;
     if (Cout % h2_variant(variant).couts) return PWC_EUNSUPPORTED;
     switch (variant) {
-        case 1: return h2_launch<2, 2, 2, ABL>(a, hs, ws, (hipStream_t)stream);
-        case 2: return h2_launch<2, 2, 1, ABL>(a, hs, ws, (hipStream_t)stream);
-        case 3: return h2_launch<3, 1, 1, ABL>(a, hs, ws, (hipStream_t)stream);
-        case 4: return h2_launch<1, 2, 1, ABL>(a, hs, ws, (hipStream_t)stream);
-        default: return h2_launch<1, 2, 2, ABL>(a, hs, ws, (hipStream_t)stream);
+        case 1: return h2_launch<2, 2, 2, ABL>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);
+        case 2: return h2_launch<2, 2, 1, ABL>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);
+        case 3: return h2_launch<3, 1, 1, ABL>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);
+        case 4: return h2_launch<1, 2, 1, ABL>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);
+        default: return h2_launch<1, 2, 2, ABL>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);
     }
+}
+
+// Workspace of the stream-K form: one partial tile per CU, every word 0xFFFFFFFF before the first launch that uses the buffer
+// (every launch leaves it so).  0 where the launch has no more tiles than CUs (no workspace is used).
+extern "C" size_t pwc_conv3x3_h2_workspace_floats(int N, int H, int W, int Cin_phys, int Cout, int dilation) {
+    long nb = 0;
+    const int v = h2_plan(N, H, W, Cin_phys, Cout, dilation, &nb);
+    const int cus = h2_cu_count();
+    if (!v || nb <= cus) return 0;
+    const H2Variant t = h2_variant(v);
+    return (size_t)cus * t.couts * t.rows * 32;
 }
 
 extern "C" int pwc_conv3x3_h2_f32(const float* x, int x_cs, const float* packed_w, const float* bias, float* y,
                                   int y_cs, int N, int H, int W, int Cin_phys, int Cout, int dilation,
-                                  int apply_act, float slope, pwc_stream_t stream) {
-    return h2_run<0>(x, x_cs, packed_w, bias, y, y_cs, N, H, W, Cin_phys, Cout, dilation, apply_act, slope, stream);
+                                  int apply_act, float slope, float* workspace, size_t workspace_floats, pwc_stream_t stream) {
+    return h2_run<0>(x, x_cs, packed_w, bias, y, y_cs, N, H, W, Cin_phys, Cout, dilation, apply_act, slope, stream, 0,
+                     workspace, workspace_floats);
 }
 
 // The tile variant pwc_conv3x3_h2_f32 uses for a shape (1 - 5, see h2_variant; 0 = none fits), and the same convolution with
@@ -476,7 +683,9 @@ extern "C" int pwc_conv3x3_h2_plan(int N, int H, int W, int Cin_phys, int Cout, 
 
 extern "C" int pwc_conv3x3_h2_variant_f32(const float* x, int x_cs, const float* packed_w, const float* bias, float* y,
                                           int y_cs, int N, int H, int W, int Cin_phys, int Cout, int dilation,
-                                          int apply_act, float slope, int variant, pwc_stream_t stream) {
+                                          int apply_act, float slope, int variant, float* workspace, size_t workspace_floats,
+                                          pwc_stream_t stream) {
     if (variant < 1 || variant > 5) return PWC_EINVAL;
-    return h2_run<0>(x, x_cs, packed_w, bias, y, y_cs, N, H, W, Cin_phys, Cout, dilation, apply_act, slope, stream, variant);
+    return h2_run<0>(x, x_cs, packed_w, bias, y, y_cs, N, H, W, Cin_phys, Cout, dilation, apply_act, slope, stream, variant,
+                     workspace, workspace_floats);
 }

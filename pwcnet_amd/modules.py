@@ -262,9 +262,15 @@ class _ConvRunner:
                                                      cin, x.C, cout, _p(packed.data_ptr()), s), "conv3x3 h2 pack")
                 cache[key] = packed
             _keep(packed, y_t)
+            # more tiles than CUs: one workgroup per CU with an equal share of the (tile, stage) sequence (stream-K)
+            wsf = L.pwc_conv3x3_h2_workspace_floats(x.N, x.H, x.W, x.C, cout, dilation)
+            ws = _h2_workspace(kern.value.device, wsf) if wsf and getattr(self.owner, "f16x2_stream_k", True) else None
+            if ws is not None:
+                _keep(ws)
             _launch(L.pwc_conv3x3_h2_f32,
                     (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
-                     x.N, x.H, x.W, x.C, cout, dilation, act, sl, s),
+                     x.N, x.H, x.W, x.C, cout, dilation, act, sl, _p(ws.data_ptr()) if ws is not None else None,
+                     ws.numel() if ws is not None else 0, s),
                     f"conv3x3_h2 {name}", "conv3x3_h2_kernel",
                     2.0 * x.N * Ho * Wo * 9 * cin * cout, 4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout),
                     # executed: three fp16 products per multiply-add, per physical input channel
@@ -391,6 +397,20 @@ def _workspace(device, want_floats):
     return ws
 
 
+_H2_WS = {}
+
+
+def _h2_workspace(device, want_floats):
+    """Caller-owned workspace of pwc_conv3x3_h2_f32's stream-K form: one per device AND stream (launches that may run
+    concurrently must not share it), every byte 0xFF when created (= "nothing published"; the kernel leaves it so)."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _H2_WS.get(key)
+    if ws is None or ws.numel() < want_floats:
+        ws = torch.full((int(want_floats),), -1, dtype=torch.int32, device=device).view(torch.float32)
+        _H2_WS[key] = ws
+    return ws
+
+
 def _wino_pays(L, N, H, W, cout, dilation):
     """Measured on MI355X (scripts/tune_conv.py --wino): the Winograd kernel wins (1.1-2.2x)
     from the 14x32 pyramid level upwards, i.e. whenever its 16x16-pixel blocks are reasonably
@@ -429,6 +449,7 @@ def _mfma_kernel_name(L, M, cout, cin_phys, tile, split):
 class _Module:
     winograd = False     # route eligible convs (stride 1, dilation 1, Cout % 32 == 0) to the Winograd kernel
     winograd4 = True     # ... and the big ones among them to the F(4x4,3x3) kernel (pwc_conv3x3_wino4_supported)
+    f16x2_stream_k = True    # ... with one workgroup per CU and an equal share of the work each where a launch has more tiles than CUs
     f16x2 = True         # the layers pwc_conv3x3_h2_supported names go to the direct F16-matrix-pipe kernel (fp32 operands as
                          # exact-to-22-bit fp16 pairs, fp32 accumulation; inputs must stay below 65504)
 

@@ -5,6 +5,7 @@
 #include "../pwcnet_amd/csrc/conv3x3_wino.hip"
 #include "../pwcnet_amd/csrc/conv3x3_h2.hip"
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 #include <cmath>
@@ -31,6 +32,8 @@ int main(int argc, char** argv) {
                       {16, 112, 256, 32, 32, 1, 32, 1.f}, {16, 56, 128, 64, 64, 1, 64, 1.f}, {16, 28, 64, 96, 96, 1, 96, 1.f}, {8, 56, 128, 128, 96, 1, 128, 1.f},
                       {8, 56, 128, 96, 64, 1, 96, 1.f}, {8, 56, 128, 64, 32, 1, 64, 1.f}, {8, 112, 256, 48, 128, 1, 48, 1.f}, {8, 28, 64, 192, 128, 1, 192, 1.f},
                       {8, 112, 256, 96, 64, 16, 96, 1.f}};
+    const size_t WSF = (size_t)304 * 32768;
+    float* wsp; (void)hipMalloc(&wsp, WSF * 4); (void)hipMemset(wsp, 0xFF, WSF * 4);
     int idx = -1;
     for (auto sh : shapes) {
         ++idx;
@@ -66,13 +69,43 @@ int main(int argc, char** argv) {
         { long nb = 0; const int pv = h2_plan(sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, &nb); printf("  plan: variant %d, %ld workgroups\n", pv, nb); if (!pv) continue; }
         rc = pwc_conv3x3_wino_f32(x, sh.xcs, u2, b, y2, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0);
         int rc4 = pwc_conv3x3_wino4_f32(x, sh.xcs, u4, b, y4, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0);
-        int rcb = pwc_conv3x3_h2_f32(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0);
+        int rcb = pwc_conv3x3_h2_f32(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, wsp, WSF, 0);
         (void)hipDeviceSynchronize();
+        {
+            std::vector<unsigned> hws(WSF);
+            (void)hipMemcpy(hws.data(), wsp, WSF * 4, hipMemcpyDeviceToHost);
+            size_t dirty = 0, byq[4] = {0, 0, 0, 0};
+            for (size_t i = 0; i < WSF; ++i) if (hws[i] != 0xFFFFFFFFu) { ++dirty; ++byq[(i / 16) & 3]; }
+            printf("  workspace after the launch: %zu words are not the sentinel (by 64-byte quarter of 256 B: %zu %zu %zu %zu)\n", dirty, byq[0], byq[1], byq[2], byq[3]);
+        }
+        {
+            unsigned* dc; (void)hipMalloc(&dc, 64); (void)hipMemset(dc, 0, 64);
+            h2_debug_counters = dc;
+            for (int rep = 0; rep < 5; ++rep) h2_run<64>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0, 0, wsp, WSF);
+            (void)hipDeviceSynchronize();
+            unsigned hc[16]; (void)hipMemcpy(hc, dc, 64, hipMemcpyDeviceToHost);
+            printf("  DEBUG exchange of a constant: wrong words by lane quarter %u %u %u %u; last wrong values %08x %08x %08x %08x; at (pt ct q) %u, expected there %08x\n", hc[0], hc[1], hc[2], hc[3], hc[4], hc[5], hc[6], hc[7], hc[8], hc[9]);
+            h2_debug_counters = nullptr; (void)hipFree(dc);
+            rcb = pwc_conv3x3_h2_f32(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, wsp, WSF, 0);
+            (void)hipDeviceSynchronize();
+        }
         printf("  launch rc: F(2x2) %d, F(4x4) %d, F(4x4) f16x2 direct %d; hip: %s\n", rc, rc4, rcb, hipGetErrorString(hipGetLastError()));
         std::vector<float> h2(npix * ycs), h4(npix * ycs), hbb(npix * ycs);
         (void)hipMemcpy(h2.data(), y2, h2.size() * 4, hipMemcpyDeviceToHost);
         (void)hipMemcpy(h4.data(), y4, h4.size() * 4, hipMemcpyDeviceToHost);
         (void)hipMemcpy(hbb.data(), yb, hbb.size() * 4, hipMemcpyDeviceToHost);
+        { size_t b2 = 0, b42 = 0; for (size_t p = 0; p < npix; ++p) for (int c = 0; c < sh.Cout; ++c) { if (fabs((double)hbb[p * ycs + c] - h2[p * ycs + c]) > 2e-4 * sh.in_scale) ++b2; if (fabs((double)h4[p * ycs + c] - h2[p * ycs + c]) > 2e-4 * sh.in_scale) ++b42; }
+          printf("  entries off by more than 2e-4: f16x2 direct vs F(2x2) %zu, F(4x4) vs F(2x2) %zu\n", b2, b42);
+          if (b2 && sh.dil == 1 && sh.Cout == 128) {
+              size_t bym7[7] = {0}, byrow[8] = {0}; int shown = 0;
+              for (size_t p = 0; p < npix; ++p) for (int c = 0; c < sh.Cout; ++c) if (fabs((double)hbb[p * ycs + c] - h2[p * ycs + c]) > 2e-4 * sh.in_scale) {
+                  const int n = (int)(p / ((size_t)sh.H * sh.W)), yy = (int)((p / sh.W) % sh.H), xx = (int)(p % sh.W);
+                  const int tile = (n * ((sh.H + 7) / 8) + yy / 8) * ((sh.W + 31) / 32) + xx / 32;
+                  ++bym7[tile % 7]; ++byrow[yy % 8];
+                  if (shown < 8 && c == 0) { printf("    bad tile %d (n %d y %d x %d): got %.6f want %.6f\n", tile, n, yy, xx, hbb[p * ycs + c], h2[p * ycs + c]); ++shown; }
+              }
+              printf("    bad by tile %% 7:"); for (int i = 0; i < 7; ++i) printf(" %zu", bym7[i]); printf("   by row %% 8:"); for (int i = 0; i < 8; ++i) printf(" %zu", byrow[i]); printf("\n");
+          } }
         double md = 0, mx = 0, mpad = 0; size_t bad = 0, nan = 0;
         size_t hy[16] = {0}, hxm[32] = {0}, hc[8] = {0};
         const double tol = 2e-4 * sh.in_scale;
@@ -121,14 +154,15 @@ int main(int argc, char** argv) {
         for (int round = 0; round < 2; ++round) {
             const float t2 = time_us([&](int) { pwc_conv3x3_wino_f32(x, sh.xcs, u2, b, y2, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10);
             const float t4 = time_us([&](int) { pwc_conv3x3_wino4_f32(x, sh.xcs, u4, b, y4, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10);
-            const float tb = time_us([&](int) { pwc_conv3x3_h2_f32(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10);
+            const float tb = time_us([&](int) { pwc_conv3x3_h2_f32(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, wsp, WSF, 0); }, 10);
             printf("  F(2x2) %8.1f us %6.1f TF | F(4x4) fp32 %8.1f us %6.1f TF | F(4x4) f16x2 direct %8.1f us %6.1f TF (direct-conv flops)  x%.2f vs fp32 F(4x4)\n",
                    t2, gf / t2 * 1e3, t4, gf / t4 * 1e3, tb, gf / tb * 1e3, t4 / tb);
             fflush(stdout);
         }
-        for (int v = 1; v <= 5; ++v) {
+        for (int vv = 2; vv <= 11; ++vv) {
+            const int v = vv >> 1; const bool use_ws = vv & 1;
             (void)hipMemset(yb, 0, npix * ycs * 4);
-            const int rv = h2_run<0>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0, v);
+            const int rv = h2_run<0>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0, v, use_ws ? wsp : nullptr, use_ws ? WSF : 0);
             if (rv) continue;
             (void)hipMemcpy(hbb.data(), yb, hbb.size() * 4, hipMemcpyDeviceToHost);
             double mdv = 0; size_t nanv = 0;
@@ -138,12 +172,32 @@ int main(int argc, char** argv) {
                     if (a != a) { ++nanv; continue; }
                     mdv = fmax(mdv, fabs(a - e));
                 }
-            const float tv = time_us([&](int) { h2_run<0>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0, v); }, 10);
-            printf("  variant %d: max |diff| vs fp32 F(2x2) %.3e, %zu NaN, %8.1f us %6.1f TF\n", v, mdv, nanv, tv, gf / tv * 1e3);
+            const float tv = time_us([&](int) { h2_run<0>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0, v, use_ws ? wsp : nullptr, use_ws ? WSF : 0); }, 10);
+            printf("  variant %d %s: max |diff| vs fp32 F(2x2) %.3e, %zu NaN, %8.1f us %6.1f TF\n", v, use_ws ? "stream-K    " : "tile per WG ", mdv, nanv, tv, gf / tv * 1e3);
             fflush(stdout);
         }
         if (idx == 0 || idx == 2) {
-            auto ab = [&](auto tag) { return time_us([&](int) { h2_run<decltype(tag)::value>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0); }, 10); };
+            {
+                std::vector<float> ta, tc;
+                for (int rep = 0; rep < 9; ++rep) {
+                    ta.push_back(time_us([&](int) { h2_run<0>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0, 0, wsp, WSF); }, 10));
+                    tc.push_back(time_us([&](int) { h2_run<0>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0, 0, nullptr, 0); }, 10));
+                }
+                std::sort(ta.begin(), ta.end()); std::sort(tc.begin(), tc.end());
+                printf("  medians of 9 interleaved rounds: stream-K %.1f us (min %.1f), one workgroup per tile %.1f us (min %.1f)\n", ta[4], ta[0], tc[4], tc[0]);
+            }
+            unsigned* dc; (void)hipMalloc(&dc, 256 * 8 * 16); (void)hipMemset(dc, 0, 256 * 8 * 16);
+            h2_debug_counters = dc;
+            for (int rep = 0; rep < 3; ++rep) h2_run<2048>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0, 0, wsp, WSF);
+            (void)hipDeviceSynchronize();
+            std::vector<unsigned> hc(256 * 8 * 4); (void)hipMemcpy(hc.data(), dc, hc.size() * 4, hipMemcpyDeviceToHost);
+            double st = 0, sw = 0, sb = 0, sf = 0; for (int i = 0; i < 256 * 8; ++i) { st += hc[i * 4]; sw += hc[i * 4 + 1]; sb += hc[i * 4 + 2]; sf += hc[i * 4 + 3]; }
+            printf("  s_memtime, mean over waves: kernel %.0f ticks; waiting for fetches %.0f (%.1f %%), in barriers %.0f (%.1f %%), piece ends %.0f (%.1f %%)\n", st / 2048, sw / 2048, 100 * sw / st, sb / 2048, 100 * sb / st, sf / 2048, 100 * sf / st);
+            printf("    workgroup 0: "); for (int w = 0; w < 8; ++w) printf("[%u %u %u %u] ", hc[w * 4], hc[w * 4 + 1], hc[w * 4 + 2], hc[w * 4 + 3]); printf("\n");
+            h2_debug_counters = nullptr; (void)hipFree(dc);
+        }
+        if (idx == 0 || idx == 2) {
+            auto ab = [&](auto tag) { return time_us([&](int) { h2_run<decltype(tag)::value>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0, 0, wsp, WSF); }, 10); };
             printf("  ablations: no patch DMA %.1f | no weight DMA %.1f | no DMA %.1f | no MFMA %.1f | m' = 0 %.1f | no split %.1f | no fragment reads %.1f |"
                    " no DMA, no MFMA %.1f | no MFMA, no fragment reads %.1f | MFMA only %.1f | nothing %.1f us\n",
                    ab(std::integral_constant<int, 1>{}), ab(std::integral_constant<int, 2>{}), ab(std::integral_constant<int, 3>{}),

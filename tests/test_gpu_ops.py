@@ -256,7 +256,7 @@ def test_conv_winograd_f4x4_physical_layout_and_plan(pa):
 H2_COUTS = {1: 128, 2: 64, 3: 96, 4: 32, 5: 64}
 
 
-def run_conv_h2(x, k, b, slope, cin_map=None, y_cs=None, dil=1, variant=0):
+def run_conv_h2(x, k, b, slope, cin_map=None, y_cs=None, dil=1, variant=0, ws=None):
     from pwcnet_amd import _lib
     L = _lib.lib()
     N, H, W, cs = x.shape
@@ -268,11 +268,12 @@ def run_conv_h2(x, k, b, slope, cin_map=None, y_cs=None, dil=1, variant=0):
     y_cs = cout if y_cs is None else y_cs
     y = torch.full((N, H, W, y_cs), -7.0, device="cuda")
     act, sl = (0 if slope is None else 1), (0.0 if slope is None else slope)
+    wp, wn = (None, 0) if ws is None else (_p(ws), ws.numel())
     if variant:
         _lib.check(L.pwc_conv3x3_h2_variant_f32(_p(xg), cs, _p(packed), _p(bg), _p(y), y_cs, N, H, W, cs, cout, dil, act, sl,
-                                                variant, None))
+                                                variant, wp, wn, None))
     else:
-        _lib.check(L.pwc_conv3x3_h2_f32(_p(xg), cs, _p(packed), _p(bg), _p(y), y_cs, N, H, W, cs, cout, dil, act, sl, None))
+        _lib.check(L.pwc_conv3x3_h2_f32(_p(xg), cs, _p(packed), _p(bg), _p(y), y_cs, N, H, W, cs, cout, dil, act, sl, wp, wn, None))
     torch.cuda.synchronize()
     return y
 
@@ -312,11 +313,41 @@ def test_conv_f16x2_direct_full_size_vs_oracle(pa, cin, cout, dil):
     x = rnd((N, H, W, cin), 281)
     k = rnd((3, 3, cin, cout), 282) * float(1.0 / np.sqrt(9 * cin))
     b = rnd((cout,), 283) * 0.1
-    y = run_conv_h2(x, k, b, 0.1, y_cs=cout + 16, dil=dil)
+    y = run_conv_h2(x, k, b, 0.1, y_cs=cout + 16, dil=dil, ws=h2_workspace(N, H, W, cin, cout, dil))
     for i in (0, N - 1):
         close(y[i:i + 1, ..., :cout], orc.conv3x3(x[i:i + 1], k, b, 1, dil, 0.1))
     assert bool(torch.isfinite(y).all())
     assert float(y[..., cout:].min()) == -7.0 and float(y[..., cout:].max()) == -7.0
+
+
+def h2_workspace(N, H, W, cs, cout, dil):
+    from pwcnet_amd import _lib
+    n = _lib.lib().pwc_conv3x3_h2_workspace_floats(N, H, W, cs, cout, dil)
+    return None if n == 0 else torch.full((n,), -1, dtype=torch.int32, device="cuda").view(torch.float32)
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,dil", [(8, 112, 256, 128, 128, 1), (8, 112, 256, 64, 32, 1), (3, 112, 250, 96, 96, 2),
+                                               (5, 100, 256, 48, 64, 1), (2, 224, 512, 32, 128, 4)])
+def test_conv_f16x2_direct_stream_k(pa, N, H, W, cin, cout, dil):
+    """More tiles than CUs + a workspace: one workgroup per CU, each with an equal share of the (tile, stage) sequence; tiles
+    cut in two are finished through the workspace.  Ten launches must agree BITWISE (the sum of two finished pieces does
+    not depend on which workgroup is faster), match the one-workgroup-per-tile launch to fp32 rounding and the oracle on
+    the first and the last image, and leave the workspace as they found it (every word 0xFFFFFFFF)."""
+    x = rnd((N, H, W, cin), 291)
+    k = rnd((3, 3, cin, cout), 292) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 293) * 0.1
+    ws = h2_workspace(N, H, W, cin, cout, dil)
+    assert ws is not None
+    plain = run_conv_h2(x, k, b, 0.1, dil=dil)
+    first = run_conv_h2(x, k, b, 0.1, dil=dil, ws=ws)
+    for _ in range(9):
+        again = run_conv_h2(x, k, b, 0.1, dil=dil, ws=ws)
+        assert torch.equal(first, again)
+    assert bool((ws.view(torch.int32) == -1).all())
+    scale = float(plain.abs().max())
+    assert float((first - plain).abs().max()) <= 2e-6 * scale
+    for i in (0, N - 1):
+        close(first[i:i + 1], orc.conv3x3(x[i:i + 1], k, b, 1, dil, 0.1))
 
 
 def test_conv_f16x2_direct_physical_layout_range_and_plan(pa):
