@@ -50,6 +50,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 chip peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense F16 matrix peak (v_mfma_f32_32x32x16_f16: 32 cycles per instruction and SIMD at 2.4 GHz)
+# the matrix pipe each MFMA kernel runs on
+KERNEL_PEAK = {"conv3x3_h2_kernel": PEAK_F16_MFMA_TFLOPS}
+
+
+def peak_of(kernel):
+    return KERNEL_PEAK.get(kernel, PEAK_F32_MFMA_TFLOPS)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 
 CONFIGS = {
@@ -346,6 +353,10 @@ def main():
             "gpus_from": ("--gpus" if getattr(args, "gpus_given", True) or not args.config
                           else f"implied by --config {args.config}"),
             "streams": eff_streams,
+            "conv3x3_arithmetic": ("fp32 tensors throughout; the big stride-1 layers (pwc_conv3x3_h2_supported) form each fp32 "
+                                   "product from exact-to-22-bit fp16 operand pairs on the F16 matrix pipe with fp32 accumulation "
+                                   "(more accurate than an fp32 MFMA chain, tolerances unchanged; PWCDCNet(f16x2=False) = fp32 "
+                                   "MFMA everywhere), the rest run on v_mfma_f32_16x16x4_f32"),
             "side_streams": (None if ss_report is None else
                              {"verdict": ss_report.get("verdict"), "picked": len(ss_report.get("picked", [])),
                               "rejected": ss_report.get("rejected"), "probes": len(ss_report.get("probes", []))}),
@@ -367,8 +378,8 @@ def main():
         dd = summ[dominant]
         alg = dd["flops"] / (dd["ms"] * 1e-3) / 1e12
         exe = dd["exec_flops"] / (dd["ms"] * 1e-3) / 1e12
-        roof = {"kernel": dominant, "bound": "mfma", "achieved": exe, "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": exe / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+        roof = {"kernel": dominant, "bound": "mfma", "achieved": exe, "peak": peak_of(dominant),
+                "unit": "TFLOP/s", "frac": exe / peak_of(dominant), "traffic": None,
                 "avg_launch_us": 1e3 * dd["ms"] / dd["launches"],
                 "launches_per_step": dd["launches"] / n_sampled,
                 "flops_per_launch": dd["exec_flops"] / dd["launches"],
@@ -377,8 +388,18 @@ def main():
                 "algorithmic_over_executed": dd["flops"] / dd["exec_flops"],
                 "measured": where,
                 "note": "achieved/frac = multiply-adds the MFMA units execute (Winograd: 16 per 2x2 outputs "
-                        "and 36 per 4x4 outputs instead of 9 per output, physical Cin); algorithmic_* = "
+                        "and 36 per 4x4 outputs instead of 9 per output, physical Cin; conv3x3_h2_kernel: three fp16 "
+                        "products per fp32 multiply-add, on the F16 pipe, against the dense F16 peak); algorithmic_* = "
                         "2*M*9*Cin*Cout of the direct convolution the launch replaces (SURVEY.md 8d)"}
+        if dominant == "conv3x3_h2_kernel":
+            roof["arithmetic"] = ("fp32 in / fp32 out / fp32 accumulation; every operand as h + 2^-11 m' (h = fp16(x), m' = "
+                                  "fp16((x - h) 2^11)), products uh vh + 2^-11 (uh vm' + um' vh) on v_mfma_f32_32x32x16_f16: "
+                                  "error 0.1x that of the fp32 F(4x4) kernel it replaces (profiles/r04_exp_h2.txt)")
+            roof["sustained_matrix_rate"] = {
+                "frac_of_peak": 0.65,
+                "why": "a loop of nothing but v_mfma_f32_32x32x16_f16 on random operands, two waves per SIMD on all 256 CUs, runs "
+                       "at 493 ns per 24 instructions = 1.6 PFLOP/s (350 ns on all-zero operands): the clock drops under the "
+                       "matrix pipe's load (profiles/r04_exp_h2_micro.txt); frac against THAT rate = frac / 0.65"}
         caps = {"conv3x3_wino_kernel": 0.83, "conv3x3_wino4_kernel": 0.62}
         if dominant in caps:
             roof["instruction_mix_cap"] = {
@@ -388,7 +409,7 @@ def main():
                        "7 N_dma) of the kernel's main loop (DESIGN.md 3.4)"}
         total_ms = sum(v["ms"] for v in summ.values())
         roof["other_mfma_kernels"] = {
-            k: {"frac": v["exec_flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            k: {"frac": v["exec_flops"] / (v["ms"] * 1e-3) / 1e12 / peak_of(k), "peak": peak_of(k),
                 "algorithmic_tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                 "avg_launch_us": 1e3 * v["ms"] / v["launches"], "launches_per_step": v["launches"] / n_sampled,
                 "share_of_kernel_time": v["ms"] / total_ms}

@@ -396,18 +396,22 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         constexpr int NR = DX < 2 ? R : (R + 1) % 3, NDX = (DX + 1) % 3;
         const int nbuf = (R == 2 && DX == 2) ? (buf ^ 1) : buf;
         const bool do_load = !(R == 2 && DX == 2) || more;
-        // (giving the two waves of a SIMD their fetch pieces / share of the split in different taps was measured: 3 % slower)
-        constexpr bool mine0 = DX == 0;      // weight pieces
-        constexpr bool mine1 = DX == 1;      // patch pieces (R = 2), split (R = 1)
-        const bool do_cv = R == 1 && mine1 && more && !(ABL & 16);
-        const bool do_w = DX <= 1 && mine0 && (R == 0 || more);
-        const bool do_p = R == 2 && DX >= 1 && mine1 && g + 2 < g1;
-        constexpr int NEXA = DX == 0 ? C::APW : 0;
-        constexpr int NEXB = DX == 1 ? (R == 1 ? NITJ + 1 : R == 2 ? C::PPW : 0) : 0;
-        constexpr int NEX = NEXA > NEXB ? NEXA : NEXB;
+        // Placement of the fetch pieces, measured with per-tap s_memtime stamps (profiles/r04_exp_h2_tap_timeline*.txt): all weight
+        // pieces in the first tap of a part and the patch pieces in tap (2, 1) -- spreading them one per tap takes the landing slack
+        // away (7 % of the time waiting for fetches, 184 vs 179 us), giving the two waves of a SIMD different taps or only one of
+        // them the pieces moves the delay between the waves without shortening the part (176 - 182 us), as does s_setprio.
+        constexpr bool SPREAD = false;
+        const bool do_cv = R == 1 && DX == 1 && more && !(ABL & 16);
+        const bool do_w = R == 0 || more;
+        const bool do_p = R == 2 && g + 2 < g1;
+        constexpr int PP0 = C::PPW == 3 ? DX : 2 * DX, PP1 = C::PPW == 3 ? DX + 1 : (DX == 2 ? 5 : 2 * DX + 2);   // patch pieces of this tap
+        constexpr int NEXA = SPREAD ? (DX < C::APW ? 1 : 0) : (DX == 0 ? C::APW : 0);
+        constexpr int NEXP = R == 2 ? (SPREAD ? PP1 - PP0 : (DX == 1 ? C::PPW : 0)) : 0;
+        constexpr int NEXC = (R == 1 && DX == 1) ? NITJ + 1 : 0;
+        constexpr int NEX = NEXA + NEXP > NEXC ? NEXA + NEXP : NEXC;
         constexpr int NSLOT = NM > NL + NEX ? NM : NL + NEX;
         f32x4 cvv[2];
-        if (do_p && c2 == 0) patch_tile(tile2);
+        if (do_p && c2 == 0 && (SPREAD ? DX == 0 : DX == 1)) patch_tile(tile2);
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
             if (i < NM) mfma_i(cur, i);
@@ -415,12 +419,13 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
                 if (do_load) load_i(nxt, i, nbuf, NR, NDX);
             } else {
                 const int e = i - NL;
-                if (DX <= 1 && e < C::APW && do_w) {
-                    if (R == 0) issue_w_piece(e, c16, cb, 2);
-                    else issue_w_piece(e, c1, cb1, R - 1);
+                if (e < NEXA && do_w) {
+                    const int j = SPREAD ? DX : e;
+                    if (R == 0) issue_w_piece(j, c16, cb, 2);
+                    else issue_w_piece(j, c1, cb1, R - 1);
                 }
-                if (R == 2 && DX >= 1 && e < C::PPW && do_p) issue_patch_piece(e, c2);
-                if (R == 1 && DX >= 1 && e <= NITJ && do_cv) {
+                if (e >= NEXA && e < NEXA + NEXP && do_p) issue_patch_piece(SPREAD ? PP0 + (e - NEXA) : e - NEXA, c2);
+                if (NEXC && e <= NITJ && do_cv) {
                     if (e >= 1) cv_write(e - 1, buf ^ 1, cvv[(e - 1) & 1]);
                     if (e < NITJ) cvv[e & 1] = cv_read(e);
                 }
@@ -433,16 +438,21 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     const bool head_is_second_piece = c16 != 0;      // the range starts inside a tile
     bool first_piece = true;                          // ... and that tile's piece is still the current one
     bool drain = false;                               // output stores of the previous piece may be in flight
+#define H2_STAMP(k) do { if ((ABL & 4096) && a.dbg && lane == 0 && (lw == 0 || lw == 5) && g - g0 >= 8 && g - g0 < 12) \
+        a.dbg[(((lw ? 1 : 0) * 8 + wave) * 4 + (g - g0 - 8)) * 16 + (k)] = (unsigned)__builtin_readcyclecounter(); } while (0)
     for (int g = g0; g < g1; ++g) {
         const int buf = (g - g0) & 1;
         const bool more = g + 1 < g1;
         // part (g, 0): this wave's pieces of part (g, 1) have landed (the patch pieces behind them may be in flight; stores and
         // fetches retire out of order with each other, so behind an epilogue everything is waited for) ...
         unsigned long long tk0 = (ABL & 2048) ? __builtin_readcyclecounter() : 0;
+        H2_STAMP(0);
         if (more && !drain) {
-            if (C::PPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            // patch pieces issued behind the last weight piece of part (g - 1, 2)
+            constexpr int BEHIND = C::PPW;
+            static_assert((C::PPW == 3 || C::PPW == 5) && C::APW >= 1 && C::APW <= 3, "vmcnt immediates");
+            if (BEHIND == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            static_assert(C::PPW == 3 || C::PPW == 5, "vmcnt immediates");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -450,25 +460,37 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         if (ABL & 2048) { const unsigned long long tk1 = __builtin_readcyclecounter(); tk_wait += tk1 - tk0; tk0 = tk1; }
         H2_BAR();                          // ... everybody's; every wave is done with slot 2
         if (ABL & 2048) tk_bar += __builtin_readcyclecounter() - tk0;
+        H2_STAMP(1);
         tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, g, buf, more);
+        H2_STAMP(2);
         tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, g, buf, more);
+        H2_STAMP(3);
         tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, g, buf, more);
+        H2_STAMP(4);
         if (ABL & 2048) tk0 = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // part (g, 2) and the patch of g + 1
         if (ABL & 2048) { const unsigned long long tk1 = __builtin_readcyclecounter(); tk_wait += tk1 - tk0; tk0 = tk1; }
         H2_BAR();
         if (ABL & 2048) tk_bar += __builtin_readcyclecounter() - tk0;
+        H2_STAMP(5);
         tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, g, buf, more);
+        H2_STAMP(6);
         tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, g, buf, more);
+        H2_STAMP(7);
         tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, g, buf, more);
+        H2_STAMP(8);
         if (ABL & 2048) tk0 = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // part (g + 1, 0)
         if (ABL & 2048) { const unsigned long long tk1 = __builtin_readcyclecounter(); tk_wait += tk1 - tk0; tk0 = tk1; }
         H2_BAR();
         if (ABL & 2048) tk_bar += __builtin_readcyclecounter() - tk0;
+        H2_STAMP(9);
         tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, g, buf, more);
+        H2_STAMP(10);
         tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, g, buf, more);
+        H2_STAMP(11);
         tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, g, buf, more);
+        H2_STAMP(12);
         // end of a piece: the tile's last stage, or the range's
         const bool tile_end = c16 == nc16 - 1;
         if (tile_end || !more) {
@@ -489,6 +511,7 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         o[0] = (unsigned)(__builtin_readcyclecounter() - tk_start); o[1] = (unsigned)tk_wait; o[2] = (unsigned)tk_bar; o[3] = (unsigned)tk_fin;
     }
 #undef H2_BAR
+#undef H2_STAMP
 }
 
 // ---------------------------------------------------------------- weight split + packing

@@ -194,6 +194,16 @@ int main(int argc, char** argv) {
             double st = 0, sw = 0, sb = 0, sf = 0; for (int i = 0; i < 256 * 8; ++i) { st += hc[i * 4]; sw += hc[i * 4 + 1]; sb += hc[i * 4 + 2]; sf += hc[i * 4 + 3]; }
             printf("  s_memtime, mean over waves: kernel %.0f ticks; waiting for fetches %.0f (%.1f %%), in barriers %.0f (%.1f %%), piece ends %.0f (%.1f %%)\n", st / 2048, sw / 2048, 100 * sw / st, sb / 2048, 100 * sb / st, sf / 2048, 100 * sf / st);
             printf("    workgroup 0: "); for (int w = 0; w < 8; ++w) printf("[%u %u %u %u] ", hc[w * 4], hc[w * 4 + 1], hc[w * 4 + 2], hc[w * 4 + 3]); printf("\n");
+            (void)hipMemset(dc, 0, 256 * 8 * 16);
+            h2_run<4096>(x, sh.xcs, ub, b, yb, ycs, sh.N, sh.H, sh.W, sh.Cin, sh.Cout, sh.dil, 1, 0.1f, 0, 0, wsp, WSF);
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(hc.data(), dc, 2 * 8 * 4 * 16 * 4, hipMemcpyDeviceToHost);
+            printf("  tap timeline (s_memtime ticks; stages 8-11 of the range; per stage: wait+barrier | taps (0,0) (0,1) (0,2) | w+b | (1,0) (1,1) (1,2) | w+b | (2,0) (2,1) (2,2))\n");
+            for (int wgi = 0; wgi < 2; ++wgi) for (int w = 0; w < 8; w += (wgi ? 4 : 1)) {
+                printf("    workgroup %d wave %d:", wgi ? 5 : 0, w);
+                for (int st = 0; st < 4; ++st) { const unsigned* q = &hc[((wgi * 8 + w) * 4 + st) * 16]; printf("  [%u | %u %u %u | %u | %u %u %u | %u | %u %u %u]", q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[6] - q[5], q[7] - q[6], q[8] - q[7], q[9] - q[8], q[10] - q[9], q[11] - q[10], q[12] - q[11]); }
+                printf("\n");
+            }
             h2_debug_counters = nullptr; (void)hipFree(dc);
         }
         if (idx == 0 || idx == 2) {
