@@ -29,13 +29,21 @@
 //   um' 8-15][cout 32][16 bytes], are a linear copy of the packed global image.  K of an MFMA = [8 channels | 8 channels] over the
 //   two lane halves, four fragments per (cout tile, pixel tile) pair:
 //     hh = UH x VH      cross = UH x VM' + UM' x VH          UH = [uh 0-7 | uh 8-15], UM' = [um' 0-7 | um' 8-15], VH, VM' alike.
-//   Pipeline: a stage is three PARTS (tap rows).  Barrier of part (c, r): every wave is done with A[r - 1] -> the weights of
-//   (c + 1, r - 1) are fetched into it (r = 0: (c, 2) into A[2]); the barrier also publishes that part (c, r + 1) has landed, so
+//   Pipeline: a stage is three PARTS (tap rows).  Barrier of part (g, r): every wave is done with A[r - 1] -> the weights of
+//   (g + 1, r - 1) are fetched into it (r = 0: (g, 2) into A[2]); the barrier also publishes that part (g, r + 1) has landed, so
 //   the fragments of the next tap are always fetched one tap ahead, across part and stage boundaries (two fragment sets in
-//   registers).  The split of stage c + 1 runs inside part (c, 1) (half the waves during tap 1, the other half during tap 2, so
-//   that the matrix pipe of every SIMD always has one wave feeding it) from S into B[(c + 1) & 1]; the patch of stage c + 2
-//   is fetched into S from the barrier of part (c, 2).  Three barriers per stage, none of them waits for a fetch issued less
-//   than one part (~2300 cycles) earlier.
+//   registers).  A tap is a sequence of issue slots: matrix instruction i, then ONE other thing (a fragment fetch of the next
+//   tap, a fetch piece, a piece of the split).  The split of stage g + 1 runs inside taps (g, 1, 1..2) from S into B[(g + 1) & 1]; the
+//   patch of stage g + 2 is fetched into S in tap (g, 2, 1).  Three barriers per stage; 1 % of the time is spent waiting for
+//   fetches.
+//   Stream-K: with a workspace and more tiles than CUs the launch is ONE workgroup per CU; the (tile, stage) sequence of the
+//   launch is dealt in equal contiguous ranges, the pipeline above runs across tile boundaries (one prologue per workgroup),
+//   and a tile cut in two is finished by the workgroup holding its first piece (finish() below).
+//   Where the time goes (profiles/r04_exp_h2.txt, r04_exp_h2_micro.txt, r04_exp_h2_tap_timeline*.txt): a loop of nothing but
+//   these matrix instructions on random data sustains 1.6 PFLOP/s (the clock drops to ~0.8 GHz under it; 2.2 PFLOP/s on zeros)
+//   = 124 us for the 128 -> 128 layer at 8 x 112 x 256; the kernel takes 180 us: a wave issues one slot per ~43 cycles, taps
+//   that carry fetch pieces or the split take 1.5 - 3.5x a plain tap on the second wave of a SIMD, and the waves of a
+//   workgroup meet at three barriers per stage (16 % of a wave's time), piece ends take 9 %.
 #pragma once
 #include "pwc_common.h"
 #include <type_traits>
@@ -172,21 +180,22 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     // t + 512 j.  cv_read / cv_write are the two halves of an item so that they can sit in different issue slots of a tap.
     constexpr int NIT = C::NREC * 4;
     constexpr int NITJ = (NIT + 511) / 512;          // 3 / 5
+    constexpr int NFULL = NIT / 512;                 // items every thread has (the last one, if any, only threads t < NIT % 512)
     auto cv_read = [&](int j) -> f32x4 {
-        const int it = t + 512 * j;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (it < NIT) v = *reinterpret_cast<const f32x4*>(sm + C::S0 + it * 16);
-        return v;
+        int it = t + 512 * j;
+        if (j >= NFULL) it = it < NIT ? it : 0;      // (any valid address: the write is what is predicated)
+        return *reinterpret_cast<const f32x4*>(sm + C::S0 + it * 16);
     };
     auto cv_write = [&](int j, int buf, const f32x4 v) {
         const int it = t + 512 * j;
-        if (it < NIT) {
+        if (j < NFULL || it < NIT) {
             const int rec = it >> 2, g = it & 3;
             pwc_f16x4 h, m;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 h[e] = (_Float16)v[e];
-                m[e] = (ABL & 8) ? (_Float16)0.f : (_Float16)((v[e] - (float)h[e]) * 2048.f);
+                // (x - h) 2^11 = x 2^11 - h 2^11, all three exact: one multiply and one mixed-precision FMA per element
+                m[e] = (ABL & 8) ? (_Float16)0.f : (_Float16)__builtin_fmaf((float)h[e], -2048.f, v[e] * 2048.f);
             }
             const int py = rec / H2_PW, px = rec - py * H2_PW;
             char* dst = sm + C::B0 + buf * C::B_BYTES + py * H2_ROWB + (g >> 1) * H2_CHK + px * 16 + (g & 1) * 8;
@@ -399,36 +408,37 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         // Placement of the fetch pieces, measured with per-tap s_memtime stamps (profiles/r04_exp_h2_tap_timeline*.txt): all weight
         // pieces in the first tap of a part and the patch pieces in tap (2, 1) -- spreading them one per tap takes the landing slack
         // away (7 % of the time waiting for fetches, 184 vs 179 us), giving the two waves of a SIMD different taps or only one of
-        // them the pieces moves the delay between the waves without shortening the part (176 - 182 us), as does s_setprio.
-        constexpr bool SPREAD = false;
-        const bool do_cv = R == 1 && DX == 1 && more && !(ABL & 16);
+        // them the pieces (waves 0-3 issuing all weight pieces: 180 vs 179 us) moves the delay between the waves without shortening
+        // the part, as does s_setprio.
         const bool do_w = R == 0 || more;
-        const bool do_p = R == 2 && g + 2 < g1;
-        constexpr int PP0 = C::PPW == 3 ? DX : 2 * DX, PP1 = C::PPW == 3 ? DX + 1 : (DX == 2 ? 5 : 2 * DX + 2);   // patch pieces of this tap
-        constexpr int NEXA = SPREAD ? (DX < C::APW ? 1 : 0) : (DX == 0 ? C::APW : 0);
-        constexpr int NEXP = R == 2 ? (SPREAD ? PP1 - PP0 : (DX == 1 ? C::PPW : 0)) : 0;
-        constexpr int NEXC = (R == 1 && DX == 1) ? NITJ + 1 : 0;
+        const bool do_p = R == 2 && DX == 1 && g + 2 < g1;
+        // the split of stage g + 1: items 0-2 in tap (1, 1), items 3-4 (16-row tiles) in tap (1, 2).  The staging reads go out in the
+        // FIRST slots of the tap, ahead of that slot's fragment fetch: LDS returns in order, so a read issued behind the tap's
+        // fragment fetches could only be waited for by draining all of them (lgkmcnt(0), three times per stage)
+        constexpr int CV0 = (R == 1 && DX == 1) ? 0 : (R == 1 && DX == 2) ? 3 : NITJ;
+        constexpr int CV1 = (R == 1 && DX == 1) ? (NITJ < 3 ? NITJ : 3) : NITJ;
+        constexpr int NEXC = CV1 - CV0;
+        const bool do_cv = NEXC > 0 && more && !(ABL & 16);
+        constexpr int NEXA = DX == 0 ? C::APW : 0;
+        constexpr int NEXP = (R == 2 && DX == 1) ? C::PPW : 0;
         constexpr int NEX = NEXA + NEXP > NEXC ? NEXA + NEXP : NEXC;
         constexpr int NSLOT = NM > NL + NEX ? NM : NL + NEX;
-        f32x4 cvv[2];
-        if (do_p && c2 == 0 && (SPREAD ? DX == 0 : DX == 1)) patch_tile(tile2);
+        f32x4 cvv[3];
+        if (do_p && c2 == 0) patch_tile(tile2);
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
             if (i < NM) mfma_i(cur, i);
+            if (i < NEXC && do_cv) cvv[i] = cv_read(CV0 + i);
             if (i < NL) {
                 if (do_load) load_i(nxt, i, nbuf, NR, NDX);
             } else {
                 const int e = i - NL;
                 if (e < NEXA && do_w) {
-                    const int j = SPREAD ? DX : e;
-                    if (R == 0) issue_w_piece(j, c16, cb, 2);
-                    else issue_w_piece(j, c1, cb1, R - 1);
+                    if (R == 0) issue_w_piece(e, c16, cb, 2);
+                    else issue_w_piece(e, c1, cb1, R - 1);
                 }
-                if (e >= NEXA && e < NEXA + NEXP && do_p) issue_patch_piece(SPREAD ? PP0 + (e - NEXA) : e - NEXA, c2);
-                if (NEXC && e <= NITJ && do_cv) {
-                    if (e >= 1) cv_write(e - 1, buf ^ 1, cvv[(e - 1) & 1]);
-                    if (e < NITJ) cvv[e & 1] = cv_read(e);
-                }
+                if (e >= NEXA && e < NEXA + NEXP && do_p) issue_patch_piece(e - NEXA, c2);
+                if (e < NEXC && do_cv) cv_write(CV0 + e, buf ^ 1, cvv[e]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -600,13 +610,13 @@ static int h2_plan(int N, int H, int W, int Cin_phys, int Cout, int dilation, lo
 }
 
 // 1 where this kernel is the faster one for the shape (measured against conv3x3_wino4.hip / conv3x3_wino.hip on isolated layers:
-// profiles/r04_exp_h2.txt): sub-lattices of at least 8 x 24 pixels, a launch that fills at least three quarters of the CUs, three or more channel stages
-// (32 -> 32 channels is a tie with F(2x2)).
+// profiles/r04_exp_h2.txt): sub-lattices of at least 8 x 24 pixels, a launch that fills at least three quarters of the CUs, two or more channel stages
+// (32 -> 32 channels at 16 x 112 x 256: 48 us against F(2x2)'s 56).
 extern "C" int pwc_conv3x3_h2_supported(int N, int H, int W, int Cin_phys, int Cout, int dilation) {
     long nb = 0;
     if (!h2_plan(N, H, W, Cin_phys, Cout, dilation, &nb)) return 0;
     const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
-    return hs >= 8 && ws >= 24 && nb >= 192 && Cin_phys >= 48 ? 1 : 0;
+    return hs >= 8 && ws >= 24 && nb >= 192 && Cin_phys >= 32 ? 1 : 0;
 }
 
 static unsigned* h2_debug_counters = nullptr;      // harness only
