@@ -209,7 +209,7 @@ int pwc_conv3x3_wino4_supported(int N, int H, int W, int Cin_phys, int Cout, int
  * r04_exp_f16x2_numerics.txt).  RANGE: inputs and weights must be below 65504 in magnitude (fp16's largest finite
  * value); a larger input makes the outputs that depend on it NaN (inf - inf in the split), never a silently wrong
  * number.  packed_w comes from pwc_conv3x3_h2_pack_f32 (split weights, pwc_conv3x3_h2_packed_floats floats; same
- * cin_map semantics as pwc_conv3x3_pack_f32).  Needs Cout % 32 == 0, Cin_phys % 16 == 0, x and y 16-byte aligned with
+ * cin_map semantics as pwc_conv3x3_pack_f32).  Needs Cout % 32 == 0, Cout <= 512, Cin_phys % 16 == 0, x and y 16-byte aligned with
  * x_cs % 4 == 0 and y_cs % 4 == 0.  pwc_conv3x3_h2_supported: 1 where it is the fastest kernel of this library for the
  * shape (Cin_phys >= 32, sub-lattices of at least 8 x 24 pixels, at least 192 workgroups), 0 otherwise; the entry point
  * itself accepts every shape that meets the requirements above. */

@@ -71,6 +71,7 @@ struct H2Args {
 };
 
 constexpr unsigned H2_OOB = 0x7FFF0000u;
+constexpr int H2_MAX_COUT = 512;             // (the bias lives in LDS)
 constexpr int H2_SC1 = 16;                   // aux bit of the buffer intrinsics: device-scope access (gfx940+)
 constexpr unsigned H2_EMPTY = 0xFFFFFFFFu;    // workspace word that holds no published sum
 constexpr int H2_PW = 34;                    // patch width in pixels
@@ -92,7 +93,8 @@ template <int CT, int PT, int WCG> struct H2Cfg {
     static constexpr int NAP = AP / 1024;                            // ... in 1 KB pieces
     static constexpr int APW = (NAP + 7) / 8;                        // pieces per wave (the last round may be partial)
     static constexpr int S0 = 0, B0 = S_BYTES, A0 = B0 + ((2 * B_BYTES + 1023) / 1024) * 1024;
-    static constexpr int LDS = A0 + 3 * AP;
+    static constexpr int BIAS = A0 + 3 * AP;                          // the layer's bias (H2_MAX_COUT floats)
+    static constexpr int LDS = BIAS + H2_MAX_COUT * 4;
     static_assert(LDS <= 160 * 1024, "LDS");
 };
 
@@ -124,21 +126,34 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     const int lw = pwc_xcd_remap(blockIdx.x, G);
     const long total = (long)a.ntiles * nc16;
     const int g0 = (int)((long)lw * total / G), g1 = (int)((long)(lw + 1) * total / G);
-    struct Tile { int n, ry, rx, y0, x0, n0; };
+    // tile coordinates (cout block fastest, then the pixel tiles of a (sub-)image, the sub-lattices (y mod d, x mod d) of a dilated
+    // conv, the images), decoded ONCE per workgroup and stepped from then on: five divisions per tile are ~1000 cycles
+    struct Tile { int cb, bx, by, rx, ry, n; };
     auto decode = [&](int tile) {
         Tile tl;
-        const int cb = tile % a.ncb;
+        tl.cb = tile % a.ncb;
         int rest = tile / a.ncb;
-        const int bx = rest % a.tiles_x;
+        tl.bx = rest % a.tiles_x;
         rest /= a.tiles_x;
-        const int by = rest % a.tiles_y;
+        tl.by = rest % a.tiles_y;
         rest /= a.tiles_y;
         const int sub = rest % (d * d);
         tl.n = rest / (d * d);
-        tl.ry = sub / d; tl.rx = sub - tl.ry * d;          // pixel sub-lattice (y mod d, x mod d) of a dilated conv
-        tl.y0 = by * C::TR; tl.x0 = bx * 32;                // output origin of the tile, in sub-lattice coordinates
-        tl.n0 = cb * 32 * C::NCT;
+        tl.ry = sub / d; tl.rx = sub - tl.ry * d;
         return tl;
+    };
+    auto next_tile = [&](Tile& tl) {
+        if (++tl.cb < a.ncb) return;
+        tl.cb = 0;
+        if (++tl.bx < a.tiles_x) return;
+        tl.bx = 0;
+        if (++tl.by < a.tiles_y) return;
+        tl.by = 0;
+        if (++tl.rx < d) return;
+        tl.rx = 0;
+        if (++tl.ry < d) return;
+        tl.ry = 0;
+        ++tl.n;
     };
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.wp, 0, nc16 * nct_all * 9 * H2_TAPB, 0x00020000);
@@ -147,14 +162,14 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     // = 16 channels).  The lane offsets (and the image's buffer resource) change with the tile only.
     unsigned p_voff[C::PPW];
     __amdgpu_buffer_rsrc_t xrsrc;
-    auto patch_tile = [&](int tile) {
-        const Tile tl = decode(tile);
+    auto patch_tile = [&](const Tile& tl) {
+        const int y0 = tl.by * C::TR, x0 = tl.bx * 32;      // output origin of the tile, in sub-lattice coordinates
         xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)tl.n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < C::PPW; ++i) {
             const int rec = (wave + 8 * i) * 16 + (lane >> 2);
             const int py = rec / H2_PW, px = rec - py * H2_PW;
-            const int yy = tl.ry + d * (tl.y0 - 1 + py), xx = tl.rx + d * (tl.x0 - 1 + px);
+            const int yy = tl.ry + d * (y0 - 1 + py), xx = tl.rx + d * (x0 - 1 + px);
             const bool ok = rec < C::NREC && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
             p_voff[i] = ok ? (unsigned)(((yy * a.W + xx) * a.x_cs + (lane & 3) * 4) * 4) : H2_OOB;
         }
@@ -229,25 +244,20 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     };
 
     pwc_f32x16 acc[CT][PT], accx[CT][PT];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ct][pt][r] = accx[ct][pt][r] = 0.f;
-    };
-    zero_acc();
     // matrix instruction i of a tap: group i / (CT PT) (hh, UH x VM', UM' x VH), tile i % (CT PT) -- MFMAs on one accumulator
     // stay CT PT apart
-    auto mfma_i = [&](const Frags& f, int i) {
+    // fresh: the first tap of a piece starts the accumulators from the matrix pipe's constant 0 (no 128 v_mov per tile)
+    auto mfma_i = [&](const Frags& f, int i, bool fresh) {
         const int grp = i / (CT * PT), tl = i % (CT * PT), ct = tl / PT, pt = tl % PT;
+        const pwc_f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (ABL & 4) {
             if (i == 0) asm volatile("" ::"v"(f.ah[0]), "v"(f.am[CT - 1]), "v"(f.bh[0]), "v"(f.bm[PT - 1]));
+            if (fresh && grp == 0) acc[ct][pt] = zero16;
+            if (fresh && grp == 1) accx[ct][pt] = zero16;
             return;
         }
-        if (grp == 0) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[ct], f.bh[pt], acc[ct][pt], 0, 0, 0);
-        if (grp == 1) accx[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[ct], f.bm[pt], accx[ct][pt], 0, 0, 0);
+        if (grp == 0) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[ct], f.bh[pt], fresh ? zero16 : acc[ct][pt], 0, 0, 0);
+        if (grp == 1) accx[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[ct], f.bm[pt], fresh ? zero16 : accx[ct][pt], 0, 0, 0);
         if (grp == 2) accx[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.am[ct], f.bh[pt], accx[ct][pt], 0, 0, 0);
     };
 
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     // output line of the launch -- per workgroup; a flag behind plain device-scope stores was seen to overtake them.)
     // Lane = (pixel column ln, couts (r & 3) + 8 (r >> 2) + 4 kh of a tile).
     constexpr int PART_FLOATS = C::NCT * 32 * C::TR * 32;
-    auto finish = [&](int tile, int kind, bool with_other) {
+    auto finish = [&](const Tile& tl, int kind, bool with_other) {
         if (kind == 1) {
             // buffer addressing (base in SGPRs, one lane offset): flat pointers would cost two VGPRs per access, hoisted
             const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
@@ -292,31 +302,19 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         if (with_other)
             prs = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(a.ws_partial + (size_t)(lw + 1) * PART_FLOATS + (size_t)wave * (CT * PT * 16 * 64)), 0, CT * PT * 16 * 64 * 4, 0x00020000);
-        const Tile tl = decode(tile);
+        const int y0 = tl.by * C::TR, x0 = tl.bx * 32, n0 = tl.cb * 32 * C::NCT;
         const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.y + (size_t)tl.n * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
-        // the bias of the lane's 16 CT couts, fetched at once (the fragment registers of the finished tile are free): one exposed
-        // latency per piece end instead of one per store
-        f32x4 bias4[CT][4];
-        {
-            const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.Cout * 4, 0x00020000);
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    bias4[ct][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (tl.n0 + (CT * cgw + ct) * 32 + 8 * q + 4 * kh) * 4, 0, 0));
-        }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-            const int py = tl.ry + d * (tl.y0 + PT * pg + pt), px = tl.rx + d * (tl.x0 + ln);
+            const int py = tl.ry + d * (y0 + PT * pg + pt), px = tl.rx + d * (x0 + ln);
             const bool inside = py < a.H && px < a.W;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int co = tl.n0 + (CT * cgw + ct) * 32 + 8 * q + 4 * kh;
-                    const f32x4 b4 = bias4[ct][q];
+                    const int co = n0 + (CT * cgw + ct) * 32 + 8 * q + 4 * kh;
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(sm + C::BIAS + co * 4);      // (copied into LDS by the prologue)
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = acc[ct][pt][4 * q + e] + accx[ct][pt][4 * q + e] * (1.f / 2048.f);
@@ -363,34 +361,31 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     // the one after (patches two ahead), advanced incrementally -- a division per stage and wave would cost as much as a tap
     unsigned long long tk_wait = 0, tk_bar = 0, tk_fin = 0;
     const unsigned long long tk_start = (ABL & 2048) ? __builtin_readcyclecounter() : 0;
-    int tile = g0 / nc16;
-    int c16 = g0 - tile * nc16;
-    int cb = tile % a.ncb;
-    int tile1 = tile, c1 = c16, cb1 = cb;            // stage g + 1
-    auto step = [&](int& tl, int& c, int* cbp) {
-        if (++c == nc16) {
-            c = 0; ++tl;
-            if (cbp && ++*cbp == a.ncb) *cbp = 0;
-        }
+    Tile tcur = decode(g0 / nc16);                    // the tile of stage g
+    int c16 = g0 - (g0 / nc16) * nc16;
+    Tile t1 = tcur; int c1 = c16;                     // ... of stage g + 1 (weights are fetched one stage ahead)
+    auto step = [&](Tile& tl, int& c) {
+        if (++c == nc16) { c = 0; next_tile(tl); }
     };
-    step(tile1, c1, &cb1);
-    int tile2 = tile1, c2 = c1;                       // stage g + 2
-    step(tile2, c2, nullptr);
+    step(t1, c1);
+    Tile t2 = t1; int c2 = c1;                        // ... of stage g + 2 (patches two ahead)
+    step(t2, c2);
 
     // ---- prologue: patch g0, parts (g0, 0) and (g0, 1); split patch g0; patch g0 + 1
-    patch_tile(tile);
+    patch_tile(tcur);
 #pragma unroll
     for (int i = 0; i < C::PPW; ++i) issue_patch_piece(i, c16);
 #pragma unroll
-    for (int j = 0; j < C::APW; ++j) issue_w_piece(j, c16, cb, 0);
+    for (int j = 0; j < C::APW; ++j) issue_w_piece(j, c16, tcur.cb, 0);
 #pragma unroll
-    for (int j = 0; j < C::APW; ++j) issue_w_piece(j, c16, cb, 1);
+    for (int j = 0; j < C::APW; ++j) issue_w_piece(j, c16, tcur.cb, 1);
+    if (t < a.Cout) reinterpret_cast<float*>(sm + C::BIAS)[t] = a.bias[t];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     H2_BAR();
     convert(0);
     H2_BAR();
     if (g0 + 1 < g1) {
-        if (tile1 != tile) patch_tile(tile1);
+        if (c1 == 0) patch_tile(t1);
 #pragma unroll
         for (int i = 0; i < C::PPW; ++i) issue_patch_piece(i, c1);
     }
@@ -400,7 +395,7 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
 
     // One tap = NM issue slots: matrix instruction i, then ONE other instruction group (a fragment fetch of the next tap, a
     // fetch piece, a piece of the split) that issues while the matrix pipe works.
-    auto tap = [&](auto Rc, auto DXc, int g, int buf, bool more) {
+    auto tap = [&](auto Rc, auto DXc, int g, int buf, bool more, bool fresh) {
         constexpr int R = decltype(Rc)::value, DX = decltype(DXc)::value;
         constexpr int NR = DX < 2 ? R : (R + 1) % 3, NDX = (DX + 1) % 3;
         const int nbuf = (R == 2 && DX == 2) ? (buf ^ 1) : buf;
@@ -424,18 +419,18 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         constexpr int NEX = NEXA + NEXP > NEXC ? NEXA + NEXP : NEXC;
         constexpr int NSLOT = NM > NL + NEX ? NM : NL + NEX;
         f32x4 cvv[3];
-        if (do_p && c2 == 0) patch_tile(tile2);
+        if (do_p && c2 == 0) patch_tile(t2);
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
-            if (i < NM) mfma_i(cur, i);
+            if (i < NM) mfma_i(cur, i, fresh);
             if (i < NEXC && do_cv) cvv[i] = cv_read(CV0 + i);
             if (i < NL) {
                 if (do_load) load_i(nxt, i, nbuf, NR, NDX);
             } else {
                 const int e = i - NL;
                 if (e < NEXA && do_w) {
-                    if (R == 0) issue_w_piece(e, c16, cb, 2);
-                    else issue_w_piece(e, c1, cb1, R - 1);
+                    if (R == 0) issue_w_piece(e, c16, tcur.cb, 2);
+                    else issue_w_piece(e, c1, t1.cb, R - 1);
                 }
                 if (e >= NEXA && e < NEXA + NEXP && do_p) issue_patch_piece(e - NEXA, c2);
                 if (e < NEXC && do_cv) cv_write(CV0 + e, buf ^ 1, cvv[e]);
@@ -453,6 +448,7 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     for (int g = g0; g < g1; ++g) {
         const int buf = (g - g0) & 1;
         const bool more = g + 1 < g1;
+        const bool fresh0 = c16 == 0 || g == g0;        // the first stage of a piece
         // part (g, 0): this wave's pieces of part (g, 1) have landed (the patch pieces behind them may be in flight; stores and
         // fetches retire out of order with each other, so behind an epilogue everything is waited for) ...
         unsigned long long tk0 = (ABL & 2048) ? __builtin_readcyclecounter() : 0;
@@ -471,11 +467,12 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         H2_BAR();                          // ... everybody's; every wave is done with slot 2
         if (ABL & 2048) tk_bar += __builtin_readcyclecounter() - tk0;
         H2_STAMP(1);
-        tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, g, buf, more);
+        if (fresh0) tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, g, buf, more, true);
+        else tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, g, buf, more, false);
         H2_STAMP(2);
-        tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, g, buf, more);
+        tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, g, buf, more, false);
         H2_STAMP(3);
-        tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, g, buf, more);
+        tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, g, buf, more, false);
         H2_STAMP(4);
         if (ABL & 2048) tk0 = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // part (g, 2) and the patch of g + 1
@@ -483,11 +480,11 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         H2_BAR();
         if (ABL & 2048) tk_bar += __builtin_readcyclecounter() - tk0;
         H2_STAMP(5);
-        tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, g, buf, more);
+        tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, g, buf, more, false);
         H2_STAMP(6);
-        tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, g, buf, more);
+        tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, g, buf, more, false);
         H2_STAMP(7);
-        tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, g, buf, more);
+        tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, g, buf, more, false);
         H2_STAMP(8);
         if (ABL & 2048) tk0 = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // part (g + 1, 0)
@@ -495,26 +492,25 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         H2_BAR();
         if (ABL & 2048) tk_bar += __builtin_readcyclecounter() - tk0;
         H2_STAMP(9);
-        tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, g, buf, more);
+        tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, g, buf, more, false);
         H2_STAMP(10);
-        tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, g, buf, more);
+        tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, g, buf, more, false);
         H2_STAMP(11);
-        tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, g, buf, more);
+        tap(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, g, buf, more, false);
         H2_STAMP(12);
         // end of a piece: the tile's last stage, or the range's
         const bool tile_end = c16 == nc16 - 1;
         if (tile_end || !more) {
             if (ABL & 2048) tk0 = __builtin_readcyclecounter();
-            if (tile_end) finish(tile, (first_piece && head_is_second_piece) ? 1 : 0, false);
-            else finish(tile, 0, true);
-            zero_acc();
+            if (tile_end) finish(tcur, (first_piece && head_is_second_piece) ? 1 : 0, false);
+            else finish(tcur, 0, true);
             drain = true;
             first_piece = false;
             if (ABL & 2048) tk_fin += __builtin_readcyclecounter() - tk0;
         }
-        step(tile, c16, &cb);
-        step(tile1, c1, &cb1);
-        step(tile2, c2, nullptr);
+        step(tcur, c16);
+        step(t1, c1);
+        step(t2, c2);
     }
     if ((ABL & 2048) && a.dbg && lane == 0) {
         unsigned* o = a.dbg + (lw * 8 + wave) * 4;
@@ -592,7 +588,7 @@ static inline long h2_blocks(int v, int N, int hs, int ws, int Cout, int dilatio
 // The variant whose launch is estimated shortest: tiles per CU x (matrix instructions per tap and wave + 3.6), the 3.6 being
 // the measured fixed part of a tap (profiles/r04_exp_h2.txt: 52 / 40.5 / 34 us per round of 8 stages for 12 / 9 / 6).
 static int h2_plan(int N, int H, int W, int Cin_phys, int Cout, int dilation, long* blocks_out) {
-    if (N <= 0 || H <= 0 || W <= 0 || dilation < 1 || Cin_phys < 16 || (Cin_phys % 16) || Cout < 32 || (Cout % 32)) return 0;
+    if (N <= 0 || H <= 0 || W <= 0 || dilation < 1 || Cin_phys < 16 || (Cin_phys % 16) || Cout < 32 || (Cout % 32) || Cout > H2_MAX_COUT) return 0;
     const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
     int best = 0;
     double best_cost = 0.;
@@ -666,7 +662,7 @@ static int h2_run(const float* x, int x_cs, const float* packed_w, const float* 
                   float* workspace = nullptr, size_t workspace_floats = 0) {
     if (!x || !packed_w || !bias || !y) return PWC_EINVAL;
     if (N <= 0 || H <= 0 || W <= 0 || Cin_phys <= 0 || Cout <= 0 || dilation < 1) return PWC_EINVAL;
-    if (Cin_phys % 16 || Cout % 32) return PWC_EUNSUPPORTED;
+    if (Cin_phys % 16 || Cout % 32 || Cout > H2_MAX_COUT) return PWC_EUNSUPPORTED;
     if (x_cs < Cin_phys || y_cs < Cout) return PWC_EINVAL;
     if ((x_cs & 3) || (y_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(y) || !pwc_aligned16(packed_w) || !pwc_aligned16(bias) ||
         !pwc_aligned16(workspace))
