@@ -40,10 +40,14 @@
 //   launch is dealt in equal contiguous ranges, the pipeline above runs across tile boundaries (one prologue per workgroup),
 //   and a tile cut in two is finished by the workgroup holding its first piece (finish() below).
 //   Where the time goes (profiles/r04_exp_h2.txt, r04_exp_h2_micro.txt, r04_exp_h2_tap_timeline*.txt): a loop of nothing but
-//   these matrix instructions on random data sustains 1.6 PFLOP/s (the clock drops to ~0.8 GHz under it; 2.2 PFLOP/s on zeros)
-//   = 124 us for the 128 -> 128 layer at 8 x 112 x 256; the kernel takes 180 us: a wave issues one slot per ~43 cycles, taps
-//   that carry fetch pieces or the split take 1.5 - 3.5x a plain tap on the second wave of a SIMD, and the waves of a
-//   workgroup meet at three barriers per stage (16 % of a wave's time), piece ends take 9 %.
+//   these matrix instructions on random data sustains 1.6 PFLOP/s = 20.5 ns per instruction and SIMD (the chip is power-limited
+//   under the F16 matrix pipe: 2.2 PFLOP/s on all-zero operands) = 124 us for the 128 -> 128 layer at 8 x 112 x 256.  The kernel
+//   takes 175 us: inside the main loop the pipe delivers one instruction per 24.8 ns whether one or both waves of a SIMD are
+//   feeding it (83 % of the sustained rate; the three barriers per stage and the taps that carry fetch pieces or the split make
+//   up the rest), piece ends (16 x 128 KB of stores per workgroup and tile) take 9 %, the prologue 3 %.  Moving the fetch pieces
+//   (spread, staggered between the waves of a SIMD, issued right behind the barriers, given to half of the waves, s_setprio) or
+//   the weights off the LDS-DMA path (through registers: r04_exp_h2_weights_through_registers.txt) changes the per-tap pattern
+//   and not the time: the matrix pipe is what the loop waits for.
 #pragma once
 #include "pwc_common.h"
 #include <type_traits>
@@ -402,9 +406,9 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         const bool do_load = !(R == 2 && DX == 2) || more;
         // Placement of the fetch pieces, measured with per-tap s_memtime stamps (profiles/r04_exp_h2_tap_timeline*.txt): all weight
         // pieces in the first tap of a part and the patch pieces in tap (2, 1) -- spreading them one per tap takes the landing slack
-        // away (7 % of the time waiting for fetches, 184 vs 179 us), giving the two waves of a SIMD different taps or only one of
-        // them the pieces (waves 0-3 issuing all weight pieces: 180 vs 179 us) moves the delay between the waves without shortening
-        // the part, as does s_setprio.
+        // away (7 % of the time waiting for fetches, 184 vs 179 us); giving the two waves of a SIMD different taps, only one of
+        // them the pieces (waves 0-3 issuing all weight pieces: 180 vs 179 us), issuing them right behind the barrier (182 vs 179)
+        // or s_setprio move the delay between the waves without shortening the part.
         const bool do_w = R == 0 || more;
         const bool do_p = R == 2 && DX == 1 && g + 2 < g1;
         // the split of stage g + 1: items 0-2 in tap (1, 1), items 3-4 (16-row tiles) in tap (1, 2).  The staging reads go out in the
