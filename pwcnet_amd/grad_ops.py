@@ -8,7 +8,9 @@ import numpy as np
 import torch
 
 from . import _lib
-from .modules import View, _p, _wino_pays, as_view
+from .modules import View, _p, _wino_pays, _h2_workspace, as_view
+
+F16X2 = True      # training forward + data gradient: route the layers pwc_conv3x3_h2_supported names to conv3x3_h2
 
 
 def _L():
@@ -157,7 +159,20 @@ def conv3x3_raw(x, w_hwio, bias, y, stride=1, dilation=1, slope=None, keep=None)
     w_hwio = w_hwio.contiguous()
     tmp = [w_hwio, bias]
     use_mfma = cout % 16 == 0 and x.C % 16 == 0 and x.cs % 4 == 0 and x.ptr % 16 == 0
-    if use_mfma and stride == 1 and _wino_pays(L, x.N, x.H, x.W, cout, dilation):
+    if (use_mfma and stride == 1 and F16X2 and cout % 32 == 0 and y.cs % 4 == 0 and y.ptr % 16 == 0
+            and L.pwc_conv3x3_h2_supported(x.N, x.H, x.W, x.C, cout, dilation)):
+        # the big stride-1 layers, forward and data gradient alike: direct convolution on the F16 matrix pipe with
+        # exact-to-22-bit operand splits (more accurate than the fp32 Winograd kernel below; include/pwc_hip.h)
+        packed = torch.empty((L.pwc_conv3x3_h2_packed_floats(x.C, cout),), dtype=torch.float32, device=dev)
+        _lib.check(L.pwc_conv3x3_h2_pack_f32(_p(w_hwio.data_ptr()), None, x.C, x.C, cout, _p(packed.data_ptr()), s), "h2 pack")
+        wsf = L.pwc_conv3x3_h2_workspace_floats(x.N, x.H, x.W, x.C, cout, dilation)
+        ws = _h2_workspace(dev, wsf) if wsf else None
+        _lib.check(L.pwc_conv3x3_h2_f32(_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.data_ptr()), _p(y.ptr), y.cs,
+                                        x.N, x.H, x.W, x.C, cout, dilation, act, sl,
+                                        _p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0, s),
+                   "conv3x3_h2 (raw)")
+        tmp.append(packed)
+    elif use_mfma and stride == 1 and _wino_pays(L, x.N, x.H, x.W, cout, dilation):
         packed = torch.empty((L.pwc_conv3x3_wino_packed_floats(x.C, cout),), dtype=torch.float32, device=dev)
         _lib.check(L.pwc_conv3x3_wino_pack_f32(_p(w_hwio.data_ptr()), None, x.C, x.C, cout, _p(packed.data_ptr()), s), "wino pack")
         _lib.check(L.pwc_conv3x3_wino_f32(_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.data_ptr()), _p(y.ptr), y.cs,

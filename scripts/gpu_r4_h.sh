@@ -1,2 +1,4 @@
 mkdir -p gpurun_out/r4h
-for i in 0 2 3 4 12; do timeout 300 ./scripts/exp_h2.bin $i > gpurun_out/r4h/h2_$i.txt 2>&1; grep -E "^==|entries off|medians|s_memtime|tap timeline|workgroup 0 wave [04]|variant" gpurun_out/r4h/h2_$i.txt | cut -c1-420; done
+timeout 2400 python -m pytest tests/test_gpu_grad.py -x -q > gpurun_out/r4h/tests_grad.txt 2>&1
+tail -3 gpurun_out/r4h/tests_grad.txt
+timeout 300 python bench.py --mode train --steps 10 --warmup 3 2>/dev/null | tail -1 | cut -c1-220
