@@ -1,4 +1,2 @@
 mkdir -p gpurun_out/r4h
-timeout 2400 python -m pytest tests/test_gpu_grad.py -x -q > gpurun_out/r4h/tests_grad.txt 2>&1
-tail -3 gpurun_out/r4h/tests_grad.txt
-timeout 300 python bench.py --mode train --steps 10 --warmup 3 2>/dev/null | tail -1 | cut -c1-220
+timeout 1200 python -m pytest tests/test_gpu_model.py -x -q -k "f16x2 or f4x4" -s 2>&1 | grep -E "passed|failed|f16x2 layers|F\(4x4\) layers|Error|assert" | head

@@ -430,6 +430,41 @@ def test_f4x4_layers_leave_the_flows_where_f2x2_puts_them(pa):
     assert err <= 1e-3 / 3, err
 
 
+def test_f16x2_layers_leave_the_flows_where_fp32_puts_them(pa):
+    """BASELINE configs[1] batch: the big stride-1 convs run on conv3x3_h2 (fp32 operands as two-term fp16 splits on the F16
+    matrix pipe, stream-K through a workspace); with f16x2=False they run on the fp32 Winograd kernels.  Flows of a few
+    pixels (kernel gain 1.3): the two forwards must agree far inside the 1e-3 px bound, pair 0 must meet the oracle at least
+    as well as the fp32 forward does, two f16x2 forwards must agree bitwise (the cut tiles of stream-K are summed in a fixed
+    order), and the estimator input (cost volume ++ features ++ flow ++ upfeat) must be what the kernel's range expects."""
+    w = util.model_weights(False, gain=1.3)
+    im0, im1 = util.smooth_images(8, 448, 1024, seed=95, shift=(-4, 3))
+    net_h = pa.PWCDCNet(streams=1)
+    net_h.load_weights(w)
+    net_f = pa.PWCDCNet(streams=1, f16x2=False)
+    net_f.load_weights(w)
+    from pwcnet_amd.profiler import OpTimer
+    t = OpTimer()
+    with t:
+        a, _ = net_h(gpu(im0), gpu(im1))
+    names = sorted(t.summary())
+    assert any(k.startswith("conv3x3_h2") for k in names), names
+    a = a.clone()
+    a2, _ = net_h(gpu(im0), gpu(im1))
+    assert torch.equal(a, a2)
+    t2 = OpTimer()
+    with t2:
+        b, _ = net_f(gpu(im0), gpu(im1))
+    assert not any(k.startswith("conv3x3_h2") for k in t2.summary()), sorted(t2.summary())
+    mag = float(b.abs().max())
+    assert mag >= 1.0 and bool(torch.isfinite(a).all())
+    assert float((a - b).abs().max()) <= 1e-4, float((a - b).abs().max())
+    e_final, _ = orc.OraclePWCDCNet(w)(im0[:1], im1[:1])
+    err_h = float(np.abs(a[:1].cpu().numpy() - e_final).max())
+    err_f = float(np.abs(b[:1].cpu().numpy() - e_final).max())
+    print(f"f16x2 layers: max |flow| {mag:.2f} px, vs fp32 kernels {float((a - b).abs().max()):.2e}, vs oracle {err_h:.2e} (fp32 kernels: {err_f:.2e})")
+    assert err_h <= 1e-3 / 3 and err_h <= 2.0 * err_f + 1e-6, (err_h, err_f)
+
+
 def test_channel_split_launches_do_not_change_the_flows(pa, monkeypatch):
     """The coarse estimator levels run their Winograd convs with the channel loop dealt to several workgroups
     (pwc_conv3x3_wino_split_f32); with the split disabled the forward must give the same flows up to fp32 summation order."""
