@@ -229,6 +229,17 @@ int pwc_conv3x3_h2_f32(const float* x, int x_cs, const float* packed_w, const fl
  * uncut sum.  workspace = NULL: one workgroup per tile. */
 size_t pwc_conv3x3_h2_workspace_floats(int N, int H, int W, int Cin_phys, int Cout, int dilation);
 int pwc_conv3x3_h2_supported(int N, int H, int W, int Cin_phys, int Cout, int dilation);
+/* Stride 2 ('SAME', dilation 1; the extractor's down-sampling layers, reference modules.py:57-60) through the same
+ * kernel: the launch of the stride-1 convolution over the (H, W) input that stores only the sums a stride-2 convolution
+ * has.  y is (N, ceil(H/2), ceil(W/2)) with channel stride y_cs; everything else as pwc_conv3x3_h2_f32 (packed_w from
+ * the same pack function; workspace sized by pwc_conv3x3_h2_workspace_floats(N, H, W, Cin_phys, Cout, 1)).  Four times
+ * the matrix work of a strided kernel: measured 10-15 % SLOWER than pwc_conv3x3_f32 on the extractor's layers, so
+ * pwc_conv3x3_h2_stride2_supported returns 0 for every shape today and the host never routes to it. */
+int pwc_conv3x3_h2_stride2_f32(const float* x, int x_cs, const float* packed_w, const float* bias,
+                               float* y, int y_cs, int N, int H, int W, int Cin_phys, int Cout,
+                               int apply_act, float slope, float* workspace, size_t workspace_floats,
+                               pwc_stream_t stream);
+int pwc_conv3x3_h2_stride2_supported(int N, int H, int W, int Cin_phys, int Cout);
 /* Tile variants of the kernel above (workgroup = couts x rows x 32 columns): 1 = 128 x 8, 2 = 64 x 16, 3 = 96 x 8,
  * 4 = 32 x 16, 5 = 64 x 8.  pwc_conv3x3_h2_plan: the one pwc_conv3x3_h2_f32 launches for a shape (fewest estimated
  * rounds of 256 workgroups x matrix instructions per tap; 0 = the shape is not accepted).  pwc_conv3x3_h2_variant_f32:

@@ -55,6 +55,8 @@ SIGNATURES = {
     "pwc_conv3x3_h2_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "pwc_conv3x3_h2_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "pwc_conv3x3_h2_plan": (_i, [_i, _i, _i, _i, _i, _i]),
+    "pwc_conv3x3_h2_stride2_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "pwc_conv3x3_h2_stride2_supported": (_i, [_i, _i, _i, _i, _i]),
     "pwc_conv3x3_h2_variant_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "pwc_conv3x3_wino_split_plan": (_i, [_i, _i, _i, _i, _i, _i]),
     "pwc_conv3x3_wino_split_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),

@@ -72,6 +72,8 @@ struct H2Args {
     float* ws_partial;   // stream-K: one partial tile (32 CT WCG couts x PT WPG x 32 pixels, fp32) per workgroup, words 0xFFFFFFFF
                          // while nothing is published; null = every workgroup owns whole tiles
     unsigned* dbg;       // harness only
+    int stride;          // 1, or 2: only the sums at positions 2 o + off are stored, to an (Ho, Wo) output
+    int Ho, Wo, off_y, off_x;
 };
 
 constexpr unsigned H2_OOB = 0x7FFF0000u;
@@ -308,11 +310,13 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
                 (void*)(a.ws_partial + (size_t)(lw + 1) * PART_FLOATS + (size_t)wave * (CT * PT * 16 * 64)), 0, CT * PT * 16 * 64 * 4, 0x00020000);
         const int y0 = tl.by * C::TR, x0 = tl.bx * 32, n0 = tl.cb * 32 * C::NCT;
         const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.y + (size_t)tl.n * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
+            (void*)(a.y + (size_t)tl.n * a.Ho * a.Wo * a.y_cs), 0, a.Ho * a.Wo * a.y_cs * 4, 0x00020000);
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
             const int py = tl.ry + d * (y0 + PT * pg + pt), px = tl.rx + d * (x0 + ln);
-            const bool inside = py < a.H && px < a.W;
+            // stride 2: the stride-1 sum at input position 2 o + off IS output o (off = 1 - the SAME padding in front)
+            const bool inside = py < a.H && px < a.W && (a.stride == 1 || ((((py - a.off_y) | (px - a.off_x)) & 1) == 0 && py >= a.off_y && px >= a.off_x));
+            const int opy = a.stride == 1 ? py : (py - a.off_y) >> 1, opx = a.stride == 1 ? px : (px - a.off_x) >> 1;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], o[e] * a.slope);
                     }
-                    const unsigned vo = inside ? (unsigned)(((py * a.W + px) * a.y_cs + co) * 4) : H2_OOB;
+                    const unsigned vo = inside ? (unsigned)(((opy * a.Wo + opx) * a.y_cs + co) * 4) : H2_OOB;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, (int)vo, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);                    // (also bounds the registers the hoisted loads take)
                     asm volatile("s_nop 7" ::: "memory");                 // see the published sums above
@@ -663,10 +667,10 @@ static int h2_launch(H2Args& a, int hs, int ws, float* workspace, size_t workspa
 template <int ABL = 0>
 static int h2_run(const float* x, int x_cs, const float* packed_w, const float* bias, float* y, int y_cs, int N, int H, int W,
                   int Cin_phys, int Cout, int dilation, int apply_act, float slope, pwc_stream_t stream, int variant = 0,
-                  float* workspace = nullptr, size_t workspace_floats = 0) {
+                  float* workspace = nullptr, size_t workspace_floats = 0, int stride = 1) {
     if (!x || !packed_w || !bias || !y) return PWC_EINVAL;
-    if (N <= 0 || H <= 0 || W <= 0 || Cin_phys <= 0 || Cout <= 0 || dilation < 1) return PWC_EINVAL;
-    if (Cin_phys % 16 || Cout % 32 || Cout > H2_MAX_COUT) return PWC_EUNSUPPORTED;
+    if (N <= 0 || H <= 0 || W <= 0 || Cin_phys <= 0 || Cout <= 0 || dilation < 1 || (stride != 1 && stride != 2)) return PWC_EINVAL;
+    if (Cin_phys % 16 || Cout % 32 || Cout > H2_MAX_COUT || (stride == 2 && dilation != 1)) return PWC_EUNSUPPORTED;
     if (x_cs < Cin_phys || y_cs < Cout) return PWC_EINVAL;
     if ((x_cs & 3) || (y_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(y) || !pwc_aligned16(packed_w) || !pwc_aligned16(bias) ||
         !pwc_aligned16(workspace))
@@ -677,6 +681,12 @@ static int h2_run(const float* x, int x_cs, const float* packed_w, const float* 
     a.N = N; a.H = H; a.W = W; a.Cin_phys = Cin_phys; a.Cout = Cout; a.apply_act = apply_act; a.slope = slope;
     a.dil = dilation;
     a.dbg = h2_debug_counters;
+    a.stride = stride; a.Ho = H; a.Wo = W; a.off_y = a.off_x = 0;
+    if (stride == 2) {
+        int before = 0;
+        pwc_same_pad(H, 2, 1, &a.Ho, &before); a.off_y = 1 - before;
+        pwc_same_pad(W, 2, 1, &a.Wo, &before); a.off_x = 1 - before;
+    }
     const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
     if (variant == 0) variant = h2_plan(N, H, W, Cin_phys, Cout, dilation, nullptr);
     if (variant < 1 || variant > 5) return PWC_EUNSUPPORTED;
@@ -706,6 +716,24 @@ extern "C" int pwc_conv3x3_h2_f32(const float* x, int x_cs, const float* packed_
                                   int apply_act, float slope, float* workspace, size_t workspace_floats, pwc_stream_t stream) {
     return h2_run<0>(x, x_cs, packed_w, bias, y, y_cs, N, H, W, Cin_phys, Cout, dilation, apply_act, slope, stream, 0,
                      workspace, workspace_floats);
+}
+
+// Stride 2 ('SAME', dilation 1: the extractor's down-sampling layers, reference modules.py:57-60): the launch of the stride-1
+// convolution over the (H, W) input that stores only the sums a stride-2 convolution has (y is (N, ceil(H/2), ceil(W/2), y_cs)).
+// Four times the matrix work of a strided kernel: measured in the forward (batch 8, 16 -> 32 at 224 x 512 / 32 -> 64 at 112 x 256 /
+// 64 -> 96 at 56 x 128, 16 images each) 73.7 / 63.0 / 48.7 us against 64.0 / 59.4 / 42.9 us of pwc_conv3x3_f32 -- NOT the faster
+// one, so _supported says 0 everywhere and nothing routes to it; the entry point is correct (tests) and stays for the strided
+// operand image that would make it pay (even and odd columns in separate planes: DESIGN.md section 8).
+extern "C" int pwc_conv3x3_h2_stride2_supported(int N, int H, int W, int Cin_phys, int Cout) {
+    (void)N; (void)H; (void)W; (void)Cin_phys; (void)Cout;
+    return 0;
+}
+
+extern "C" int pwc_conv3x3_h2_stride2_f32(const float* x, int x_cs, const float* packed_w, const float* bias, float* y,
+                                          int y_cs, int N, int H, int W, int Cin_phys, int Cout, int apply_act, float slope,
+                                          float* workspace, size_t workspace_floats, pwc_stream_t stream) {
+    return h2_run<0>(x, x_cs, packed_w, bias, y, y_cs, N, H, W, Cin_phys, Cout, 1, apply_act, slope, stream, 0,
+                     workspace, workspace_floats, 2);
 }
 
 // The tile variant pwc_conv3x3_h2_f32 uses for a shape (1 - 5, see h2_variant; 0 = none fits), and the same convolution with

@@ -246,8 +246,12 @@ class _ConvRunner:
         use_h2 = (use_mfma and getattr(self.owner, "f16x2", True) and stride == 1 and tile < 0 and split == 0
                   and cout % 32 == 0 and y.cs % 4 == 0 and y.ptr % 16 == 0
                   and L.pwc_conv3x3_h2_supported(x.N, x.H, x.W, x.C, cout, dilation))
-        if use_h2:
-            # direct convolution on the F16 matrix pipe, fp32 operands as two-term fp16 splits (conv3x3_h2.hip)
+        use_h2s2 = (use_mfma and getattr(self.owner, "f16x2", True) and stride == 2 and dilation == 1 and tile < 0 and split == 0
+                    and cout % 32 == 0 and y.cs % 4 == 0 and y.ptr % 16 == 0
+                    and L.pwc_conv3x3_h2_stride2_supported(x.N, x.H, x.W, x.C, cout))
+        if use_h2 or use_h2s2:
+            # direct convolution on the F16 matrix pipe, fp32 operands as two-term fp16 splits (conv3x3_h2.hip); stride 2 = the
+            # stride-1 launch that stores every second sum
             key = (name, "h2", x.C, None if cin_map is None else cin_map.tobytes(), self.store.version)
             packed = cache.get(key)
             if packed is None:
@@ -267,14 +271,19 @@ class _ConvRunner:
             ws = _h2_workspace(kern.value.device, wsf) if wsf and getattr(self.owner, "f16x2_stream_k", True) else None
             if ws is not None:
                 _keep(ws)
-            _launch(L.pwc_conv3x3_h2_f32,
-                    (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
-                     x.N, x.H, x.W, x.C, cout, dilation, act, sl, _p(ws.data_ptr()) if ws is not None else None,
-                     ws.numel() if ws is not None else 0, s),
-                    f"conv3x3_h2 {name}", "conv3x3_h2_kernel",
+            wsa = (_p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0)
+            if use_h2:
+                fn = L.pwc_conv3x3_h2_f32
+                args = (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
+                        x.N, x.H, x.W, x.C, cout, dilation, act, sl) + wsa + (s,)
+            else:
+                fn = L.pwc_conv3x3_h2_stride2_f32
+                args = (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
+                        x.N, x.H, x.W, x.C, cout, act, sl) + wsa + (s,)
+            _launch(fn, args, f"conv3x3_h2 {name}", "conv3x3_h2_kernel",
                     2.0 * x.N * Ho * Wo * 9 * cin * cout, 4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout),
-                    # executed: three fp16 products per multiply-add, per physical input channel
-                    exec_flops=3.0 * 2.0 * x.N * Ho * Wo * 9 * x.C * cout)
+                    # executed: three fp16 products per multiply-add of the stride-1 launch, per physical input channel
+                    exec_flops=3.0 * 2.0 * x.N * x.H * x.W * 9 * x.C * cout)
         elif use_wino4:
             # F(4x4,3x3): 36 multiplies per 4x4 outputs (the big full-resolution layers)
             key = (name, "wino4", x.C, None if cin_map is None else cin_map.tobytes(), self.store.version)

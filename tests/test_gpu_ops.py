@@ -350,6 +350,32 @@ def test_conv_f16x2_direct_stream_k(pa, N, H, W, cin, cout, dil):
         close(first[i:i + 1], orc.conv3x3(x[i:i + 1], k, b, 1, dil, 0.1))
 
 
+@pytest.mark.parametrize("N,H,W,cin,cout", [(2, 64, 96, 16, 32), (1, 33, 47, 32, 64), (2, 50, 70, 64, 96), (16, 112, 256, 32, 64),
+                                            (3, 31, 64, 48, 128)])
+def test_conv_f16x2_direct_stride2_vs_oracle(pa, N, H, W, cin, cout):
+    """pwc_conv3x3_h2_stride2_f32: TF 'SAME' stride-2 convolution (even sizes pad bottom / right only, odd sizes one pixel on
+    each side) as the stride-1 launch that stores every second sum; strided output with untouched neighbours; with and
+    without the stream-K workspace."""
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    x = rnd((N, H, W, cin), 371)
+    k = rnd((3, 3, cin, cout), 372) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 373) * 0.1
+    xg, kg, bg = gpu(x), gpu(k), gpu(b)
+    packed = torch.empty(L.pwc_conv3x3_h2_packed_floats(cin, cout), device="cuda")
+    _lib.check(L.pwc_conv3x3_h2_pack_f32(_p(kg), None, cin, cin, cout, _p(packed), None))
+    Ho, Wo = -(-H // 2), -(-W // 2)
+    exp = orc.conv3x3(x, k, b, 2, 1, 0.1)
+    assert exp.shape == (N, Ho, Wo, cout)
+    for ws in (None, h2_workspace(N, H, W, cin, cout, 1)):
+        y = torch.full((N, Ho, Wo, cout + 8), -7.0, device="cuda")
+        wp, wn = (None, 0) if ws is None else (_p(ws), ws.numel())
+        _lib.check(L.pwc_conv3x3_h2_stride2_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout + 8, N, H, W, cin, cout, 1, 0.1, wp, wn, None))
+        torch.cuda.synchronize()
+        close(y[..., :cout], exp)
+        assert float(y[..., cout:].min()) == -7.0 and float(y[..., cout:].max()) == -7.0
+
+
 def test_conv_f16x2_direct_physical_layout_range_and_plan(pa):
     """Padded / permuted physical input channels through cin_map (the estimator buffers); operands of very different
     magnitudes (the split is relative, not absolute); an input beyond fp16's range poisons exactly the outputs that
