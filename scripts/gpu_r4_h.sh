@@ -1,5 +1,2 @@
 mkdir -p gpurun_out/r4h
-timeout 1200 python -m pytest tests/test_gpu_ops.py -x -q -k "f16x2" > gpurun_out/r4h/tests_h2.txt 2>&1
-tail -3 gpurun_out/r4h/tests_h2.txt
-timeout 600 python scripts/exp_timeline.py 8 > gpurun_out/r4h/timeline8.txt 2>&1
-grep -E "fp_extractor" gpurun_out/r4h/timeline8.txt | head -20; tail -1 gpurun_out/r4h/timeline8.txt
+for i in 0 4 12; do timeout 300 ./scripts/exp_h2.bin $i > gpurun_out/r4h/h2_$i.txt 2>&1; grep -E "^==|entries off|medians|s_memtime|variant 4 stream|x[0-9.]+ vs fp32" gpurun_out/r4h/h2_$i.txt | cut -c1-300; done
