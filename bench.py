@@ -52,7 +52,7 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 chip peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense F16 matrix peak (v_mfma_f32_32x32x16_f16: 32 cycles per instruction and SIMD at 2.4 GHz)
 # the matrix pipe each MFMA kernel runs on
-KERNEL_PEAK = {"conv3x3_h2_kernel": PEAK_F16_MFMA_TFLOPS}
+KERNEL_PEAK = {"conv3x3_h2_kernel": PEAK_F16_MFMA_TFLOPS, "conv3x3_c16pair_kernel": PEAK_F16_MFMA_TFLOPS}
 
 
 def peak_of(kernel):

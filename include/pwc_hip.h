@@ -229,6 +229,19 @@ int pwc_conv3x3_h2_f32(const float* x, int x_cs, const float* packed_w, const fl
  * uncut sum.  workspace = NULL: one workgroup per tile. */
 size_t pwc_conv3x3_h2_workspace_floats(int N, int H, int W, int Cin_phys, int Cout, int dilation);
 int pwc_conv3x3_h2_supported(int N, int H, int W, int Cin_phys, int Cout, int dilation);
+/* TWO chained 3x3 stride-1 'SAME' convolutions of 16 channels each (16 -> 16 -> 16) with a leaky-relu of slope `slope`
+ * behind each, in one launch (csrc/conv3x3_c16pair.hip; reference modules.py:62-67, the `fp_extractor/conv2d_1`,
+ * `conv2d_2` pair of pyramid level 1): the intermediate stays in LDS instead of making a round trip through memory.
+ * Arithmetic as pwc_conv3x3_h2_f32 (fp32 in / out / accumulation, exact-to-22-bit fp16 operand pairs, three products;
+ * the intermediate is rounded to fp32 exactly as a tensor in memory would be; inputs below 65504).  packed comes from
+ * pwc_conv3x3_c16pair_pack_f32 (both HWIO (3,3,16,16) kernels; pwc_conv3x3_c16pair_packed_floats floats).  x, y: NHWC
+ * with channel strides x_cs, y_cs >= 16 (multiples of 4), 16-byte aligned.  _supported: 1 where the fused launch is
+ * the faster way to run the pair (at least one 16 x 32-pixel tile per CU). */
+size_t pwc_conv3x3_c16pair_packed_floats(void);
+int pwc_conv3x3_c16pair_pack_f32(const float* w1_hwio, const float* w2_hwio, float* packed, pwc_stream_t stream);
+int pwc_conv3x3_c16pair_f32(const float* x, int x_cs, const float* packed, const float* bias1, const float* bias2,
+                            float* y, int y_cs, int N, int H, int W, float slope, pwc_stream_t stream);
+int pwc_conv3x3_c16pair_supported(int N, int H, int W);
 /* Stride 2 ('SAME', dilation 1; the extractor's down-sampling layers, reference modules.py:57-60) through the same
  * kernel: the launch of the stride-1 convolution over the (H, W) input that stores only the sums a stride-2 convolution
  * has.  y is (N, ceil(H/2), ceil(W/2)) with channel stride y_cs; everything else as pwc_conv3x3_h2_f32 (packed_w from

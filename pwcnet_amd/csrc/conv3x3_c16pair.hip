@@ -1,0 +1,267 @@
+// conv3x3_c16pair.hip -- TWO chained 3x3 stride-1 'SAME' convolutions of 16 channels each (16 -> 16 -> 16), leaky-relu behind
+// each, in ONE launch, on the F16 matrix pipe of gfx950 with the exact-to-22-bit operand splits of conv3x3_h2.hip (round 4).
+//
+// Replaces the two tf.layers.Conv2D(16, (3,3), (1,1), 'same') + tf.nn.leaky_relu calls behind the stride-2 convolution of
+// pyramid level 1 (reference modules.py:62-67 `fp_extractor/conv2d_1`, `conv2d_2`).  The intermediate (117 MB for a batch of 8
+// pairs at 448 x 1024) never leaves the CU: a workgroup computes a 16 x 32-pixel output tile from the 20 x 36-pixel input patch
+// through the 18 x 34-pixel intermediate held in LDS.  As two launches of the fp32 Winograd kernel the pair takes 160 us (each
+// moves 235 MB and runs at 30 % of the fp32 matrix pipe); here the matrix work is 14 v_mfma_f32_16x16x32_f16 per 16 pixels and
+// layer.
+//
+// Arithmetic: as conv3x3_h2.hip -- x = h + 2^-11 m', three products, two fp32 accumulators (hh, cross); the intermediate is
+// rounded to fp32 once (bias, leaky-relu) and split again, exactly like an fp32 tensor read back from memory would be.
+// K packing of a 16x16x32 MFMA (M = couts, N = 16 pixels; lane quarter kq holds K 8 kq .. 8 kq + 7):
+//   hh, tap pair (2j, 2j+1):  A = [uh(tap 2j) ch 0-7 | ch 8-15 | uh(tap 2j+1) ch 0-7 | ch 8-15]   B = vh shifted by the quarter's tap
+//   cross, tap t:             A = [uh ch 0-7 | uh ch 8-15 | um' ch 0-7 | um' ch 8-15]              B = [vm' 0-7 | vm' 8-15 | vh 0-7 | vh 8-15]
+//   = 5 + 9 = 14 instructions per 16 pixels and layer; the 28 weight operands of the two layers stay in registers.
+// LDS images are [chunk: h 0-7, h 8-15, m' 0-7, m' 8-15][pixel, row pitch 36][16 bytes]: a tile of 16 CONSECUTIVE linear pixel
+// indices p (it may wrap from one patch row to the next) reads 16 consecutive 16-byte records per chunk at p + (dy-1) 36 + (dx-1)
+// -- wrapped pixels are columns nobody needs.  Intermediate pixels outside the IMAGE are the second convolution's zero padding,
+// not convolution results: they are zeroed before they are split.
+// Persistent: one workgroup per CU loops over tiles; the patch of the next tile is fetched (LDS-DMA into the staging image)
+// under the two layers of the current one.  Three barriers per tile.
+#pragma once
+#include "pwc_common.h"
+
+typedef _Float16 c16_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 c16_f16x4 __attribute__((ext_vector_type(4)));
+
+struct C16Args {
+    const float* x;
+    const void* wp;          // [layer 2][operand 14][lane 64][8 fp16]
+    const float* b1;
+    const float* b2;
+    float* y;
+    int x_cs, y_cs;
+    int N, H, W;
+    float slope;
+    int tiles_x, tiles_y, ntiles;
+};
+
+constexpr int C16_P = 36;                      // patch width = row pitch of the LDS images
+constexpr int C16_PR = 20;                     // patch rows
+constexpr int C16_NPIX = C16_P * C16_PR;       // 720
+constexpr int C16_CH = C16_NPIX * 16;          // bytes of a chunk plane: 11 520
+constexpr int C16_IMG = 4 * C16_CH;            // 46 080
+constexpr int C16_NPC = 48;                    // 1 KB staging pieces (45 hold records)
+constexpr int C16_S0 = 0, C16_IN0 = C16_NPC * 1024, C16_MID0 = C16_IN0 + C16_IMG, C16_LDS = C16_MID0 + C16_IMG + 1024;
+constexpr int C16_MT_A = 41;                   // 16-pixel tiles of the intermediate: linear pixels [36, 692)
+constexpr int C16_MT_B = 36;                   // ... of the output: [72, 648) = rows 2 .. 17
+constexpr unsigned C16_OOB = 0x7FFF0000u;
+
+__global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float c16_smem[];
+    char* const sm = reinterpret_cast<char*>(c16_smem);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int n16 = lane & 15, kq = lane >> 4;
+
+    // ---- the 28 weight operands and the lane's four biases of each layer
+    c16_f16x8 A1[14], A2[14];
+#pragma unroll
+    for (int m = 0; m < 14; ++m) {
+        A1[m] = reinterpret_cast<const c16_f16x8*>(a.wp)[m * 64 + lane];
+        A2[m] = reinterpret_cast<const c16_f16x8*>(a.wp)[(14 + m) * 64 + lane];
+    }
+    const f32x4 b1v = *reinterpret_cast<const f32x4*>(a.b1 + 4 * kq);
+    const f32x4 b2v = *reinterpret_cast<const f32x4*>(a.b2 + 4 * kq);
+
+    // ---- per-lane fragment offsets (bytes into an image, for the tile at linear pixel 0)
+    auto tap_shift = [](int tp) { return (tp / 3) * C16_P + (tp % 3) - (C16_P + 1); };
+    int hoff[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int tp = 2 * j + (kq >> 1) > 8 ? 8 : 2 * j + (kq >> 1);      // (the tenth tap has zero weights)
+        hoff[j] = (kq & 1) * C16_CH + (n16 + tap_shift(tp)) * 16;
+    }
+    const int coff = ((kq + 2) & 3) * C16_CH + n16 * 16;
+
+    const int G = (int)gridDim.x;
+    const int lw = pwc_xcd_remap(blockIdx.x, G);
+    const int per = (a.ntiles + G - 1) / G;
+    const int tile0 = lw * per, tile1 = tile0 + per < a.ntiles ? tile0 + per : a.ntiles;      // a contiguous run: neighbours share halos in L2
+
+    // ---- patch fetch: piece pc = wave + 8 i holds records 16 pc .. 16 pc + 15 (record = patch pixel, 64 bytes)
+    unsigned p_voff[6];
+    __amdgpu_buffer_rsrc_t xrsrc;
+    auto patch_prepare = [&](int tile) {
+        const int bx = tile % a.tiles_x;
+        const int rest = tile / a.tiles_x;
+        const int by = rest % a.tiles_y, n = rest / a.tiles_y;
+        xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int rec = (wave + 8 * i) * 16 + (lane >> 2);
+            const int pr = rec / C16_P, pc = rec - pr * C16_P;
+            const int yy = by * 16 - 2 + pr, xx = bx * 32 - 2 + pc;
+            const bool ok = rec < C16_NPIX && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            p_voff[i] = ok ? (unsigned)(((yy * a.W + xx) * a.x_cs + (lane & 3) * 4) * 4) : C16_OOB;
+        }
+    };
+    auto patch_issue = [&]() {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(sm + C16_S0 + (wave + 8 * i) * 1024), 16, (int)p_voff[i], 0, 0, 0);
+    };
+#define C16_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+    // one 16-pixel tile of a layer: 14 fragment reads, 14 matrix instructions; returns hh + 2^-11 cross
+    auto mtile = [&](const char* img, int p0, const c16_f16x8* A) -> f32x4 {
+        c16_f16x8 B[14];
+        const char* base = img + p0 * 16;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) B[j] = *reinterpret_cast<const c16_f16x8*>(base + hoff[j]);
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) B[5 + tp] = *reinterpret_cast<const c16_f16x8*>(base + coff + tap_shift(tp) * 16);
+        f32x4 hh = {0.f, 0.f, 0.f, 0.f}, cx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 14; ++m) {
+            // (alternating accumulators keeps two dependent chains in flight)
+            if (m < 5) hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[m], B[m], hh, 0, 0, 0);
+            if (m + 5 < 14) cx = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[m + 5], B[m + 5], cx, 0, 0, 0);
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = hh[e] + cx[e] * (1.f / 2048.f);
+        return o;
+    };
+
+    if (tile0 < tile1) {
+        patch_prepare(tile0);
+        patch_issue();
+    }
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int bx = tile % a.tiles_x;
+        const int rest = tile / a.tiles_x;
+        const int by = rest % a.tiles_y, n = rest / a.tiles_y;
+        const int y0 = by * 16, x0 = bx * 32;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        C16_BAR();                                   // the patch has landed; everybody is done with the images of the previous tile
+        // ---- split the staging image: item = (patch pixel, 4-channel group)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int it = t + 512 * j;
+            if (it < C16_NPIX * 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(sm + C16_S0 + it * 16);
+                const int rec = it >> 2, g = it & 3;
+                c16_f16x4 h, m;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = (_Float16)v[e];
+                    m[e] = (_Float16)__builtin_fmaf((float)h[e], -2048.f, v[e] * 2048.f);
+                }
+                char* dst = sm + C16_IN0 + (g >> 1) * C16_CH + rec * 16 + (g & 1) * 8;
+                *reinterpret_cast<c16_f16x4*>(dst) = h;
+                *reinterpret_cast<c16_f16x4*>(dst + 2 * C16_CH) = m;
+            }
+        }
+        C16_BAR();
+        if (tile + 1 < tile1) {                      // the next patch, under the two layers
+            patch_prepare(tile + 1);
+            patch_issue();
+        }
+        // ---- layer 1: intermediate pixels [36, 692) -> bias, leaky-relu, zero outside the image, split, into LDS
+        for (int mt = wave; mt < C16_MT_A; mt += 8) {
+            const int p0 = C16_P + mt * 16;
+            f32x4 o = mtile(sm + C16_IN0, p0, A1);
+            const int p = p0 + n16, pr = p / C16_P, pc = p - pr * C16_P;
+            const bool in_image = (unsigned)(y0 - 2 + pr) < (unsigned)a.H && (unsigned)(x0 - 2 + pc) < (unsigned)a.W;
+            c16_f16x4 h, m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = o[e] + b1v[e];
+                v = fmaxf(v, v * a.slope);
+                v = in_image ? v : 0.f;
+                h[e] = (_Float16)v;
+                m[e] = (_Float16)__builtin_fmaf((float)h[e], -2048.f, v * 2048.f);
+            }
+            char* dst = sm + C16_MID0 + (kq >> 1) * C16_CH + p * 16 + (kq & 1) * 8;
+            *reinterpret_cast<c16_f16x4*>(dst) = h;
+            *reinterpret_cast<c16_f16x4*>(dst + 2 * C16_CH) = m;
+        }
+        C16_BAR();
+        // ---- layer 2: output rows 2 .. 17 of the patch -> bias, leaky-relu, 16 bytes (4 couts) per lane
+        const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.y + (size_t)n * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
+        for (int mt = wave; mt < C16_MT_B; mt += 8) {
+            const int p0 = 2 * C16_P + mt * 16;
+            f32x4 o = mtile(sm + C16_MID0, p0, A2);
+            const int p = p0 + n16, pr = p / C16_P, pc = p - pr * C16_P;
+            const int yy = y0 - 2 + pr, xx = x0 - 2 + pc;
+            const bool ok = pc >= 2 && pc < 34 && yy < a.H && xx < a.W;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] += b2v[e];
+                o[e] = fmaxf(o[e], o[e] * a.slope);
+            }
+            const unsigned vo = ok ? (unsigned)(((yy * a.W + xx) * a.y_cs + 4 * kq) * 4) : C16_OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, (int)vo, 0, 0);
+        }
+    }
+#undef C16_BAR
+}
+
+// ---------------------------------------------------------------- weight split + packing
+// packed[layer][operand m 14][lane 64][8 fp16]; lane = (cout i = lane & 15, K quarter kq = lane >> 4), see the header comment.
+__global__ void conv3x3_c16pair_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                            unsigned short* __restrict__ packed) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // (layer, m, lane, e)
+    if (idx >= 2 * 14 * 64 * 8) return;
+    const int e = idx & 7, lane = (idx >> 3) & 63, m = (idx >> 9) % 14, layer = idx / (14 * 512);
+    const int i = lane & 15, kq = lane >> 4;
+    const float* w = layer ? w2 : w1;                           // HWIO (3,3,16,16)
+    int tap, ch;
+    bool low;                                                   // um' (else uh)
+    if (m < 5) { tap = 2 * m + (kq >> 1); ch = 8 * (kq & 1) + e; low = false; }
+    else { tap = m - 5; ch = 8 * (kq & 1) + e; low = kq >= 2; }
+    float u = 0.f;
+    if (tap < 9) u = w[(tap * 16 + ch) * 16 + i];
+    const _Float16 h = (_Float16)u;
+    const _Float16 lo = (_Float16)((u - (float)h) * 2048.f);
+    packed[idx] = __builtin_bit_cast(unsigned short, low ? lo : h);
+}
+
+extern "C" size_t pwc_conv3x3_c16pair_packed_floats(void) { return 2 * 14 * 64 * 8 / 2; }
+
+extern "C" int pwc_conv3x3_c16pair_pack_f32(const float* w1_hwio, const float* w2_hwio, float* packed, pwc_stream_t stream) {
+    if (!w1_hwio || !w2_hwio || !packed) return PWC_EINVAL;
+    hipLaunchKernelGGL(conv3x3_c16pair_pack_kernel, dim3((2 * 14 * 64 * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       w1_hwio, w2_hwio, reinterpret_cast<unsigned short*>(packed));
+    return pwc_launch_status();
+}
+
+// 1 where the fused launch is the faster way to run the pair (at least one tile per CU).
+extern "C" int pwc_conv3x3_c16pair_supported(int N, int H, int W) {
+    if (N <= 0 || H < 16 || W < 32) return 0;
+    return (long)N * ((H + 15) / 16) * ((W + 31) / 32) >= 256 ? 1 : 0;
+}
+
+extern "C" int pwc_conv3x3_c16pair_f32(const float* x, int x_cs, const float* packed, const float* bias1, const float* bias2,
+                                       float* y, int y_cs, int N, int H, int W, float slope, pwc_stream_t stream) {
+    if (!x || !packed || !bias1 || !bias2 || !y) return PWC_EINVAL;
+    if (N <= 0 || H <= 0 || W <= 0 || x_cs < 16 || y_cs < 16) return PWC_EINVAL;
+    if ((x_cs & 3) || (y_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(y) || !pwc_aligned16(packed) || !pwc_aligned16(bias1) ||
+        !pwc_aligned16(bias2))
+        return PWC_EALIGN;
+    if ((long)H * W * x_cs * 4 >= (long)C16_OOB || (long)H * W * y_cs * 4 >= (long)C16_OOB) return PWC_ERANGE;
+    C16Args a;
+    a.x = x; a.wp = packed; a.b1 = bias1; a.b2 = bias2; a.y = y; a.x_cs = x_cs; a.y_cs = y_cs;
+    a.N = N; a.H = H; a.W = W; a.slope = slope;
+    a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 15) / 16;
+    const long nt = (long)N * a.tiles_x * a.tiles_y;
+    if (nt >= (1L << 31)) return PWC_ERANGE;
+    a.ntiles = (int)nt;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int grid = a.ntiles < cus ? a.ntiles : cus;
+    static PwcDevOnce attr_once;
+    if (pwc_first_on_device(&attr_once))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c16pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS);
+    hipLaunchKernelGGL(conv3x3_c16pair_kernel, dim3((unsigned)grid), dim3(512), C16_LDS, (hipStream_t)stream, a);
+    return pwc_launch_status();
+}

@@ -217,6 +217,47 @@ class _ConvRunner:
         self.scope = _scoped(owner.name)
         self.store = default_store()
 
+    def conv_pair(self, x, cout, slope=0.1):
+        """Two consecutive stride-1 convs x -> cout -> cout (conv2d_k, conv2d_{k+1}), both + leaky_relu.  16 -> 16 -> 16 on
+        a shape pwc_conv3x3_c16pair_supported names: ONE launch with the intermediate in LDS; otherwise two conv() calls.
+        Returns (View y, tensor)."""
+        L = _lib.lib()
+        fused = (x.C == 16 and cout == 16 and slope is not None and getattr(self.owner, "f16x2", True)
+                 and x.cs % 4 == 0 and x.ptr % 16 == 0 and L.pwc_conv3x3_c16pair_supported(x.N, x.H, x.W))
+        if not fused:
+            x, _ = self.conv(x, cout, slope=slope)
+            return self.conv(x, cout, slope=slope)
+        names = []
+        for _ in range(2):
+            names.append(self.scope + "/conv2d" + ("" if self.k == 0 else f"_{self.k}"))
+            self.k += 1
+        k1 = self.store.get(names[0] + "/kernel", (3, 3, 16, 16), "kernel")
+        b1 = self.store.get(names[0] + "/bias", (16,), "bias")
+        k2 = self.store.get(names[1] + "/kernel", (3, 3, 16, 16), "kernel")
+        b2 = self.store.get(names[1] + "/bias", (16,), "bias")
+        dev = k1.value.device
+        s = _lib.current_stream()
+        y_t = torch.empty((x.N, x.H, x.W, 16), dtype=torch.float32, device=dev)
+        y = View(y_t.data_ptr(), 16, x.N, x.H, x.W, 16)
+        cache = self.owner._cache
+        key = (names[0], "c16pair", self.store.version)
+        packed = cache.get(key)
+        if packed is None:
+            packed = torch.empty((L.pwc_conv3x3_c16pair_packed_floats(),), dtype=torch.float32, device=dev)
+            _lib.check(L.pwc_conv3x3_c16pair_pack_f32(_p(k1.value.data_ptr()), _p(k2.value.data_ptr()), _p(packed.data_ptr()), s),
+                       "conv3x3 c16pair pack")
+            cache[key] = packed
+        _keep(packed, y_t)
+        M = x.N * x.H * x.W
+        _launch(L.pwc_conv3x3_c16pair_f32,
+                (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(b1.value.data_ptr()), _p(b2.value.data_ptr()), _p(y.ptr), y.cs,
+                 x.N, x.H, x.W, float(slope), s),
+                f"conv3x3_c16pair {names[0]}+{names[1]}", "conv3x3_c16pair_kernel",
+                2.0 * 2.0 * M * 9 * 16 * 16, 4.0 * (M * 16 + M * 16),
+                # executed: 14 MFMAs of 16x16x32 per 16 pixels and layer on 1.27 / 1.13 x the tile's pixels (halo, row wrap)
+                exec_flops=2.0 * 14 * 16 * 16 * 32 * (41 + 36) * (M / 512.0))
+        return y, y_t
+
     def conv(self, x, cout, y=None, stride=1, dilation=1, slope=0.1, cin_map=None,
              cin_logical=None, residual=None, tile=-1, split=0):
         """x: View over the PHYSICAL input channels.  cin_map: physical->logical map (or
@@ -538,8 +579,7 @@ class FeaturePyramidExtractor_custom(_Module):
                 x = View(y_t.data_ptr(), f, n_tot, Ho, Wo, f)
             else:
                 x, y_t = run.conv(x, f, stride=2)
-            x, t1 = run.conv(x, f)
-            x, t2 = run.conv(x, f)
+            x, t2 = run.conv_pair(x, f)
             feats.append(t2)
         return feats
 

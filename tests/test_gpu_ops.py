@@ -376,6 +376,37 @@ def test_conv_f16x2_direct_stride2_vs_oracle(pa, N, H, W, cin, cout):
         assert float(y[..., cout:].min()) == -7.0 and float(y[..., cout:].max()) == -7.0
 
 
+@pytest.mark.parametrize("N,H,W,xcs,ycs", [(2, 50, 70, 16, 16), (1, 16, 32, 16, 16), (3, 33, 47, 20, 24), (1, 97, 130, 16, 16),
+                                          (16, 224, 512, 16, 16)])
+def test_conv_c16_pair_vs_oracle(pa, N, H, W, xcs, ycs):
+    """pwc_conv3x3_c16pair_f32: conv2d_1 + conv2d_2 of pyramid level 1 (16 -> 16 -> 16, leaky-relu behind each) in one launch
+    with the intermediate in LDS, against the oracle's two convolutions: ragged 16 x 32-pixel tiles (the intermediate's zero
+    padding at the image border is NOT a convolution result), strided input and output with untouched neighbours, the
+    production shape (first and last image).  fp32 default tolerance."""
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    x = rnd((N, H, W, 16), 471)
+    k1 = rnd((3, 3, 16, 16), 472) * float(1.0 / np.sqrt(9 * 16))
+    k2 = rnd((3, 3, 16, 16), 473) * float(1.0 / np.sqrt(9 * 16))
+    b1, b2 = rnd((16,), 474) * 0.1, rnd((16,), 475) * 0.1
+    xp = np.full((N, H, W, xcs), 3.0, np.float32)
+    xp[..., :16] = x
+    xg = gpu(xp)
+    packed = torch.empty(L.pwc_conv3x3_c16pair_packed_floats(), device="cuda")
+    k1g, k2g = gpu(k1), gpu(k2)
+    _lib.check(L.pwc_conv3x3_c16pair_pack_f32(_p(k1g), _p(k2g), _p(packed), None))
+    y = torch.full((N, H, W, ycs), -7.0, device="cuda")
+    b1g, b2g = gpu(b1), gpu(b2)
+    _lib.check(L.pwc_conv3x3_c16pair_f32(_p(xg), xcs, _p(packed), _p(b1g), _p(b2g), _p(y), ycs, N, H, W, 0.1, None))
+    torch.cuda.synchronize()
+    for i in sorted({0, N - 1}):
+        mid = orc.conv3x3(x[i:i + 1], k1, b1, 1, 1, 0.1)
+        close(y[i:i + 1, ..., :16], orc.conv3x3(mid, k2, b2, 1, 1, 0.1))
+    assert bool(torch.isfinite(y).all())
+    if ycs > 16:
+        assert float(y[..., 16:].min()) == -7.0 and float(y[..., 16:].max()) == -7.0
+
+
 def test_conv_f16x2_direct_physical_layout_range_and_plan(pa):
     """Padded / permuted physical input channels through cin_map (the estimator buffers); operands of very different
     magnitudes (the split is relative, not absolute); an input beyond fp16's range poisons exactly the outputs that
