@@ -18,6 +18,13 @@
 // indices p (it may wrap from one patch row to the next) reads 16 consecutive 16-byte records per chunk at p + (dy-1) 36 + (dx-1)
 // -- wrapped pixels are columns nobody needs.  Intermediate pixels outside the IMAGE are the second convolution's zero padding,
 // not convolution results: they are zeroed before they are split.
+// Where the time goes (profiles/r04_exp_c16pair.txt, 16 x 224 x 512): 100 us; the two layers alone 74, fetch + split + barriers
+// alone 28.  A 16x16x32 MFMA with only 16 couts as M reads a fresh 1 KB pixel operand per instruction: 4 SIMDs x 1 KB per 16
+// cycles IS the LDS's 256 B/clk, so the layers are LDS-read-bound at the matrix pipe's own rate (35 us each way, not
+// overlapping fully); re-fetching a consumed fragment for the next tile behind its instruction (rolling prefetch, three
+// accumulator chains) made it 109 us.  What would halve the reads: v_mfma_f32_32x32x16_f16 with M = [uh | um'] stacked (hh and
+// um' vh from ONE pixel operand, rows r and r + 16 of a lane's accumulator) -- 2 KB and 64 pipe cycles per tap and 32 pixels
+// instead of 3.1 KB and 50.
 // Persistent: one workgroup per CU loops over tiles; the patch of the next tile is fetched (LDS-DMA into the staging image)
 // under the two layers of the current one.  Three barriers per tile.
 #pragma once
@@ -49,6 +56,8 @@ constexpr int C16_MT_A = 41;                   // 16-pixel tiles of the intermed
 constexpr int C16_MT_B = 36;                   // ... of the output: [72, 648) = rows 2 .. 17
 constexpr unsigned C16_OOB = 0x7FFF0000u;
 
+// ABL (harness only): 1 = no patch DMA, 2 = no split of the staging image, 4 = no layer 1, 8 = no layer 2
+template <int ABL = 0>
 __global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
     typedef __attribute__((address_space(3))) void* lptr_t;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
     auto patch_issue = [&]() {
 #pragma unroll
         for (int i = 0; i < 6; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(sm + C16_S0 + (wave + 8 * i) * 1024), 16, (int)p_voff[i], 0, 0, 0);
+            if (!(ABL & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(sm + C16_S0 + (wave + 8 * i) * 1024), 16, (int)p_voff[i], 0, 0, 0);
     };
 #define C16_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int it = t + 512 * j;
-            if (it < C16_NPIX * 4) {
+            if (it < C16_NPIX * 4 && !(ABL & 2)) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(sm + C16_S0 + it * 16);
                 const int rec = it >> 2, g = it & 3;
                 c16_f16x4 h, m;
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
             patch_issue();
         }
         // ---- layer 1: intermediate pixels [36, 692) -> bias, leaky-relu, zero outside the image, split, into LDS
-        for (int mt = wave; mt < C16_MT_A; mt += 8) {
+        for (int mt = wave; mt < ((ABL & 4) ? 0 : C16_MT_A); mt += 8) {
             const int p0 = C16_P + mt * 16;
             f32x4 o = mtile(sm + C16_IN0, p0, A1);
             const int p = p0 + n16, pr = p / C16_P, pc = p - pr * C16_P;
@@ -185,7 +194,7 @@ __global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
         // ---- layer 2: output rows 2 .. 17 of the patch -> bias, leaky-relu, 16 bytes (4 couts) per lane
         const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.y + (size_t)n * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
-        for (int mt = wave; mt < C16_MT_B; mt += 8) {
+        for (int mt = wave; mt < ((ABL & 8) ? 0 : C16_MT_B); mt += 8) {
             const int p0 = 2 * C16_P + mt * 16;
             f32x4 o = mtile(sm + C16_MID0, p0, A2);
             const int p = p0 + n16, pr = p / C16_P, pc = p - pr * C16_P;
@@ -238,8 +247,9 @@ extern "C" int pwc_conv3x3_c16pair_supported(int N, int H, int W) {
     return (long)N * ((H + 15) / 16) * ((W + 31) / 32) >= 256 ? 1 : 0;
 }
 
-extern "C" int pwc_conv3x3_c16pair_f32(const float* x, int x_cs, const float* packed, const float* bias1, const float* bias2,
-                                       float* y, int y_cs, int N, int H, int W, float slope, pwc_stream_t stream) {
+template <int ABL = 0>
+static int c16pair_run(const float* x, int x_cs, const float* packed, const float* bias1, const float* bias2,
+                       float* y, int y_cs, int N, int H, int W, float slope, pwc_stream_t stream) {
     if (!x || !packed || !bias1 || !bias2 || !y) return PWC_EINVAL;
     if (N <= 0 || H <= 0 || W <= 0 || x_cs < 16 || y_cs < 16) return PWC_EINVAL;
     if ((x_cs & 3) || (y_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(y) || !pwc_aligned16(packed) || !pwc_aligned16(bias1) ||
@@ -261,7 +271,12 @@ extern "C" int pwc_conv3x3_c16pair_f32(const float* x, int x_cs, const float* pa
     const int grid = a.ntiles < cus ? a.ntiles : cus;
     static PwcDevOnce attr_once;
     if (pwc_first_on_device(&attr_once))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c16pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS);
-    hipLaunchKernelGGL(conv3x3_c16pair_kernel, dim3((unsigned)grid), dim3(512), C16_LDS, (hipStream_t)stream, a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c16pair_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS);
+    hipLaunchKernelGGL((conv3x3_c16pair_kernel<ABL>), dim3((unsigned)grid), dim3(512), C16_LDS, (hipStream_t)stream, a);
     return pwc_launch_status();
+}
+
+extern "C" int pwc_conv3x3_c16pair_f32(const float* x, int x_cs, const float* packed, const float* bias1, const float* bias2,
+                                       float* y, int y_cs, int N, int H, int W, float slope, pwc_stream_t stream) {
+    return c16pair_run<0>(x, x_cs, packed, bias1, bias2, y, y_cs, N, H, W, slope, stream);
 }

@@ -96,6 +96,12 @@ int main() {
         }
         std::sort(ta.begin(), ta.end()); std::sort(tb.begin(), tb.end());
         printf("  medians of 7 interleaved rounds: fused %.1f us (min %.1f), two F(2x2) launches %.1f us (min %.1f)\n", ta[3], ta[0], tb[3], tb[0]);
+        if (sh.N == 16) {
+            auto ab = [&](auto tag) { return time_us([&](int) { c16pair_run<decltype(tag)::value>(x, 16, up, b1, b2, yf, 16, sh.N, sh.H, sh.W, 0.1f, 0); }, 10); };
+            printf("  ablations: no patch DMA %.1f | no split %.1f | no layer 1 %.1f | no layer 2 %.1f | no layers %.1f | no DMA, no split %.1f | nothing %.1f us\n",
+                   ab(std::integral_constant<int, 1>{}), ab(std::integral_constant<int, 2>{}), ab(std::integral_constant<int, 4>{}), ab(std::integral_constant<int, 8>{}),
+                   ab(std::integral_constant<int, 12>{}), ab(std::integral_constant<int, 3>{}), ab(std::integral_constant<int, 15>{}));
+        }
         (void)hipFree(x); (void)hipFree(w1); (void)hipFree(w2); (void)hipFree(b1); (void)hipFree(b2); (void)hipFree(ym); (void)hipFree(yr); (void)hipFree(yf);
         (void)hipFree(u1); (void)hipFree(u2); (void)hipFree(up);
     }
