@@ -79,6 +79,7 @@ struct H2Args {
 constexpr unsigned H2_OOB = 0x7FFF0000u;
 constexpr int H2_MAX_COUT = 512;             // (the bias lives in LDS)
 constexpr int H2_SC1 = 16;                   // aux bit of the buffer intrinsics: device-scope access (gfx940+)
+constexpr int H2_MIN_STAGES = 3;              // stream-K only where a CU gets at least this many 16-channel stages
 constexpr unsigned H2_EMPTY = 0xFFFFFFFFu;    // workspace word that holds no published sum
 constexpr int H2_PW = 34;                    // patch width in pixels
 constexpr int H2_CHK = H2_PW * 16;           // bytes of a chunk row in the operand image: 544
@@ -125,9 +126,9 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     const int nc16 = a.Cin_phys >> 4;
     const int nct_all = a.Cout >> 5;                // cout tiles of 32 in the packed image
     // ---- the workgroup's range of the launch's (tile, channel stage) sequence.  Tiles: cout block fastest, then the pixel
-    // tiles of a (sub-)image; logical workgroup ids are XCD-aware (neighbouring ranges share an L2).  gridDim.x <= ntiles, so a
-    // range holds at least one whole tile's worth of stages: a tile is cut into at most TWO pieces, the first at the END of
-    // workgroup w's range, the second at the START of workgroup w + 1's.
+    // tiles of a (sub-)image; logical workgroup ids are XCD-aware (neighbouring ranges share an L2).  A tile is cut into as many
+    // pieces as ranges touch it: the piece that holds the tile's FIRST stage sits at the end of workgroup w's range, the others
+    // belong to workgroups w + 1, w + 2, ... (the last one at the START of its owner's range).
     const int G = (int)gridDim.x;
     const int lw = pwc_xcd_remap(blockIdx.x, G);
     const long total = (long)a.ntiles * nc16;
@@ -277,7 +278,8 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     // output line of the launch -- per workgroup; a flag behind plain device-scope stores was seen to overtake them.)
     // Lane = (pixel column ln, couts (r & 3) + 8 (r >> 2) + 4 kh of a tile).
     constexpr int PART_FLOATS = C::NCT * 32 * C::TR * 32;
-    auto finish = [&](const Tile& tl, int kind, bool with_other) {
+    auto finish = [&](const Tile& tl, int kind, int nother) {
+        const bool with_other = nother > 0;
         if (kind == 1) {
             // buffer addressing (base in SGPRs, one lane offset): flat pointers would cost two VGPRs per access, hoisted
             const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
@@ -304,10 +306,6 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
                     }
             return;
         }
-        __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, 0, 0x00020000);
-        if (with_other)
-            prs = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(a.ws_partial + (size_t)(lw + 1) * PART_FLOATS + (size_t)wave * (CT * PT * 16 * 64)), 0, CT * PT * 16 * 64 * 4, 0x00020000);
         const int y0 = tl.by * C::TR, x0 = tl.bx * 32, n0 = tl.cb * 32 * C::NCT;
         const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.y + (size_t)tl.n * a.Ho * a.Wo * a.y_cs), 0, a.Ho * a.Wo * a.y_cs * 4, 0x00020000);
@@ -326,7 +324,9 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = acc[ct][pt][4 * q + e] + accx[ct][pt][4 * q + e] * (1.f / 2048.f);
-                    if (with_other) {
+                    for (int k = 1; k <= nother; ++k) {      // the other pieces, in the order of their stages
+                        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+                            (void*)(a.ws_partial + (size_t)(lw + k) * PART_FLOATS + (size_t)wave * (CT * PT * 16 * 64)), 0, CT * PT * 16 * 64 * 4, 0x00020000);
                         const int po = ((pt * CT + ct) * 4 + q) * 1024;
                         u32x4 p4 = __builtin_amdgcn_raw_buffer_load_b128(prs, lane * 16, po, H2_SC1);
                         // bounded (~1 s): a sum that never arrives (it cannot, short of a fault) leaves the sentinel -- a NaN --
@@ -342,9 +342,9 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
                         const f32x4 pf = __builtin_bit_cast(f32x4, p4);
                         if ((ABL & 64) && a.dbg) {
                             for (int e = 0; e < 4; ++e)
-                                if (p4[e] != (0x40000000u | ((unsigned)((lw + 1) & 255) << 16) | ((unsigned)wave << 12) | ((unsigned)((pt * CT + ct) * 4 + q) << 8) | (lane << 2) | e)) {
+                                if (p4[e] != (0x40000000u | ((unsigned)((lw + k) & 255) << 16) | ((unsigned)wave << 12) | ((unsigned)((pt * CT + ct) * 4 + q) << 8) | (lane << 2) | e)) {
                                     atomicAdd(a.dbg + ((lane >> 2) & 3), 1u); a.dbg[4 + ((lane >> 2) & 3)] = p4[e]; a.dbg[8] = pt * 100 + ct * 10 + q;
-                                    a.dbg[9] = (0x40000000u | ((unsigned)((lw + 1) & 255) << 16) | ((unsigned)wave << 12) | ((unsigned)((pt * CT + ct) * 4 + q) << 8) | (lane << 2) | e);
+                                    a.dbg[9] = (0x40000000u | ((unsigned)((lw + k) & 255) << 16) | ((unsigned)wave << 12) | ((unsigned)((pt * CT + ct) * 4 + q) << 8) | (lane << 2) | e);
                                 }
                         }
 #pragma unroll
@@ -448,8 +448,7 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         cur = nxt;
     };
 
-    const bool head_is_second_piece = c16 != 0;      // the range starts inside a tile
-    bool first_piece = true;                          // ... and that tile's piece is still the current one
+    int piece_c0 = c16;                               // the stage of its tile the current piece began with
     bool drain = false;                               // output stores of the previous piece may be in flight
 #define H2_STAMP(k) do { if ((ABL & 4096) && a.dbg && lane == 0 && (lw == 0 || lw == 5) && g - g0 >= 8 && g - g0 < 12) \
         a.dbg[(((lw ? 1 : 0) * 8 + wave) * 4 + (g - g0 - 8)) * 16 + (k)] = (unsigned)__builtin_readcyclecounter(); } while (0)
@@ -510,10 +509,19 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         const bool tile_end = c16 == nc16 - 1;
         if (tile_end || !more) {
             if (ABL & 2048) tk0 = __builtin_readcyclecounter();
-            if (tile_end) finish(tcur, (first_piece && head_is_second_piece) ? 1 : 0, false);
-            else finish(tcur, 0, true);
+            if (piece_c0 != 0) {
+                finish(tcur, 1, 0);                     // not the tile's first stage: publish
+            } else if (tile_end) {
+                finish(tcur, 0, 0);                     // a whole tile
+            } else {
+                // the tile's first piece: the rest belongs to workgroups lw + 1, lw + 2, ... until one's range reaches the tile's end
+                const long tile_end_g = (long)(g - c16) + nc16;
+                int nother = 0;
+                for (int w2 = lw + 1; w2 < G && (long)w2 * total / G < tile_end_g; ++w2) ++nother;
+                finish(tcur, 0, nother);
+            }
             drain = true;
-            first_piece = false;
+            piece_c0 = 0;
             if (ABL & 2048) tk_fin += __builtin_readcyclecounter() - tk0;
         }
         step(tcur, c16);
@@ -601,7 +609,9 @@ static int h2_plan(int N, int H, int W, int Cin_phys, int Cout, int dilation, lo
     int best = 0;
     double best_cost = 0.;
     long best_blocks = 0;
-    for (int v = 1; v <= 5; ++v) {
+    const int order[5] = {1, 2, 3, 5, 4};          // (ties go to the wider tile)
+    for (int oi = 0; oi < 5; ++oi) {
+        const int v = order[oi];
         const H2Variant t = h2_variant(v);
         if (Cout % t.couts) continue;
         const long nb = h2_blocks(v, N, hs, ws, Cout, dilation);
@@ -613,17 +623,14 @@ static int h2_plan(int N, int H, int W, int Cin_phys, int Cout, int dilation, lo
     return best;
 }
 
-// 1 where this kernel is the faster one for the shape (measured against conv3x3_wino4.hip / conv3x3_wino.hip on isolated layers:
-// profiles/r04_exp_h2.txt): sub-lattices of at least 8 x 24 pixels, a launch that fills at least three quarters of the CUs, two or more channel stages
-// (32 -> 32 channels at 16 x 112 x 256: 48 us against F(2x2)'s 56).
-extern "C" int pwc_conv3x3_h2_supported(int N, int H, int W, int Cin_phys, int Cout, int dilation) {
-    long nb = 0;
-    if (!h2_plan(N, H, W, Cin_phys, Cout, dilation, &nb)) return 0;
-    const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
-    return hs >= 8 && ws >= 24 && nb >= 192 && Cin_phys >= 32 ? 1 : 0;
+// Stream-K (one workgroup per CU, equal shares of the (tile, stage) sequence) pays where it removes a partly filled last round
+// (more tiles than CUs), or where the launch has so few tiles that a CU's share is at least 5.5 stages shorter than a whole
+// tile's channel loop (measured, profiles/r04_exp_h2.txt: 192 -> 128 at 8 x 28 x 64 27 us against 34 us as 128 whole tiles; at
+// 224 tiles the exchange costs more than the 1.5 stages it saves: 76 against 70 us).
+static inline bool h2_split_pays(long ntiles, int nc16, int cus) {
+    if (ntiles > cus) return ntiles * nc16 >= (long)H2_MIN_STAGES * cus;
+    return ntiles < cus && ntiles * nc16 >= (long)H2_MIN_STAGES * cus && 2L * nc16 * (cus - ntiles) >= 11L * cus;
 }
-
-static unsigned* h2_debug_counters = nullptr;      // harness only
 
 static int h2_cu_count() {
     static int cus[64] = {0};
@@ -637,6 +644,19 @@ static int h2_cu_count() {
     return cus[dev];
 }
 
+// 1 where this kernel is the faster one for the shape (measured against conv3x3_wino4.hip / conv3x3_wino.hip on isolated layers:
+// profiles/r04_exp_h2.txt): sub-lattices of at least 8 x 24 pixels, a launch that fills at least three quarters of the CUs, two or more channel stages
+// (32 -> 32 channels at 16 x 112 x 256: 48 us against F(2x2)'s 56).
+extern "C" int pwc_conv3x3_h2_supported(int N, int H, int W, int Cin_phys, int Cout, int dilation) {
+    long nb = 0;
+    if (!h2_plan(N, H, W, Cin_phys, Cout, dilation, &nb)) return 0;
+    const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
+    const bool filled = nb >= 192 || (nb >= 64 && h2_split_pays(nb, Cin_phys >> 4, h2_cu_count()));     // (the latter needs the workspace)
+    return hs >= 8 && ws >= 24 && filled && Cin_phys >= 32 ? 1 : 0;
+}
+
+static unsigned* h2_debug_counters = nullptr;      // harness only
+
 template <int CT, int PT, int WCG, int ABL>
 static int h2_launch(H2Args& a, int hs, int ws, float* workspace, size_t workspace_floats, hipStream_t stream) {
     typedef H2Cfg<CT, PT, WCG> C;
@@ -644,13 +664,13 @@ static int h2_launch(H2Args& a, int hs, int ws, float* workspace, size_t workspa
     const long nblk = (long)a.N * a.dil * a.dil * a.tiles_x * a.tiles_y * a.ncb;
     if (nblk * (a.Cin_phys >> 4) >= (1L << 31)) return PWC_ERANGE;
     a.ntiles = (int)nblk;
-    // one workgroup per tile, or -- with a workspace and more tiles than CUs -- one workgroup per CU, each with an equal share
-    // of the (tile, stage) sequence
+    // one workgroup per tile, or -- with a workspace and at least H2_MIN_STAGES stages per CU -- one workgroup per CU, each with an
+    // equal share of the (tile, stage) sequence (a tile is then cut into as many pieces as ranges touch it)
     const int cus = h2_cu_count();
     int grid = a.ntiles;
     a.ws_partial = nullptr;
     const size_t part = (size_t)C::NCT * 32 * C::TR * 32;
-    if (workspace && a.ntiles > cus && workspace_floats >= (size_t)cus * part) {
+    if (workspace && h2_split_pays(a.ntiles, a.Cin_phys >> 4, cus) && workspace_floats >= (size_t)cus * part) {
         grid = cus;
         a.ws_partial = workspace;
     }
@@ -706,7 +726,7 @@ extern "C" size_t pwc_conv3x3_h2_workspace_floats(int N, int H, int W, int Cin_p
     long nb = 0;
     const int v = h2_plan(N, H, W, Cin_phys, Cout, dilation, &nb);
     const int cus = h2_cu_count();
-    if (!v || nb <= cus) return 0;
+    if (!v || !h2_split_pays(nb, Cin_phys >> 4, cus)) return 0;
     const H2Variant t = h2_variant(v);
     return (size_t)cus * t.couts * t.rows * 32;
 }

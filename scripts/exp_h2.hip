@@ -31,7 +31,8 @@ int main(int argc, char** argv) {
                       {2, 50, 70, 64, 64, 1, 80, 1.f}, {1, 16, 32, 64, 64, 1, 64, 1.f}, {2, 112, 256, 128, 128, 1, 128, 300.f},
                       {16, 112, 256, 32, 32, 1, 32, 1.f}, {16, 56, 128, 64, 64, 1, 64, 1.f}, {16, 28, 64, 96, 96, 1, 96, 1.f}, {8, 56, 128, 128, 96, 1, 128, 1.f},
                       {8, 56, 128, 96, 64, 1, 96, 1.f}, {8, 56, 128, 64, 32, 1, 64, 1.f}, {8, 112, 256, 48, 128, 1, 48, 1.f}, {8, 28, 64, 192, 128, 1, 192, 1.f},
-                      {8, 112, 256, 96, 64, 16, 96, 1.f}};
+                      {8, 112, 256, 96, 64, 16, 96, 1.f}, {8, 28, 64, 128, 128, 1, 128, 1.f}, {8, 28, 64, 128, 96, 1, 128, 1.f}, {8, 28, 64, 96, 64, 1, 96, 1.f},
+                      {8, 28, 64, 64, 32, 1, 64, 1.f}, {4, 28, 64, 192, 128, 1, 192, 1.f}};
     const size_t WSF = (size_t)304 * 32768;
     float* wsp; (void)hipMalloc(&wsp, WSF * 4); (void)hipMemset(wsp, 0xFF, WSF * 4);
     int idx = -1;

@@ -1,3 +1,3 @@
 mkdir -p gpurun_out/r4h
-timeout 300 ./scripts/exp_c16pair.bin > gpurun_out/r4h/c16pair.txt 2>&1
-grep -E "^==|fused vs|float64|medians" gpurun_out/r4h/c16pair.txt | cut -c1-200
+timeout 1200 python -m pytest tests/test_gpu_ops.py -x -q -k "f16x2" > gpurun_out/r4h/tests_h2.txt 2>&1
+tail -3 gpurun_out/r4h/tests_h2.txt

@@ -327,9 +327,11 @@ def h2_workspace(N, H, W, cs, cout, dil):
 
 
 @pytest.mark.parametrize("N,H,W,cin,cout,dil", [(8, 112, 256, 128, 128, 1), (8, 112, 256, 64, 32, 1), (3, 112, 250, 96, 96, 2),
-                                               (5, 100, 256, 48, 64, 1), (2, 224, 512, 32, 128, 4)])
+                                               (5, 100, 256, 48, 64, 1), (2, 224, 512, 32, 128, 4),
+                                               # fewer tiles than CUs: every tile is cut into several pieces
+                                               (8, 28, 64, 192, 128, 1), (8, 28, 64, 256, 64, 1)])
 def test_conv_f16x2_direct_stream_k(pa, N, H, W, cin, cout, dil):
-    """More tiles than CUs + a workspace: one workgroup per CU, each with an equal share of the (tile, stage) sequence; tiles
+    """More tiles than CUs (or far fewer) + a workspace: one workgroup per CU, each with an equal share of the (tile, stage) sequence; tiles
     cut in two are finished through the workspace.  Ten launches must agree BITWISE (the sum of two finished pieces does
     not depend on which workgroup is faster), match the one-workgroup-per-tile launch to fp32 rounding and the oracle on
     the first and the last image, and leave the workspace as they found it (every word 0xFFFFFFFF)."""
