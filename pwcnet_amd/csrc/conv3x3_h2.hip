@@ -316,40 +316,50 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
             const bool inside = py < a.H && px < a.W && (a.stride == 1 || ((((py - a.off_y) | (px - a.off_x)) & 1) == 0 && py >= a.off_y && px >= a.off_x));
             const int opy = a.stride == 1 ? py : (py - a.off_y) >> 1, opx = a.stride == 1 ? px : (px - a.off_x) >> 1;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+            for (int ct = 0; ct < CT; ++ct) {
+                f32x4 o4[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int co = n0 + (CT * cgw + ct) * 32 + 8 * q + 4 * kh;
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(sm + C::BIAS + co * 4);      // (copied into LDS by the prologue)
-                    f32x4 o;
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = acc[ct][pt][4 * q + e] + accx[ct][pt][4 * q + e] * (1.f / 2048.f);
-                    for (int k = 1; k <= nother; ++k) {      // the other pieces, in the order of their stages
-                        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
-                            (void*)(a.ws_partial + (size_t)(lw + k) * PART_FLOATS + (size_t)wave * (CT * PT * 16 * 64)), 0, CT * PT * 16 * 64 * 4, 0x00020000);
-                        const int po = ((pt * CT + ct) * 4 + q) * 1024;
-                        u32x4 p4 = __builtin_amdgcn_raw_buffer_load_b128(prs, lane * 16, po, H2_SC1);
-                        // bounded (~1 s): a sum that never arrives (it cannot, short of a fault) leaves the sentinel -- a NaN --
-                        // in the output instead of hanging the device
-                        for (int tries = 0; tries < (1 << 20); ++tries) {
-                            const bool missing = p4[0] == H2_EMPTY || p4[1] == H2_EMPTY || p4[2] == H2_EMPTY || p4[3] == H2_EMPTY;
-                            if (!__builtin_amdgcn_ballot_w64(missing)) break;
-                            __builtin_amdgcn_s_sleep(16);
-                            p4 = __builtin_amdgcn_raw_buffer_load_b128(prs, lane * 16, po, H2_SC1);
-                        }
-                        const u32x4 empty = {H2_EMPTY, H2_EMPTY, H2_EMPTY, H2_EMPTY};
-                        __builtin_amdgcn_raw_buffer_store_b128(empty, prs, lane * 16, po, H2_SC1);       // clean for the next launch
-                        const f32x4 pf = __builtin_bit_cast(f32x4, p4);
+                    for (int e = 0; e < 4; ++e) o4[q][e] = acc[ct][pt][4 * q + e] + accx[ct][pt][4 * q + e] * (1.f / 2048.f);
+                for (int k = 1; k <= nother; ++k) {      // the other pieces, in the order of their stages; FOUR chunks per round trip
+                    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*)(a.ws_partial + (size_t)(lw + k) * PART_FLOATS + (size_t)wave * (CT * PT * 16 * 64)), 0, CT * PT * 16 * 64 * 4, 0x00020000);
+                    const int po = (pt * CT + ct) * 4 * 1024;
+                    u32x4 p4[4];
+                    // bounded (~1 s): a sum that never arrives (it cannot, short of a fault) leaves the sentinel -- a NaN -- in the
+                    // output instead of hanging the device
+                    for (int tries = 0; tries < (1 << 20); ++tries) {
+                        bool missing = false;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) p4[q] = __builtin_amdgcn_raw_buffer_load_b128(prs, lane * 16, po + q * 1024, H2_SC1);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            missing = missing || p4[q][0] == H2_EMPTY || p4[q][1] == H2_EMPTY || p4[q][2] == H2_EMPTY || p4[q][3] == H2_EMPTY;
+                        if (!__builtin_amdgcn_ballot_w64(missing)) break;
+                        __builtin_amdgcn_s_sleep(16);
+                    }
+                    const u32x4 empty = {H2_EMPTY, H2_EMPTY, H2_EMPTY, H2_EMPTY};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        __builtin_amdgcn_raw_buffer_store_b128(empty, prs, lane * 16, po + q * 1024, H2_SC1);       // clean for the next launch
+                        const f32x4 pf = __builtin_bit_cast(f32x4, p4[q]);
                         if ((ABL & 64) && a.dbg) {
                             for (int e = 0; e < 4; ++e)
-                                if (p4[e] != (0x40000000u | ((unsigned)((lw + k) & 255) << 16) | ((unsigned)wave << 12) | ((unsigned)((pt * CT + ct) * 4 + q) << 8) | (lane << 2) | e)) {
-                                    atomicAdd(a.dbg + ((lane >> 2) & 3), 1u); a.dbg[4 + ((lane >> 2) & 3)] = p4[e]; a.dbg[8] = pt * 100 + ct * 10 + q;
+                                if (p4[q][e] != (0x40000000u | ((unsigned)((lw + k) & 255) << 16) | ((unsigned)wave << 12) | ((unsigned)((pt * CT + ct) * 4 + q) << 8) | (lane << 2) | e)) {
+                                    atomicAdd(a.dbg + ((lane >> 2) & 3), 1u); a.dbg[4 + ((lane >> 2) & 3)] = p4[q][e]; a.dbg[8] = pt * 100 + ct * 10 + q;
                                     a.dbg[9] = (0x40000000u | ((unsigned)((lw + k) & 255) << 16) | ((unsigned)wave << 12) | ((unsigned)((pt * CT + ct) * 4 + q) << 8) | (lane << 2) | e);
                                 }
                         }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += pf[e];
+                        for (int e = 0; e < 4; ++e) o4[q][e] += pf[e];
                     }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = n0 + (CT * cgw + ct) * 32 + 8 * q + 4 * kh;
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(sm + C::BIAS + co * 4);      // (copied into LDS by the prologue)
+                    f32x4 o = o4[q];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] += b4[e];
                     if (a.apply_act) {
@@ -362,6 +372,7 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
                     asm volatile("s_nop 7" ::: "memory");                 // see the published sums above
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
         }
     };
 
