@@ -211,7 +211,8 @@ int pwc_conv3x3_wino4_supported(int N, int H, int W, int Cin_phys, int Cout, int
  * number.  packed_w comes from pwc_conv3x3_h2_pack_f32 (split weights, pwc_conv3x3_h2_packed_floats floats; same
  * cin_map semantics as pwc_conv3x3_pack_f32).  Needs Cout % 32 == 0, Cout <= 512, Cin_phys % 16 == 0, x and y 16-byte aligned with
  * x_cs % 4 == 0 and y_cs % 4 == 0.  pwc_conv3x3_h2_supported: 1 where it is the fastest kernel of this library for the
- * shape (Cin_phys >= 32, sub-lattices of at least 8 x 24 pixels, at least 192 workgroups), 0 otherwise; the entry point
+ * shape (Cin_phys >= 32, sub-lattices of at least 8 x 24 pixels, at least 192 tiles -- or at least 64 with a channel loop
+ * long enough for the workspace form below to spread it over the CUs), 0 otherwise; the entry point
  * itself accepts every shape that meets the requirements above. */
 size_t pwc_conv3x3_h2_packed_floats(int Cin_phys, int Cout);
 int pwc_conv3x3_h2_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin, int Cin_phys,
@@ -222,11 +223,13 @@ int pwc_conv3x3_h2_f32(const float* x, int x_cs, const float* packed_w, const fl
                        pwc_stream_t stream);
 /* `workspace` (caller-owned, 16-byte aligned, pwc_conv3x3_h2_workspace_floats floats, every byte 0xFF before the first
  * launch that uses the buffer -- every launch leaves it so -- and not shared by launches that may run concurrently)
- * turns a launch with more tiles than CUs into one workgroup per CU, each computing an equal share of the launch's
- * (tile, 16-channel stage) sequence: no partly filled last round, one prologue per workgroup instead of one per tile.
- * A tile cut in two is finished by the workgroup holding its first piece, which adds the other's published fp32 sums to
- * its own (one addition of two finished sums: the result does not depend on timing) -- within fp32 rounding of the
- * uncut sum.  workspace = NULL: one workgroup per tile. */
+ * turns a launch into one workgroup per CU, each computing an equal share of the launch's (tile, 16-channel stage)
+ * sequence, wherever that is the faster form (more tiles than CUs: no partly filled last round, one prologue per workgroup
+ * instead of one per tile; far fewer tiles than CUs and a long channel loop: every CU gets a part of it).  A tile cut into
+ * pieces is finished by the workgroup holding its first piece, which adds the others' published fp32 sums to its own in the
+ * order of their stages (finished sums, fixed order: the result does not depend on timing, launches repeat bitwise) --
+ * within fp32 rounding of the uncut sum.  workspace = NULL (or pwc_conv3x3_h2_workspace_floats = 0): one workgroup per
+ * tile. */
 size_t pwc_conv3x3_h2_workspace_floats(int N, int H, int W, int Cin_phys, int Cout, int dilation);
 int pwc_conv3x3_h2_supported(int N, int H, int W, int Cin_phys, int Cout, int dilation);
 /* TWO chained 3x3 stride-1 'SAME' convolutions of 16 channels each (16 -> 16 -> 16) with a leaky-relu of slope `slope`
