@@ -211,7 +211,8 @@ int pwc_conv3x3_wino4_supported(int N, int H, int W, int Cin_phys, int Cout, int
  * number.  packed_w comes from pwc_conv3x3_h2_pack_f32 (split weights, pwc_conv3x3_h2_packed_floats floats; same
  * cin_map semantics as pwc_conv3x3_pack_f32).  Needs Cout % 32 == 0, Cout <= 512, Cin_phys % 16 == 0, x and y 16-byte aligned with
  * x_cs % 4 == 0 and y_cs % 4 == 0.  pwc_conv3x3_h2_supported: 1 where it is the fastest kernel of this library for the
- * shape (Cin_phys >= 32, sub-lattices of at least 8 x 24 pixels, at least 192 tiles -- or at least 64 with a channel loop
+ * shape (Cin_phys >= 32, sub-lattices of at least 7 x 24 pixels -- narrower ones of an even dilation are taken two at a time
+ * where Cout % 64 == 0 --, at least 192 tiles -- or at least 64 with a channel loop
  * long enough for the workspace form below to spread it over the CUs), 0 otherwise; the entry point
  * itself accepts every shape that meets the requirements above. */
 size_t pwc_conv3x3_h2_packed_floats(int Cin_phys, int Cout);

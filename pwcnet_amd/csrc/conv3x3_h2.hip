@@ -67,7 +67,7 @@ struct H2Args {
     int apply_act;
     float slope;
     int tiles_x, tiles_y, ncb;   // pixel tiles per (sub-)image, cout blocks of the workgroup's 32 CT WCG couts
-    int dil;
+    int dil_y, dil_x;    // steps of the pixel lattice a workgroup's tile lives on (dilation d: (d, d), or (d, d / 2) with XS = 2)
     int ntiles;
     float* ws_partial;   // stream-K: one partial tile (32 CT WCG couts x PT WPG x 32 pixels, fp32) per workgroup, words 0xFFFFFFFF
                          // while nothing is published; null = every workgroup owns whole tiles
@@ -81,21 +81,24 @@ constexpr int H2_MAX_COUT = 512;             // (the bias lives in LDS)
 constexpr int H2_SC1 = 16;                   // aux bit of the buffer intrinsics: device-scope access (gfx940+)
 constexpr int H2_MIN_STAGES = 3;              // stream-K only where a CU gets at least this many 16-channel stages
 constexpr unsigned H2_EMPTY = 0xFFFFFFFFu;    // workspace word that holds no published sum
-constexpr int H2_PW = 34;                    // patch width in pixels
-constexpr int H2_CHK = H2_PW * 16;           // bytes of a chunk row in the operand image: 544
-constexpr int H2_ROWB = 4 * H2_CHK;          // bytes of a patch row in the operand image: 4 chunks x 34 pixels x 16 B = 2176
 constexpr int H2_TAPB = 4 * 32 * 16;         // bytes of the weights of one (cout tile, tap): 2048
 
-template <int CT, int PT, int WCG> struct H2Cfg {
+// XS: the lattice columns a tap step spans.  1: the lattice of a dilation-d convolution is (y mod d, x mod d).  2: the lattice
+// is (y mod d, x mod d/2) and a tap moves TWO lattice columns -- a sub-lattice of only 16 columns (d = 16 at W = 256) would fill
+// half of a 32-column tile, the twice-as-dense lattice fills it (patch 36 instead of 34 pixels wide).
+template <int CT, int PT, int WCG, int XS = 1> struct H2Cfg {
+    static constexpr int PW = 32 + 2 * XS;       // patch width in pixels: 34 / 36
+    static constexpr int CHK = PW * 16;          // bytes of a chunk row in the operand image: 544
+    static constexpr int ROWB = 4 * CHK;         // bytes of a patch row in the operand image: 4 chunks x 34 pixels x 16 B = 2176
     static constexpr int WPG = 8 / WCG;          // pixel groups (PT rows each)
     static constexpr int NCT = CT * WCG;         // cout tiles of the workgroup
     static constexpr int TR = PT * WPG;          // tile rows: 8 or 16
     static constexpr int PH = TR + 2;            // patch rows
-    static constexpr int NREC = PH * H2_PW;      // patch pixels: 340 / 612
+    static constexpr int NREC = PH * PW;         // patch pixels: 340 / 612
     static constexpr int NBP = (NREC + 15) / 16; // 1 KB pieces of the staging image (16 records of 64 B): 22 / 39
     static constexpr int PPW = (NBP + 7) / 8;    // patch pieces per wave: 3 / 5
     static constexpr int S_BYTES = (PPW * 8) * 1024;                 // staging (incl. the surplus pieces)
-    static constexpr int B_BYTES = PH * H2_ROWB;                     // one operand image: 21 760 / 39 168
+    static constexpr int B_BYTES = PH * ROWB;                        // one operand image: 21 760 / 39 168
     static constexpr int AP = NCT * 3 * H2_TAPB;                     // weights of a part (tap row): 24 576 / 12 288 / 18 432 / 6144
     static constexpr int NAP = AP / 1024;                            // ... in 1 KB pieces
     static constexpr int APW = (NAP + 7) / 8;                        // pieces per wave (the last round may be partial)
@@ -108,9 +111,9 @@ template <int CT, int PT, int WCG> struct H2Cfg {
 // ABL (harness only): 1 = no patch DMA, 2 = no weight DMA, 4 = no MFMA, 8 = m' = 0, 16 = no split at all, 32 = no fragment reads,
 // 64 = the published sums are replaced by position tags and checked by the reader (self-test of the exchange), 2048 = s_memtime
 // totals of the waits, barriers and piece ends per wave
-template <int CT, int PT, int WCG, int ABL = 0>
+template <int CT, int PT, int WCG, int ABL = 0, int XS = 1>
 __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
-    typedef H2Cfg<CT, PT, WCG> C;
+    typedef H2Cfg<CT, PT, WCG, XS> C;
     typedef __attribute__((address_space(3))) void* lptr_t;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     const int pg = wave % C::WPG, cgw = wave / C::WPG;     // pixel group (rows PT pg ..), cout group (CT tiles)
     const int ln = lane & 31, kh = lane >> 5;
 
-    const int d = a.dil;
+    const int dly = a.dil_y, dlx = a.dil_x;
     const int nc16 = a.Cin_phys >> 4;
     const int nct_all = a.Cout >> 5;                // cout tiles of 32 in the packed image
     // ---- the workgroup's range of the launch's (tile, channel stage) sequence.  Tiles: cout block fastest, then the pixel
@@ -144,9 +147,9 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         rest /= a.tiles_x;
         tl.by = rest % a.tiles_y;
         rest /= a.tiles_y;
-        const int sub = rest % (d * d);
-        tl.n = rest / (d * d);
-        tl.ry = sub / d; tl.rx = sub - tl.ry * d;
+        const int sub = rest % (dly * dlx);
+        tl.n = rest / (dly * dlx);
+        tl.ry = sub / dlx; tl.rx = sub - tl.ry * dlx;
         return tl;
     };
     auto next_tile = [&](Tile& tl) {
@@ -156,9 +159,9 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         tl.bx = 0;
         if (++tl.by < a.tiles_y) return;
         tl.by = 0;
-        if (++tl.rx < d) return;
+        if (++tl.rx < dlx) return;
         tl.rx = 0;
-        if (++tl.ry < d) return;
+        if (++tl.ry < dly) return;
         tl.ry = 0;
         ++tl.n;
     };
@@ -175,8 +178,8 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
 #pragma unroll
         for (int i = 0; i < C::PPW; ++i) {
             const int rec = (wave + 8 * i) * 16 + (lane >> 2);
-            const int py = rec / H2_PW, px = rec - py * H2_PW;
-            const int yy = tl.ry + d * (y0 - 1 + py), xx = tl.rx + d * (x0 - 1 + px);
+            const int py = rec / C::PW, px = rec - py * C::PW;
+            const int yy = tl.ry + dly * (y0 - 1 + py), xx = tl.rx + dlx * (x0 - XS + px);
             const bool ok = rec < C::NREC && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
             p_voff[i] = ok ? (unsigned)(((yy * a.W + xx) * a.x_cs + (lane & 3) * 4) * 4) : H2_OOB;
         }
@@ -219,10 +222,10 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
                 // (x - h) 2^11 = x 2^11 - h 2^11, all three exact: one multiply and one mixed-precision FMA per element
                 m[e] = (ABL & 8) ? (_Float16)0.f : (_Float16)__builtin_fmaf((float)h[e], -2048.f, v[e] * 2048.f);
             }
-            const int py = rec / H2_PW, px = rec - py * H2_PW;
-            char* dst = sm + C::B0 + buf * C::B_BYTES + py * H2_ROWB + (g >> 1) * H2_CHK + px * 16 + (g & 1) * 8;
+            const int py = rec / C::PW, px = rec - py * C::PW;
+            char* dst = sm + C::B0 + buf * C::B_BYTES + py * C::ROWB + (g >> 1) * C::CHK + px * 16 + (g & 1) * 8;
             *reinterpret_cast<pwc_f16x4*>(dst) = h;
-            *reinterpret_cast<pwc_f16x4*>(dst + 2 * H2_CHK) = m;
+            *reinterpret_cast<pwc_f16x4*>(dst + 2 * C::CHK) = m;
         }
     };
     auto convert = [&](int buf) {
@@ -236,17 +239,17 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     struct Frags { pwc_f16x8 ah[CT], am[CT], bh[PT], bm[PT]; };
     constexpr int NL = 2 * (CT + PT);
     constexpr int NM = 3 * CT * PT;
-    const char* const bbase = sm + C::B0 + (PT * pg) * H2_ROWB + kh * H2_CHK + ln * 16;
+    const char* const bbase = sm + C::B0 + (PT * pg) * C::ROWB + kh * C::CHK + ln * 16;
     const char* const abase = sm + C::A0 + (CT * cgw) * 3 * H2_TAPB + kh * 512 + ln * 16;
     auto load_i = [&](Frags& f, int i, int buf, int r, int dx) {
         if (ABL & 32) return;
-        const char* const bb = bbase + buf * C::B_BYTES + r * H2_ROWB + dx * 16;
+        const char* const bb = bbase + buf * C::B_BYTES + r * C::ROWB + dx * XS * 16;
         const char* const ab = abase + r * C::AP + dx * H2_TAPB;
         // order: AH0, BH0 .. BH(PT-1), AH1 .. AH(CT-1), BM0 .., AM0 ..
         if (i == 0) f.ah[0] = *reinterpret_cast<const pwc_f16x8*>(ab);
-        else if (i <= PT) f.bh[i - 1] = *reinterpret_cast<const pwc_f16x8*>(bb + (i - 1) * H2_ROWB);
+        else if (i <= PT) f.bh[i - 1] = *reinterpret_cast<const pwc_f16x8*>(bb + (i - 1) * C::ROWB);
         else if (i < PT + CT) f.ah[i - PT] = *reinterpret_cast<const pwc_f16x8*>(ab + (i - PT) * 3 * H2_TAPB);
-        else if (i < 2 * PT + CT) f.bm[i - PT - CT] = *reinterpret_cast<const pwc_f16x8*>(bb + (i - PT - CT) * H2_ROWB + 2 * H2_CHK);
+        else if (i < 2 * PT + CT) f.bm[i - PT - CT] = *reinterpret_cast<const pwc_f16x8*>(bb + (i - PT - CT) * C::ROWB + 2 * C::CHK);
         else f.am[i - 2 * PT - CT] = *reinterpret_cast<const pwc_f16x8*>(ab + (i - 2 * PT - CT) * 3 * H2_TAPB + 1024);
     };
 
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
             (void*)(a.y + (size_t)tl.n * a.Ho * a.Wo * a.y_cs), 0, a.Ho * a.Wo * a.y_cs * 4, 0x00020000);
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-            const int py = tl.ry + d * (y0 + PT * pg + pt), px = tl.rx + d * (x0 + ln);
+            const int py = tl.ry + dly * (y0 + PT * pg + pt), px = tl.rx + dlx * (x0 + ln);
             // stride 2: the stride-1 sum at input position 2 o + off IS output o (off = 1 - the SAME padding in front)
             const bool inside = py < a.H && px < a.W && (a.stride == 1 || ((((py - a.off_y) | (px - a.off_x)) & 1) == 0 && py >= a.off_y && px >= a.off_x));
             const int opy = a.stride == 1 ? py : (py - a.off_y) >> 1, opx = a.stride == 1 ? px : (px - a.off_x) >> 1;
@@ -608,15 +611,24 @@ static inline H2Variant h2_variant(int v) {
         default: return {64, 8, 6};
     }
 }
-static inline long h2_blocks(int v, int N, int hs, int ws, int Cout, int dilation) {
+// The lattice a dilation-d launch works on (see H2Cfg): sub-lattices of fewer than 24 columns are taken two at a time.
+struct H2Geo { int dy, dx, xs, hs, ws; };
+static inline H2Geo h2_geometry(int H, int W, int d, int Cout) {
+    H2Geo g = {d, d, 1, (H + d - 1) / d, (W + d - 1) / d};
+    if (g.ws < 24 && d % 2 == 0 && (W + d / 2 - 1) / (d / 2) >= 24 && Cout % 64 == 0) {      // (8-row tiles: 64 couts or more)
+        g.dx = d / 2; g.xs = 2; g.ws = (W + g.dx - 1) / g.dx;
+    }
+    return g;
+}
+static inline long h2_blocks(int v, int N, const H2Geo& g, int Cout) {
     const H2Variant t = h2_variant(v);
-    return (long)N * dilation * dilation * ((ws + 31) / 32) * ((hs + t.rows - 1) / t.rows) * (Cout / t.couts);
+    return (long)N * g.dy * g.dx * ((g.ws + 31) / 32) * ((g.hs + t.rows - 1) / t.rows) * (Cout / t.couts);
 }
 // The variant whose launch is estimated shortest: tiles per CU x (matrix instructions per tap and wave + 3.6), the 3.6 being
 // the measured fixed part of a tap (profiles/r04_exp_h2.txt: 52 / 40.5 / 34 us per round of 8 stages for 12 / 9 / 6).
 static int h2_plan(int N, int H, int W, int Cin_phys, int Cout, int dilation, long* blocks_out) {
     if (N <= 0 || H <= 0 || W <= 0 || dilation < 1 || Cin_phys < 16 || (Cin_phys % 16) || Cout < 32 || (Cout % 32) || Cout > H2_MAX_COUT) return 0;
-    const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
+    const H2Geo geo = h2_geometry(H, W, dilation, Cout);
     int best = 0;
     double best_cost = 0.;
     long best_blocks = 0;
@@ -625,7 +637,8 @@ static int h2_plan(int N, int H, int W, int Cin_phys, int Cout, int dilation, lo
         const int v = order[oi];
         const H2Variant t = h2_variant(v);
         if (Cout % t.couts) continue;
-        const long nb = h2_blocks(v, N, hs, ws, Cout, dilation);
+        if (geo.xs == 2 && t.rows != 8) continue;  // (the 36-pixel patch exists for the 8-row tiles)
+        const long nb = h2_blocks(v, N, geo, Cout);
         if (nb >= (1L << 31)) continue;
         const double cost = (nb <= 256 ? 1.0 : (double)nb / 256.0) * (t.nm + 3.6);      // stream-K: no rounding up to whole rounds
         if (!best || cost < best_cost) { best = v; best_cost = cost; best_blocks = nb; }
@@ -656,23 +669,24 @@ static int h2_cu_count() {
 }
 
 // 1 where this kernel is the faster one for the shape (measured against conv3x3_wino4.hip / conv3x3_wino.hip on isolated layers:
-// profiles/r04_exp_h2.txt): sub-lattices of at least 8 x 24 pixels, a launch that fills at least three quarters of the CUs, two or more channel stages
+// profiles/r04_exp_h2.txt): sub-lattices of at least 7 x 24 pixels (h2_geometry pairs narrower ones), a launch that fills at least three quarters of the CUs, two or more channel stages
 // (32 -> 32 channels at 16 x 112 x 256: 48 us against F(2x2)'s 56).
 extern "C" int pwc_conv3x3_h2_supported(int N, int H, int W, int Cin_phys, int Cout, int dilation) {
     long nb = 0;
     if (!h2_plan(N, H, W, Cin_phys, Cout, dilation, &nb)) return 0;
-    const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
+    const H2Geo geo = h2_geometry(H, W, dilation, Cout);
+    const int hs = geo.hs, ws = geo.ws;
     const bool filled = nb >= 192 || (nb >= 64 && h2_split_pays(nb, Cin_phys >> 4, h2_cu_count()));     // (the latter needs the workspace)
-    return hs >= 8 && ws >= 24 && filled && Cin_phys >= 32 ? 1 : 0;
+    return hs >= 7 && ws >= 24 && filled && Cin_phys >= 32 ? 1 : 0;
 }
 
 static unsigned* h2_debug_counters = nullptr;      // harness only
 
-template <int CT, int PT, int WCG, int ABL>
+template <int CT, int PT, int WCG, int ABL, int XS = 1>
 static int h2_launch(H2Args& a, int hs, int ws, float* workspace, size_t workspace_floats, hipStream_t stream) {
-    typedef H2Cfg<CT, PT, WCG> C;
+    typedef H2Cfg<CT, PT, WCG, XS> C;
     a.tiles_x = (ws + 31) / 32; a.tiles_y = (hs + C::TR - 1) / C::TR; a.ncb = a.Cout / (32 * C::NCT);
-    const long nblk = (long)a.N * a.dil * a.dil * a.tiles_x * a.tiles_y * a.ncb;
+    const long nblk = (long)a.N * a.dil_y * a.dil_x * a.tiles_x * a.tiles_y * a.ncb;
     if (nblk * (a.Cin_phys >> 4) >= (1L << 31)) return PWC_ERANGE;
     a.ntiles = (int)nblk;
     // one workgroup per tile, or -- with a workspace and at least H2_MIN_STAGES stages per CU -- one workgroup per CU, each with an
@@ -687,10 +701,10 @@ static int h2_launch(H2Args& a, int hs, int ws, float* workspace, size_t workspa
     }
     static PwcDevOnce attr_once;
     if (pwc_first_on_device(&attr_once)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2_kernel<CT, PT, WCG, ABL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2_kernel<CT, PT, WCG, ABL, XS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     }
-    hipLaunchKernelGGL((conv3x3_h2_kernel<CT, PT, WCG, ABL>), dim3((unsigned)grid), dim3(512), C::LDS, stream, a);
+    hipLaunchKernelGGL((conv3x3_h2_kernel<CT, PT, WCG, ABL, XS>), dim3((unsigned)grid), dim3(512), C::LDS, stream, a);
     return pwc_launch_status();
 }
 
@@ -710,7 +724,8 @@ static int h2_run(const float* x, int x_cs, const float* packed_w, const float* 
     H2Args a;
     a.x = x; a.wp = packed_w; a.bias = bias; a.y = y; a.x_cs = x_cs; a.y_cs = y_cs;
     a.N = N; a.H = H; a.W = W; a.Cin_phys = Cin_phys; a.Cout = Cout; a.apply_act = apply_act; a.slope = slope;
-    a.dil = dilation;
+    const H2Geo geo = h2_geometry(H, W, dilation, Cout);
+    a.dil_y = geo.dy; a.dil_x = geo.dx;
     a.dbg = h2_debug_counters;
     a.stride = stride; a.Ho = H; a.Wo = W; a.off_y = a.off_x = 0;
     if (stride == 2) {
@@ -718,10 +733,19 @@ static int h2_run(const float* x, int x_cs, const float* packed_w, const float* 
         pwc_same_pad(H, 2, 1, &a.Ho, &before); a.off_y = 1 - before;
         pwc_same_pad(W, 2, 1, &a.Wo, &before); a.off_x = 1 - before;
     }
-    const int hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
+    const int hs = geo.hs, ws = geo.ws;
     if (variant == 0) variant = h2_plan(N, H, W, Cin_phys, Cout, dilation, nullptr);
     if (variant < 1 || variant > 5) return PWC_EUNSUPPORTED;
     if (Cout % h2_variant(variant).couts) return PWC_EUNSUPPORTED;
+    if (geo.xs == 2) {
+        if (stride != 1) return PWC_EUNSUPPORTED;
+        switch (variant) {
+            case 1: return h2_launch<2, 2, 2, ABL, 2>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);
+            case 3: return h2_launch<3, 1, 1, ABL, 2>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);
+            case 5: return h2_launch<1, 2, 2, ABL, 2>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);
+            default: return PWC_EUNSUPPORTED;
+        }
+    }
     switch (variant) {
         case 1: return h2_launch<2, 2, 2, ABL>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);
         case 2: return h2_launch<2, 2, 1, ABL>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);

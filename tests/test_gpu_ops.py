@@ -281,7 +281,9 @@ def run_conv_h2(x, k, b, slope, cin_map=None, y_cs=None, dil=1, variant=0, ws=No
 @pytest.mark.parametrize("N,H,W,cin,cout,dil", [
     (1, 32, 64, 128, 128, 1), (2, 16, 32, 64, 32, 1), (1, 33, 47, 32, 64, 1), (1, 5, 3, 16, 32, 1), (2, 50, 70, 160, 96, 1),
     (1, 56, 64, 128, 96, 2), (1, 40, 48, 64, 64, 4), (1, 112, 96, 32, 32, 8), (2, 19, 23, 48, 64, 3), (1, 20, 40, 16, 128, 1),
-    (2, 30, 33, 80, 192, 1), (1, 17, 100, 48, 256, 1)])
+    (2, 30, 33, 80, 192, 1), (1, 17, 100, 48, 256, 1),
+    # sub-lattices of fewer than 24 columns: two of them share a tile (taps two lattice columns apart, 36-pixel patches)
+    (1, 112, 256, 96, 64, 16), (1, 50, 180, 32, 128, 8), (2, 40, 100, 48, 96, 6)])
 def test_conv_f16x2_direct_vs_oracle(pa, N, H, W, cin, cout, dil):
     """pwc_conv3x3_h2_f32 (direct convolution on the F16 matrix pipe, fp32 operands as two-term fp16 splits) in EVERY tile
     variant whose couts divide Cout: ragged 8/16-row x 32-column tiles, dilations (sub-lattices), one to ten channel stages
@@ -293,8 +295,9 @@ def test_conv_f16x2_direct_vs_oracle(pa, N, H, W, cin, cout, dil):
     exp = orc.conv3x3(x, k, b, 1, dil, 0.1)
     exp_lin = orc.conv3x3(x, k, b, 1, dil, None)
     ran = 0
+    paired = dil % 2 == 0 and -(-W // dil) < 24 <= -(-W // (dil // 2)) and cout % 64 == 0
     for v in (0, 1, 2, 3, 4, 5):
-        if v and cout % H2_COUTS[v]:
+        if v and (cout % H2_COUTS[v] or (paired and v in (2, 4))):      # (paired sub-lattices: the 8-row tiles only)
             continue
         close(run_conv_h2(x, k, b, 0.1, dil=dil, variant=v), exp)
         y = run_conv_h2(x, k, b, None, y_cs=cout + 8, dil=dil, variant=v)
@@ -304,7 +307,7 @@ def test_conv_f16x2_direct_vs_oracle(pa, N, H, W, cin, cout, dil):
     assert ran >= 2
 
 
-@pytest.mark.parametrize("cin,cout,dil", [(160, 128, 1), (128, 96, 2), (64, 32, 1)])
+@pytest.mark.parametrize("cin,cout,dil", [(160, 128, 1), (128, 96, 2), (64, 32, 1), (96, 64, 16)])
 def test_conv_f16x2_direct_full_size_vs_oracle(pa, cin, cout, dil):
     """pwc_conv3x3_h2_f32 at the PRODUCTION shape (8 x 112 x 256: 896 - 1792 workgroups of 512 threads, XCD remap) against
     the oracle's convolution on the first and the last image of the batch, every entry; the other six are checked for
@@ -441,9 +444,11 @@ def test_conv_f16x2_direct_physical_layout_range_and_plan(pa):
     assert float(np.abs(np.where(nan, 0.0, yb - good)).max()) <= 1e-5 * float(np.abs(good).max())
     assert L.pwc_conv3x3_h2_supported(8, 112, 256, 160, 128, 1) == 1
     assert L.pwc_conv3x3_h2_supported(8, 112, 256, 128, 96, 8) == 1
+    assert L.pwc_conv3x3_h2_supported(8, 112, 256, 96, 64, 16) == 1            # 16 x 8 lattice, 7 x 32 pixels each
     assert L.pwc_conv3x3_h2_supported(8, 112, 256, 64, 32, 1) == 1
     assert L.pwc_conv3x3_h2_supported(8, 56, 128, 192, 128, 1) == 1
-    assert L.pwc_conv3x3_h2_supported(8, 112, 256, 128, 64, 16) == 0        # 7-row sub-lattices
+    assert L.pwc_conv3x3_h2_supported(8, 96, 256, 128, 64, 16) == 0         # 6-row sub-lattices
+    assert L.pwc_conv3x3_h2_supported(8, 112, 256, 96, 32, 16) == 0         # 16-column sub-lattices, no 8-row tile for 32 couts
     assert L.pwc_conv3x3_h2_supported(8, 14, 32, 128, 128, 1) == 0          # a coarse level does not fill the GPU
     assert L.pwc_conv3x3_h2_supported(8, 112, 256, 128, 48, 1) == 0         # Cout % 32
     assert L.pwc_conv3x3_h2_plan(8, 112, 256, 128, 96, 1) == 3
