@@ -246,6 +246,22 @@ int pwc_conv3x3_c16pair_pack_f32(const float* w1_hwio, const float* w2_hwio, flo
 int pwc_conv3x3_c16pair_f32(const float* x, int x_cs, const float* packed, const float* bias1, const float* bias2,
                             float* y, int y_cs, int N, int H, int W, float slope, pwc_stream_t stream);
 int pwc_conv3x3_c16pair_supported(int N, int H, int W);
+/* The same launch with the stride-2 'SAME' convolution of the RAW images in front (3 -> 16 -> 16 -> 16, leaky-relu behind
+ * each; reference modules.py:57-67, `fp_extractor/conv2d`, `conv2d_1`, `conv2d_2`: all of pyramid level 1): a workgroup
+ * fetches the 41 x 73-pixel raw patch of its 16 x 32-pixel output tile and neither intermediate leaves the CU.  The first
+ * convolution runs on the same split arithmetic (27 of a 32-deep matrix instruction).  The images are two batches that
+ * share the weights (the two frames of a pair): N_a images at x_a, N_b at x_b (x_b = NULL with N_b = 0), NHWC with
+ * EXACTLY 3 channels at channel stride 3, H0 x W0 with W0 % 4 == 0 (PWC_EUNSUPPORTED otherwise), 16-byte aligned; y:
+ * (N_a + N_b) x ceil(H0 / 2) x W0 / 2 x 16 at channel stride y_cs.  packed: pwc_conv3x3_c3c16pair_pack_f32 of the HWIO
+ * (3,3,3,16), (3,3,16,16), (3,3,16,16) kernels (pwc_conv3x3_c3c16pair_packed_floats floats).  _supported: W0 % 4 == 0
+ * and the level-1 image is one pwc_conv3x3_c16pair_supported names. */
+size_t pwc_conv3x3_c3c16pair_packed_floats(void);
+int pwc_conv3x3_c3c16pair_pack_f32(const float* w0_hwio, const float* w1_hwio, const float* w2_hwio, float* packed,
+                                   pwc_stream_t stream);
+int pwc_conv3x3_c3c16pair_f32(const float* x_a, int N_a, const float* x_b, int N_b, const float* packed,
+                              const float* bias0, const float* bias1, const float* bias2, float* y, int y_cs,
+                              int H0, int W0, float slope, pwc_stream_t stream);
+int pwc_conv3x3_c3c16pair_supported(int N, int H0, int W0);
 /* Stride 2 ('SAME', dilation 1; the extractor's down-sampling layers, reference modules.py:57-60) through the same
  * kernel: the launch of the stride-1 convolution over the (H, W) input that stores only the sums a stride-2 convolution
  * has.  y is (N, ceil(H/2), ceil(W/2)) with channel stride y_cs; everything else as pwc_conv3x3_h2_f32 (packed_w from

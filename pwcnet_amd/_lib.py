@@ -61,6 +61,10 @@ SIGNATURES = {
     "pwc_conv3x3_c16pair_pack_f32": (_i, [_vp, _vp, _vp, _vp]),
     "pwc_conv3x3_c16pair_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "pwc_conv3x3_c16pair_supported": (_i, [_i, _i, _i]),
+    "pwc_conv3x3_c3c16pair_packed_floats": (_sz, []),
+    "pwc_conv3x3_c3c16pair_pack_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "pwc_conv3x3_c3c16pair_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "pwc_conv3x3_c3c16pair_supported": (_i, [_i, _i, _i]),
     "pwc_conv3x3_h2_variant_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "pwc_conv3x3_wino_split_plan": (_i, [_i, _i, _i, _i, _i, _i]),
     "pwc_conv3x3_wino_split_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),

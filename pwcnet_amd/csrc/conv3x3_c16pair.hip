@@ -29,6 +29,7 @@
 // under the two layers of the current one.  Three barriers per tile.
 #pragma once
 #include "pwc_common.h"
+#include <type_traits>
 
 typedef _Float16 c16_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 c16_f16x4 __attribute__((ext_vector_type(4)));
@@ -43,6 +44,10 @@ struct C16Args {
     int N, H, W;
     float slope;
     int tiles_x, tiles_y, ntiles;
+    // FIRST form only: the raw images (N_a from x, the others from x_b; 3 channels, channel stride 3), H0 x W0, stride-2 'SAME'
+    const float* x_b;
+    const float* b0;
+    int N_a, H0, W0, pad_t;
 };
 
 constexpr int C16_P = 36;                      // patch width = row pitch of the LDS images
@@ -55,9 +60,15 @@ constexpr int C16_S0 = 0, C16_IN0 = C16_NPC * 1024, C16_MID0 = C16_IN0 + C16_IMG
 constexpr int C16_MT_A = 41;                   // 16-pixel tiles of the intermediate: linear pixels [36, 692)
 constexpr int C16_MT_B = 36;                   // ... of the output: [72, 648) = rows 2 .. 17
 constexpr unsigned C16_OOB = 0x7FFF0000u;
+// FIRST form: the raw patch is 41 rows x 73 pixels x 3 floats = 55 16-byte chunks a row; a row's fetch instruction writes 1 KB, the
+// row pitch of 1072 bytes keeps the three rows a pixel reads 12 banks apart (41 x 1072 = 43 952 bytes of the 48 KB staging area)
+constexpr int C16_RAW_ROWS = 41, C16_RAW_CHUNKS = 55, C16_RAW_PITCH = 1072;
 
-// ABL (harness only): 1 = no patch DMA, 2 = no split of the staging image, 4 = no layer 1, 8 = no layer 2
-template <int ABL = 0>
+// ABL (harness only): 1 = no patch DMA, 2 = no split of the staging image (FIRST: no stride-2 convolution), 4 = no layer 1,
+// 8 = no layer 2
+// FIRST: the input is the raw 3-channel image pair and the stride-2 convolution in front of the two layers (`conv2d`, reference
+// modules.py:60-61) is computed into the operand image instead of the split of a fetched 16-channel patch.
+template <int ABL = 0, bool FIRST = false>
 __global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
     typedef __attribute__((address_space(3))) void* lptr_t;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -73,6 +84,13 @@ __global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
     for (int m = 0; m < 14; ++m) {
         A1[m] = reinterpret_cast<const c16_f16x8*>(a.wp)[m * 64 + lane];
         A2[m] = reinterpret_cast<const c16_f16x8*>(a.wp)[(14 + m) * 64 + lane];
+    }
+    c16_f16x8 A0h = {}, A0m = {};
+    f32x4 b0v = {0.f, 0.f, 0.f, 0.f};
+    if (FIRST) {
+        A0h = reinterpret_cast<const c16_f16x8*>(a.wp)[28 * 64 + lane];
+        A0m = reinterpret_cast<const c16_f16x8*>(a.wp)[29 * 64 + lane];
+        b0v = *reinterpret_cast<const f32x4*>(a.b0 + 4 * kq);
     }
     const f32x4 b1v = *reinterpret_cast<const f32x4*>(a.b1 + 4 * kq);
     const f32x4 b2v = *reinterpret_cast<const f32x4*>(a.b2 + 4 * kq);
@@ -99,6 +117,22 @@ __global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
         const int bx = tile % a.tiles_x;
         const int rest = tile / a.tiles_x;
         const int by = rest % a.tiles_y, n = rest / a.tiles_y;
+        if (FIRST) {
+            const float* img = n < a.N_a ? a.x + (size_t)n * a.H0 * a.W0 * 3 : a.x_b + (size_t)(n - a.N_a) * a.H0 * a.W0 * 3;
+            xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, a.H0 * a.W0 * 12, 0x00020000);
+            const int rowb = a.W0 * 12;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int r = wave + 8 * i;
+                const int c = lane;
+                const int yy = 2 * (by * 16 - 2) - a.pad_t + r;
+                const int cb = (2 * (bx * 32 - 2)) * 12 + 16 * c;                    // first byte of the chunk within the image row
+                const bool ok = r < C16_RAW_ROWS && (unsigned)c < (unsigned)C16_RAW_CHUNKS && (unsigned)yy < (unsigned)a.H0 &&
+                                (unsigned)cb < (unsigned)rowb;
+                p_voff[i] = ok ? (unsigned)(yy * rowb + cb) : C16_OOB;
+            }
+            return;
+        }
         xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -111,20 +145,27 @@ __global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
     };
     auto patch_issue = [&]() {
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-            if (!(ABL & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(sm + C16_S0 + (wave + 8 * i) * 1024), 16, (int)p_voff[i], 0, 0, 0);
+        for (int i = 0; i < 6; ++i) {
+            if (FIRST) {
+                const int roff = (wave + 8 * i) * C16_RAW_PITCH;
+                if (!(ABL & 1) && wave + 8 * i < C16_RAW_ROWS)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(sm + C16_S0 + roff), 16, (int)p_voff[i], 0, 0, 0);
+            } else if (!(ABL & 1)) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(sm + C16_S0 + (wave + 8 * i) * 1024), 16, (int)p_voff[i], 0, 0, 0);
+            }
+        }
     };
 #define C16_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
     // one 16-pixel tile of a layer: 14 fragment reads, 14 matrix instructions; returns hh + 2^-11 cross
-    auto mtile = [&](const char* img, int p0, const c16_f16x8* A) -> f32x4 {
+    auto mtile = [&](const char* img, int p0, const c16_f16x8* A, const f32x4 bias) -> f32x4 {
         c16_f16x8 B[14];
         const char* base = img + p0 * 16;
 #pragma unroll
         for (int j = 0; j < 5; ++j) B[j] = *reinterpret_cast<const c16_f16x8*>(base + hoff[j]);
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) B[5 + tp] = *reinterpret_cast<const c16_f16x8*>(base + coff + tap_shift(tp) * 16);
-        f32x4 hh = {0.f, 0.f, 0.f, 0.f}, cx = {0.f, 0.f, 0.f, 0.f};
+        f32x4 hh = bias, cx = {0.f, 0.f, 0.f, 0.f};        // (the bias rides in the accumulator)
 #pragma unroll
         for (int m = 0; m < 14; ++m) {
             // (alternating accumulators keeps two dependent chains in flight)
@@ -137,6 +178,12 @@ __global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
         return o;
     };
 
+    // FIRST: the lane's pixel of the stride-2 layer's tile `wave` (16 consecutive linear patch pixels a tile), its source in the
+    // raw staging rows (quarter dy < 3: floats 0 .. 7 of raw row 2 pr + dy at column 2 pc; quarter 3: float 8 of the three rows)
+    // and its destination in the operand image
+    const int pr_first = (16 * wave + n16) / C16_P, pc_first = (16 * wave + n16) - pr_first * C16_P;
+    const int src_lane = kq < 3 ? kq * C16_RAW_PITCH : 32;
+    const int dst_lane = (kq >> 1) * C16_CH + (16 * wave + n16) * 16 + (kq & 1) * 8;
     if (tile0 < tile1) {
         patch_prepare(tile0);
         patch_issue();
@@ -146,8 +193,78 @@ __global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
         const int rest = tile / a.tiles_x;
         const int by = rest % a.tiles_y, n = rest / a.tiles_y;
         const int y0 = by * 16, x0 = bx * 32;
+        const bool interior = y0 >= 2 && y0 + 18 <= a.H && x0 >= 2 && x0 + 34 <= a.W;      // no patch pixel outside the image
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         C16_BAR();                                   // the patch has landed; everybody is done with the images of the previous tile
+        if (FIRST) {
+            // ---- the stride-2 convolution of the raw patch: 45 tiles of 16 patch pixels, K = 27 of 32 (quarter dy < 3: the first
+            // 8 of the 9 floats of raw row 2 pr + dy at columns 2 pc .. 2 pc + 2; quarter 3: the ninth float of the three rows),
+            // one hh and two cross instructions; bias, leaky-relu, zero outside the image, split, into the operand image
+            // (three tiles at a time: their reads go out together, the latencies of the three chains overlap; a lane's pixel of
+            // tile wave + 8 i is 128 i linear pixels = 3 rows and 20 columns behind its pixel of tile `wave`)
+            auto stage0 = [&](auto interior_tag) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
+            int pr = pr_first, pc = pc_first;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float v[3][8];
+                bool in_image[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int i = 3 * g + u;
+                    const char* src = sm + C16_S0 + pr * (2 * C16_RAW_PITCH) + pc * 24 + src_lane;
+                    in_image[u] = INTERIOR || ((unsigned)(y0 - 2 + pr) < (unsigned)a.H && (unsigned)(x0 - 2 + pc) < (unsigned)a.W);
+                    pc += 20; pr += 3;
+                    if (pc >= C16_P) { pc -= C16_P; pr += 1; }
+                    if (wave + 8 * i >= ((ABL & 2) ? 0 : C16_NPIX / 16)) continue;
+                    if (kq < 3) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const f32x2 q = *reinterpret_cast<const f32x2*>(src + 8 * e);
+                            v[u][2 * e] = q[0]; v[u][2 * e + 1] = q[1];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) v[u][e] = *reinterpret_cast<const float*>(src + e * C16_RAW_PITCH);
+                    }
+                }
+                f32x4 hh[3], cx[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    c16_f16x8 Bh, Bm;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        Bh[e] = (_Float16)v[u][e];
+                        Bm[e] = (_Float16)__builtin_fmaf((float)Bh[e], -2048.f, v[u][e] * 2048.f);
+                    }
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    hh[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0h, Bh, b0v, 0, 0, 0);        // (the bias rides in the accumulator)
+                    cx[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0h, Bm, z, 0, 0, 0);
+                    cx[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0m, Bh, cx[u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int i = 3 * g + u;
+                    if (wave + 8 * i >= ((ABL & 2) ? 0 : C16_NPIX / 16)) continue;
+                    c16_f16x4 h, m;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float o = hh[u][e] + cx[u][e] * (1.f / 2048.f);
+                        o = fmaxf(o, o * a.slope);
+                        if (!INTERIOR) o = in_image[u] ? o : 0.f;
+                        h[e] = (_Float16)o;
+                        m[e] = (_Float16)__builtin_fmaf((float)h[e], -2048.f, o * 2048.f);
+                    }
+                    char* dst = sm + C16_IN0 + dst_lane + i * 2048;
+                    *reinterpret_cast<c16_f16x4*>(dst) = h;
+                    *reinterpret_cast<c16_f16x4*>(dst + 2 * C16_CH) = m;
+                }
+            }
+            };
+            if (interior) stage0(std::true_type{}); else stage0(std::false_type{});
+        } else {
         // ---- split the staging image: item = (patch pixel, 4-channel group)
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -166,45 +283,51 @@ __global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
                 *reinterpret_cast<c16_f16x4*>(dst + 2 * C16_CH) = m;
             }
         }
+        }
         C16_BAR();
         if (tile + 1 < tile1) {                      // the next patch, under the two layers
             patch_prepare(tile + 1);
             patch_issue();
         }
         // ---- layer 1: intermediate pixels [36, 692) -> bias, leaky-relu, zero outside the image, split, into LDS
-        for (int mt = wave; mt < ((ABL & 4) ? 0 : C16_MT_A); mt += 8) {
-            const int p0 = C16_P + mt * 16;
-            f32x4 o = mtile(sm + C16_IN0, p0, A1);
-            const int p = p0 + n16, pr = p / C16_P, pc = p - pr * C16_P;
-            const bool in_image = (unsigned)(y0 - 2 + pr) < (unsigned)a.H && (unsigned)(x0 - 2 + pc) < (unsigned)a.W;
-            c16_f16x4 h, m;
+        auto layer1 = [&](auto interior_tag) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
+            for (int mt = wave; mt < ((ABL & 4) ? 0 : C16_MT_A); mt += 8) {
+                const int p0 = C16_P + mt * 16;
+                f32x4 o = mtile(sm + C16_IN0, p0, A1, b1v);
+                const int p = p0 + n16;
+                bool in_image = true;
+                if (!INTERIOR) {
+                    const int pr = p / C16_P, pc = p - pr * C16_P;
+                    in_image = (unsigned)(y0 - 2 + pr) < (unsigned)a.H && (unsigned)(x0 - 2 + pc) < (unsigned)a.W;
+                }
+                c16_f16x4 h, m;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = o[e] + b1v[e];
-                v = fmaxf(v, v * a.slope);
-                v = in_image ? v : 0.f;
-                h[e] = (_Float16)v;
-                m[e] = (_Float16)__builtin_fmaf((float)h[e], -2048.f, v * 2048.f);
+                for (int e = 0; e < 4; ++e) {
+                    float v = o[e];
+                    v = fmaxf(v, v * a.slope);
+                    if (!INTERIOR) v = in_image ? v : 0.f;
+                    h[e] = (_Float16)v;
+                    m[e] = (_Float16)__builtin_fmaf((float)h[e], -2048.f, v * 2048.f);
+                }
+                char* dst = sm + C16_MID0 + (kq >> 1) * C16_CH + p * 16 + (kq & 1) * 8;
+                *reinterpret_cast<c16_f16x4*>(dst) = h;
+                *reinterpret_cast<c16_f16x4*>(dst + 2 * C16_CH) = m;
             }
-            char* dst = sm + C16_MID0 + (kq >> 1) * C16_CH + p * 16 + (kq & 1) * 8;
-            *reinterpret_cast<c16_f16x4*>(dst) = h;
-            *reinterpret_cast<c16_f16x4*>(dst + 2 * C16_CH) = m;
-        }
+        };
+        if (interior) layer1(std::true_type{}); else layer1(std::false_type{});
         C16_BAR();
         // ---- layer 2: output rows 2 .. 17 of the patch -> bias, leaky-relu, 16 bytes (4 couts) per lane
         const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.y + (size_t)n * a.H * a.W * a.y_cs), 0, a.H * a.W * a.y_cs * 4, 0x00020000);
         for (int mt = wave; mt < ((ABL & 8) ? 0 : C16_MT_B); mt += 8) {
             const int p0 = 2 * C16_P + mt * 16;
-            f32x4 o = mtile(sm + C16_MID0, p0, A2);
+            f32x4 o = mtile(sm + C16_MID0, p0, A2, b2v);
             const int p = p0 + n16, pr = p / C16_P, pc = p - pr * C16_P;
             const int yy = y0 - 2 + pr, xx = x0 - 2 + pc;
             const bool ok = pc >= 2 && pc < 34 && yy < a.H && xx < a.W;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[e] += b2v[e];
-                o[e] = fmaxf(o[e], o[e] * a.slope);
-            }
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], o[e] * a.slope);
             const unsigned vo = ok ? (unsigned)(((yy * a.W + xx) * a.y_cs + 4 * kq) * 4) : C16_OOB;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, (int)vo, 0, 0);
         }
@@ -232,7 +355,35 @@ __global__ void conv3x3_c16pair_pack_kernel(const float* __restrict__ w1, const 
     packed[idx] = __builtin_bit_cast(unsigned short, low ? lo : h);
 }
 
+// The stride-2 convolution's two operands behind the 28 of the layers: packed[28 + (0: uh, 1: um')][lane 64][8 fp16], K as in the
+// kernel: quarter kq < 3 = tap row kq, floats j = 3 dx + c = 0 .. 7; quarter 3 = (tap row e, j = 8) for e < 3, zeros behind.
+__global__ void conv3x3_c16pair_pack0_kernel(const float* __restrict__ w0, unsigned short* __restrict__ packed) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // (low, lane, e)
+    if (idx >= 2 * 64 * 8) return;
+    const int e = idx & 7, lane = (idx >> 3) & 63, low = idx >> 9;
+    const int i = lane & 15, kq = lane >> 4;
+    int dy = -1, j = 0;
+    if (kq < 3) { dy = kq; j = e; }
+    else if (e < 3) { dy = e; j = 8; }
+    float u = 0.f;
+    if (dy >= 0) u = w0[((dy * 3 + j / 3) * 3 + j % 3) * 16 + i];   // HWIO (3,3,3,16)
+    const _Float16 h = (_Float16)u;
+    const _Float16 lo = (_Float16)((u - (float)h) * 2048.f);
+    packed[28 * 64 * 8 + idx] = __builtin_bit_cast(unsigned short, low ? lo : h);
+}
+
 extern "C" size_t pwc_conv3x3_c16pair_packed_floats(void) { return 2 * 14 * 64 * 8 / 2; }
+extern "C" size_t pwc_conv3x3_c3c16pair_packed_floats(void) { return (2 * 14 + 2) * 64 * 8 / 2; }
+
+extern "C" int pwc_conv3x3_c3c16pair_pack_f32(const float* w0_hwio, const float* w1_hwio, const float* w2_hwio, float* packed,
+                                              pwc_stream_t stream) {
+    if (!w0_hwio || !w1_hwio || !w2_hwio || !packed) return PWC_EINVAL;
+    hipLaunchKernelGGL(conv3x3_c16pair_pack_kernel, dim3((2 * 14 * 64 * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       w1_hwio, w2_hwio, reinterpret_cast<unsigned short*>(packed));
+    hipLaunchKernelGGL(conv3x3_c16pair_pack0_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, w0_hwio,
+                       reinterpret_cast<unsigned short*>(packed));
+    return pwc_launch_status();
+}
 
 extern "C" int pwc_conv3x3_c16pair_pack_f32(const float* w1_hwio, const float* w2_hwio, float* packed, pwc_stream_t stream) {
     if (!w1_hwio || !w2_hwio || !packed) return PWC_EINVAL;
@@ -245,6 +396,57 @@ extern "C" int pwc_conv3x3_c16pair_pack_f32(const float* w1_hwio, const float* w
 extern "C" int pwc_conv3x3_c16pair_supported(int N, int H, int W) {
     if (N <= 0 || H < 16 || W < 32) return 0;
     return (long)N * ((H + 15) / 16) * ((W + 31) / 32) >= 256 ? 1 : 0;
+}
+
+// 1 where the three-layer launch is supported and the faster way: raw rows that are whole 16-byte chunks, a level-1 image the
+// pair kernel takes.
+extern "C" int pwc_conv3x3_c3c16pair_supported(int N, int H0, int W0) {
+    if (N <= 0 || H0 < 2 || W0 < 4 || (W0 & 3)) return 0;
+    return pwc_conv3x3_c16pair_supported(N, (H0 + 1) / 2, W0 / 2);
+}
+
+static int c16pair_grid(int ntiles) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    return ntiles < cus ? ntiles : cus;
+}
+
+// images: N_a at x_a and N_b at x_b (x_b may be null with N_b = 0), NHWC with exactly 3 channels (channel stride 3), H0 x W0,
+// W0 % 4 == 0; y: (N_a + N_b) x ceil(H0 / 2) x W0 / 2 x 16 at channel stride y_cs.
+template <int ABL = 0>
+static int c3c16pair_run(const float* x_a, int N_a, const float* x_b, int N_b, const float* packed, const float* bias0,
+                         const float* bias1, const float* bias2, float* y, int y_cs, int H0, int W0, float slope,
+                         pwc_stream_t stream) {
+    if (!x_a || !packed || !bias0 || !bias1 || !bias2 || !y || (N_b > 0 && !x_b)) return PWC_EINVAL;
+    if (N_a <= 0 || N_b < 0 || H0 <= 0 || W0 <= 0 || y_cs < 16) return PWC_EINVAL;
+    if (W0 & 3) return PWC_EUNSUPPORTED;
+    if ((y_cs & 3) || !pwc_aligned16(x_a) || !pwc_aligned16(x_b) || !pwc_aligned16(y) || !pwc_aligned16(packed) ||
+        !pwc_aligned16(bias0) || !pwc_aligned16(bias1) || !pwc_aligned16(bias2))
+        return PWC_EALIGN;
+    const int H = (H0 + 1) / 2, W = W0 / 2;
+    if ((long)H0 * W0 * 12 >= (long)C16_OOB || (long)H * W * y_cs * 4 >= (long)C16_OOB) return PWC_ERANGE;
+    C16Args a;
+    a.x = x_a; a.x_b = x_b; a.N_a = N_a; a.wp = packed; a.b0 = bias0; a.b1 = bias1; a.b2 = bias2; a.y = y; a.x_cs = 3; a.y_cs = y_cs;
+    a.N = N_a + N_b; a.H = H; a.W = W; a.H0 = H0; a.W0 = W0; a.pad_t = H0 & 1; a.slope = slope;      // TF 'SAME', stride 2: odd sizes pad one row on top
+    a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 15) / 16;
+    const long nt = (long)a.N * a.tiles_x * a.tiles_y;
+    if (nt >= (1L << 31)) return PWC_ERANGE;
+    a.ntiles = (int)nt;
+    const int grid = c16pair_grid(a.ntiles);
+    static PwcDevOnce attr_once;
+    if (pwc_first_on_device(&attr_once))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c16pair_kernel<ABL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS);
+    hipLaunchKernelGGL((conv3x3_c16pair_kernel<ABL, true>), dim3((unsigned)grid), dim3(512), C16_LDS, (hipStream_t)stream, a);
+    return pwc_launch_status();
+}
+
+extern "C" int pwc_conv3x3_c3c16pair_f32(const float* x_a, int N_a, const float* x_b, int N_b, const float* packed,
+                                         const float* bias0, const float* bias1, const float* bias2, float* y, int y_cs,
+                                         int H0, int W0, float slope, pwc_stream_t stream) {
+    return c3c16pair_run<0>(x_a, N_a, x_b, N_b, packed, bias0, bias1, bias2, y, y_cs, H0, W0, slope, stream);
 }
 
 template <int ABL = 0>
@@ -263,12 +465,8 @@ static int c16pair_run(const float* x, int x_cs, const float* packed, const floa
     const long nt = (long)N * a.tiles_x * a.tiles_y;
     if (nt >= (1L << 31)) return PWC_ERANGE;
     a.ntiles = (int)nt;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
-    const int grid = a.ntiles < cus ? a.ntiles : cus;
+    a.x_b = nullptr; a.b0 = nullptr; a.N_a = N; a.H0 = 0; a.W0 = 0; a.pad_t = 0;
+    const int grid = c16pair_grid(a.ntiles);
     static PwcDevOnce attr_once;
     if (pwc_first_on_device(&attr_once))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c16pair_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS);

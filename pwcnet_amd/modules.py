@@ -258,6 +258,52 @@ class _ConvRunner:
                 exec_flops=2.0 * 14 * 16 * 16 * 32 * (41 + 36) * (M / 512.0))
         return y, y_t
 
+    def conv_level1(self, image_views, slope=0.1):
+        """ALL of pyramid level 1 from the raw frames: conv2d (3 -> 16, stride 2), conv2d_1, conv2d_2 (16 -> 16), leaky_relu
+        behind each (reference modules.py:57-67), in ONE launch for one or two image batches that share the weights.
+        Returns (View y over the stacked batch, tensor), or None where pwc_conv3x3_c3c16pair_supported says no (the caller
+        then runs the three layers one by one)."""
+        L = _lib.lib()
+        v0 = image_views[0]
+        n_tot = sum(v.N for v in image_views)
+        ok = (self.k == 0 and len(image_views) <= 2 and slope is not None and getattr(self.owner, "f16x2", True)
+              and all(v.C == 3 and v.cs == 3 and v.ptr % 16 == 0 and v.H == v0.H and v.W == v0.W for v in image_views)
+              and L.pwc_conv3x3_c3c16pair_supported(n_tot, v0.H, v0.W))
+        if not ok:
+            return None
+        names = [self.scope + "/conv2d" + ("" if k == 0 else f"_{k}") for k in range(3)]
+        self.k = 3
+        shapes = [(3, 3, 3, 16), (3, 3, 16, 16), (3, 3, 16, 16)]
+        ks = [self.store.get(nm + "/kernel", sh, "kernel") for nm, sh in zip(names, shapes)]
+        bs = [self.store.get(nm + "/bias", (16,), "bias") for nm in names]
+        dev = ks[0].value.device
+        s = _lib.current_stream()
+        Ho, Wo = _same_out(v0.H, 2), _same_out(v0.W, 2)
+        y_t = torch.empty((n_tot, Ho, Wo, 16), dtype=torch.float32, device=dev)
+        y = View(y_t.data_ptr(), 16, n_tot, Ho, Wo, 16)
+        cache = self.owner._cache
+        key = (names[0], "c3c16pair", self.store.version)
+        packed = cache.get(key)
+        if packed is None:
+            packed = torch.empty((L.pwc_conv3x3_c3c16pair_packed_floats(),), dtype=torch.float32, device=dev)
+            _lib.check(L.pwc_conv3x3_c3c16pair_pack_f32(_p(ks[0].value.data_ptr()), _p(ks[1].value.data_ptr()),
+                                                        _p(ks[2].value.data_ptr()), _p(packed.data_ptr()), s),
+                       "conv3x3 c3c16pair pack")
+            cache[key] = packed
+        _keep(packed, y_t)
+        va = image_views[0]
+        vb = image_views[1] if len(image_views) == 2 else None
+        M = n_tot * Ho * Wo
+        _launch(L.pwc_conv3x3_c3c16pair_f32,
+                (_p(va.ptr), va.N, _p(vb.ptr) if vb is not None else None, vb.N if vb is not None else 0, _p(packed.data_ptr()),
+                 _p(bs[0].value.data_ptr()), _p(bs[1].value.data_ptr()), _p(bs[2].value.data_ptr()), _p(y.ptr), y.cs,
+                 v0.H, v0.W, float(slope), s),
+                f"conv3x3_c3c16pair {names[0]}+{names[1]}+{names[2]}", "conv3x3_c16pair_kernel",
+                2.0 * M * 9 * (3 * 16 + 2 * 16 * 16), 4.0 * (n_tot * v0.H * v0.W * 3 + M * 16),
+                # executed: 3 MFMAs of 16x16x32 per 16 patch pixels (45 tiles) + 14 per 16 pixels and layer (41 + 36 tiles)
+                exec_flops=2.0 * 16 * 16 * 32 * (3 * 45 + 14 * (41 + 36)) * (M / 512.0))
+        return y, y_t
+
     def conv(self, x, cout, y=None, stride=1, dilation=1, slope=0.1, cin_map=None,
              cin_logical=None, residual=None, tile=-1, split=0):
         """x: View over the PHYSICAL input channels.  cin_map: physical->logical map (or
@@ -566,6 +612,12 @@ class FeaturePyramidExtractor_custom(_Module):
         x = None
         for l in range(self.num_levels):
             f = self.filters[l]
+            if l == 0 and f == 16:
+                fused = run.conv_level1(image_views)
+                if fused is not None:
+                    x, t2 = fused
+                    feats.append(t2)
+                    continue
             if l == 0:
                 Ho, Wo = _same_out(v0.H, 2), _same_out(v0.W, 2)
                 y_t = torch.empty((n_tot, Ho, Wo, f), dtype=torch.float32, device=device)

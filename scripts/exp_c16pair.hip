@@ -2,6 +2,7 @@
 // exact operand splits) against two launches of the fp32 Winograd F(2x2) kernel and a float64 convolution pair on samples.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize scripts/exp_c16pair.hip -o scripts/exp_c16pair.bin
 #include "../pwcnet_amd/csrc/conv3x3_wino.hip"
+#include "../pwcnet_amd/csrc/conv3x3_direct.hip"
 #include "../pwcnet_amd/csrc/conv3x3_c16pair.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -104,6 +105,57 @@ int main() {
         }
         (void)hipFree(x); (void)hipFree(w1); (void)hipFree(w2); (void)hipFree(b1); (void)hipFree(b2); (void)hipFree(ym); (void)hipFree(yr); (void)hipFree(yf);
         (void)hipFree(u1); (void)hipFree(u2); (void)hipFree(up);
+    }
+    {   // ---- all of pyramid level 1 from the raw frames: 8 + 8 images of 448 x 1024 x 3
+        const int Na = 8, Nb = 8, H0 = 448, W0 = 1024, H = 224, W = 512;
+        const size_t nraw = (size_t)Na * H0 * W0 * 3, npix = (size_t)(Na + Nb) * H * W;
+        std::vector<float> ha(nraw), hb(nraw), hw0(27 * 16), hw1(9 * 256), hw2(9 * 256), hb0(16), hb1(16), hb2(16);
+        unsigned r = 4321;
+        auto rnd = [&]() { r = r * 1664525u + 1013904223u; return ((r >> 8) & 0xFFFF) / 65536.f - 0.5f; };
+        for (auto& v : ha) v = rnd() + 0.5f;
+        for (auto& v : hb) v = rnd() + 0.5f;
+        for (auto& v : hw0) v = 2.f * sqrtf(6.f / (9.f * 19)) * rnd();
+        for (auto& v : hw1) v = 2.f * sqrtf(6.f / (9.f * 32)) * rnd();
+        for (auto& v : hw2) v = 2.f * sqrtf(6.f / (9.f * 32)) * rnd();
+        for (auto& v : hb0) v = 0.2f * rnd();
+        for (auto& v : hb1) v = 0.2f * rnd();
+        for (auto& v : hb2) v = 0.2f * rnd();
+        float *xa, *xb, *w0, *w1, *w2, *b0, *b1, *b2, *y0, *yr, *yf, *up, *up3;
+        (void)hipMalloc(&xa, nraw * 4); (void)hipMalloc(&xb, nraw * 4); (void)hipMalloc(&w0, 27 * 64); (void)hipMalloc(&w1, 9 * 1024); (void)hipMalloc(&w2, 9 * 1024);
+        (void)hipMalloc(&b0, 64); (void)hipMalloc(&b1, 64); (void)hipMalloc(&b2, 64);
+        (void)hipMalloc(&y0, npix * 64); (void)hipMalloc(&yr, npix * 64); (void)hipMalloc(&yf, npix * 64);
+        (void)hipMalloc(&up, pwc_conv3x3_c16pair_packed_floats() * 4); (void)hipMalloc(&up3, pwc_conv3x3_c3c16pair_packed_floats() * 4);
+        (void)hipMemcpy(xa, ha.data(), nraw * 4, hipMemcpyHostToDevice); (void)hipMemcpy(xb, hb.data(), nraw * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(w0, hw0.data(), 27 * 64, hipMemcpyHostToDevice); (void)hipMemcpy(w1, hw1.data(), 9 * 1024, hipMemcpyHostToDevice);
+        (void)hipMemcpy(w2, hw2.data(), 9 * 1024, hipMemcpyHostToDevice);
+        (void)hipMemcpy(b0, hb0.data(), 64, hipMemcpyHostToDevice); (void)hipMemcpy(b1, hb1.data(), 64, hipMemcpyHostToDevice); (void)hipMemcpy(b2, hb2.data(), 64, hipMemcpyHostToDevice);
+        int rc = pwc_conv3x3_c16pair_pack_f32(w1, w2, up, 0) | pwc_conv3x3_c3c16pair_pack_f32(w0, w1, w2, up3, 0);
+        auto ref = [&]() {
+            pwc_conv3x3_direct_f32(xa, 3, w0, b0, y0, 16, nullptr, 0, Na, H0, W0, 3, 16, 2, 1, 1, 0.1f, 0);
+            pwc_conv3x3_direct_f32(xb, 3, w0, b0, y0 + (size_t)Na * H * W * 16, 16, nullptr, 0, Nb, H0, W0, 3, 16, 2, 1, 1, 0.1f, 0);
+            pwc_conv3x3_c16pair_f32(y0, 16, up, b1, b2, yr, 16, Na + Nb, H, W, 0.1f, 0);
+        };
+        ref();
+        const int rcf = pwc_conv3x3_c3c16pair_f32(xa, Na, xb, Nb, up3, b0, b1, b2, yf, 16, H0, W0, 0.1f, 0);
+        (void)hipDeviceSynchronize();
+        printf("== level 1 from the raw frames, %d + %d x %dx%dx3: pack rc %d, launch rc %d, hip %s, supported %d\n", Na, Nb, H0, W0, rc, rcf,
+               hipGetErrorString(hipGetLastError()), pwc_conv3x3_c3c16pair_supported(Na + Nb, H0, W0));
+        std::vector<float> hr(npix * 16), hf(npix * 16);
+        (void)hipMemcpy(hr.data(), yr, hr.size() * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(hf.data(), yf, hf.size() * 4, hipMemcpyDeviceToHost);
+        double md = 0, mx = 0; size_t nan = 0;
+        for (size_t i = 0; i < hr.size(); ++i) { if (hf[i] != hf[i]) { ++nan; continue; } md = fmax(md, fabs((double)hf[i] - hr[i])); mx = fmax(mx, fabs((double)hr[i])); }
+        printf("  three-layer launch vs fp32 stride-2 launches + pair launch: max |diff| %.3e (max |value| %.3f), %zu NaN\n", md, mx, nan);
+        std::vector<float> ta, tb;
+        for (int rep = 0; rep < 7; ++rep) {
+            ta.push_back(time_us([&](int) { pwc_conv3x3_c3c16pair_f32(xa, Na, xb, Nb, up3, b0, b1, b2, yf, 16, H0, W0, 0.1f, 0); }, 10));
+            tb.push_back(time_us([&](int) { ref(); }, 10));
+        }
+        std::sort(ta.begin(), ta.end()); std::sort(tb.begin(), tb.end());
+        printf("  medians of 7 interleaved rounds: three-layer launch %.1f us (min %.1f), three launches %.1f us (min %.1f)\n", ta[3], ta[0], tb[3], tb[0]);
+        auto ab = [&](auto tag) { return time_us([&](int) { c3c16pair_run<decltype(tag)::value>(xa, Na, xb, Nb, up3, b0, b1, b2, yf, 16, H0, W0, 0.1f, 0); }, 10); };
+        printf("  ablations: no patch DMA %.1f | no stride-2 layer %.1f | no layer 1 %.1f | no layer 2 %.1f | no layers 1, 2 %.1f | no DMA, no stride-2 layer %.1f | nothing %.1f us\n",
+               ab(std::integral_constant<int, 1>{}), ab(std::integral_constant<int, 2>{}), ab(std::integral_constant<int, 4>{}), ab(std::integral_constant<int, 8>{}),
+               ab(std::integral_constant<int, 12>{}), ab(std::integral_constant<int, 3>{}), ab(std::integral_constant<int, 15>{}));
     }
     return 0;
 }

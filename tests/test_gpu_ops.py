@@ -412,6 +412,44 @@ def test_conv_c16_pair_vs_oracle(pa, N, H, W, xcs, ycs):
         assert float(y[..., 16:].min()) == -7.0 and float(y[..., 16:].max()) == -7.0
 
 
+@pytest.mark.parametrize("Na,Nb,H0,W0,ycs", [(1, 1, 64, 96, 16), (2, 0, 33, 64, 24), (1, 2, 101, 140, 16), (1, 0, 32, 64, 16),
+                                             (8, 8, 448, 1024, 16)])
+def test_conv_c3_c16_pair_vs_oracle(pa, Na, Nb, H0, W0, ycs):
+    """pwc_conv3x3_c3c16pair_f32: ALL of pyramid level 1 (stride-2 3 -> 16, then 16 -> 16 -> 16, leaky-relu behind each) in one
+    launch from the raw images of the two frames (separate tensors), against the oracle's three convolutions: even and odd
+    heights (TF 'SAME' pads the top row only for odd sizes), ragged tiles, the right / bottom zero column and row of the
+    stride-2 layer, strided output with untouched neighbours, the production shape (first and last image).  fp32 default
+    tolerance."""
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    assert L.pwc_conv3x3_c3c16pair_supported(16, 448, 1024) == 1 and L.pwc_conv3x3_c3c16pair_supported(16, 448, 1022) == 0
+    xa, xb = rnd((Na, H0, W0, 3), 481), rnd((max(Nb, 1), H0, W0, 3), 482)
+    k0 = rnd((3, 3, 3, 16), 483) * float(1.0 / np.sqrt(27))
+    k1 = rnd((3, 3, 16, 16), 484) * float(1.0 / np.sqrt(9 * 16))
+    k2 = rnd((3, 3, 16, 16), 485) * float(1.0 / np.sqrt(9 * 16))
+    b0, b1, b2 = rnd((16,), 486) * 0.1, rnd((16,), 487) * 0.1, rnd((16,), 488) * 0.1
+    xag, xbg, k0g, k1g, k2g, b0g, b1g, b2g = gpu(xa), gpu(xb), gpu(k0), gpu(k1), gpu(k2), gpu(b0), gpu(b1), gpu(b2)
+    packed = torch.empty(L.pwc_conv3x3_c3c16pair_packed_floats(), device="cuda")
+    _lib.check(L.pwc_conv3x3_c3c16pair_pack_f32(_p(k0g), _p(k1g), _p(k2g), _p(packed), None))
+    H, W = -(-H0 // 2), W0 // 2
+    N = Na + Nb
+    y = torch.full((N, H, W, ycs), -7.0, device="cuda")
+    _lib.check(L.pwc_conv3x3_c3c16pair_f32(_p(xag), Na, _p(xbg) if Nb else None, Nb, _p(packed), _p(b0g), _p(b1g), _p(b2g), _p(y), ycs,
+                                           H0, W0, 0.1, None))
+    torch.cuda.synchronize()
+    for i in sorted({0, Na - 1, N - 1}):
+        img = xa[i:i + 1] if i < Na else xb[i - Na:i - Na + 1]
+        l0 = orc.conv3x3(img, k0, b0, 2, 1, 0.1)
+        assert l0.shape == (1, H, W, 16)
+        l1 = orc.conv3x3(l0, k1, b1, 1, 1, 0.1)
+        close(y[i:i + 1, ..., :16], orc.conv3x3(l1, k2, b2, 1, 1, 0.1))
+    assert bool(torch.isfinite(y).all())
+    if ycs > 16:
+        assert float(y[..., 16:].min()) == -7.0 and float(y[..., 16:].max()) == -7.0
+    xo = torch.zeros((1, 32, 62, 3), device="cuda")
+    assert L.pwc_conv3x3_c3c16pair_f32(_p(xo), 1, None, 0, _p(packed), _p(b0g), _p(b1g), _p(b2g), _p(y), ycs, 32, 62, 0.1, None) == -4
+
+
 def test_conv_f16x2_direct_physical_layout_range_and_plan(pa):
     """Padded / permuted physical input channels through cin_map (the estimator buffers); operands of very different
     magnitudes (the split is relative, not absolute); an input beyond fp16's range poisons exactly the outputs that
