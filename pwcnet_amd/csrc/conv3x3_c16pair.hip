@@ -27,6 +27,18 @@
 // instead of 3.1 KB and 50.
 // Persistent: one workgroup per CU loops over tiles; the patch of the next tile is fetched (LDS-DMA into the staging image)
 // under the two layers of the current one.  Three barriers per tile.
+//
+// FIRST form (pwc_conv3x3_c3c16pair_f32): ALL of pyramid level 1 from the raw frames.  The staging area receives the 41 x 73-pixel
+// 3-channel raw patch instead (one 16-byte-chunk fetch instruction per raw row, rows of whole chunks: W0 % 4 == 0; chunks beyond
+// the row end and rows beyond the image are the 'SAME' zeros), and the split stage becomes the stride-2 convolution
+// (`fp_extractor/conv2d`, reference modules.py:57-61): per 16 patch pixels each lane reads its 8 of the 27 (+5 zero) K values
+// straight from the raw rows, splits them, and three 16x16x32 instructions (hh, two cross) produce the 16 channels that are
+// biased, activated, zeroed outside the image, split and written into the operand image the pair reads.  165 -> 131 us for the
+// three layers at 16 x 448 x 1024 (profiles/r04_exp_c16pair.txt): the 117 MB level-1 input of the pair is never written or read.
+// The stride-2 stage costs 40-47 us of the 131 and is VALU ISSUE (about 100 vector instructions per 16 pixels: 12 operand
+// splits at 3.5 instructions, the epilogue, addresses; 2 waves per SIMD x 6 tiles x 4 cycles an instruction).  Running it for
+// tile t + 1 BESIDE layer 2 of tile t (waves 0-3 one order, waves 4-7 the other, two barriers per tile) changed nothing
+// (130.8 us): every wave still executes both in series and neither saturates a unit the other needs.
 #pragma once
 #include "pwc_common.h"
 #include <type_traits>

@@ -20,6 +20,7 @@ timeout 300 python bench.py --mode train --steps 10 --warmup 3 2>/dev/null | tai
 timeout 300 python scripts/exp_timeline.py 8 > $O/timeline_batch8.txt 2>/dev/null
 timeout 200 python scripts/exp_host.py 1 > $O/exp_host_issue_vs_graph_b1.txt 2>&1
 timeout 900 ./scripts/exp_h2.bin > $O/exp_h2.txt 2>&1
+timeout 300 ./scripts/exp_c16pair.bin > $O/exp_c16pair.txt 2>&1
 timeout 300 ./scripts/exp_h2_micro.bin > $O/exp_h2_micro.txt 2>&1
 timeout 600 python scripts/exp_ab_model.py f16x2 8 2>&1 | grep -v amdgpu.ids > $O/exp_ab_f16x2.txt
 timeout 600 python scripts/exp_ab_model.py f16x2_stream_k 8 2>&1 | grep -v amdgpu.ids > $O/exp_ab_stream_k.txt
