@@ -33,10 +33,10 @@
 // the row end and rows beyond the image are the 'SAME' zeros), and the split stage becomes the stride-2 convolution
 // (`fp_extractor/conv2d`, reference modules.py:57-61): per 16 patch pixels each lane reads its 8 of the 27 (+5 zero) K values
 // straight from the raw rows, splits them, and three 16x16x32 instructions (hh, two cross) produce the 16 channels that are
-// biased, activated, zeroed outside the image, split and written into the operand image the pair reads.  165 -> 131 us for the
+// biased, activated, zeroed outside the image, split and written into the operand image the pair reads.  165 -> 123 us for the
 // three layers at 16 x 448 x 1024 (profiles/r04_exp_c16pair.txt): the 117 MB level-1 input of the pair is never written or read.
-// The stride-2 stage costs 40-47 us of the 131 and is VALU ISSUE (about 100 vector instructions per 16 pixels: 12 operand
-// splits at 3.5 instructions, the epilogue, addresses; 2 waves per SIMD x 6 tiles x 4 cycles an instruction).  Running it for
+// The stride-2 stage costs 42 us of the 123 and is VALU ISSUE (2 waves per SIMD x 6 tiles x 4 cycles an instruction; about 100
+// vector instructions per 16 pixels with the compiler's 3.5-instruction operand split, 131 us; c16_split2 made it 123).  Running it for
 // tile t + 1 BESIDE layer 2 of tile t (waves 0-3 one order, waves 4-7 the other, two barriers per tile) changed nothing
 // (130.8 us): every wave still executes both in series and neither saturates a unit the other needs.
 #pragma once
@@ -45,6 +45,34 @@
 
 typedef _Float16 c16_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 c16_f16x4 __attribute__((ext_vector_type(4)));
+
+typedef _Float16 c16_f16x2 __attribute__((ext_vector_type(2)));
+
+// The operand split of TWO fp32 values in four vector instructions: h = fp16(x) of both (v_cvt_pk_f16_f32), x 2^11 of both
+// (v_pk_mul_f32), and m' = fp16(fma(h, -2^11, x 2^11)) = fp16((x - h) 2^11) per value with the fp16 half read in place and
+// the result written to its half of the pair (v_fma_mixlo / mixhi_f16): the same values as the scalar form
+//   h = (_Float16)x;  m' = (_Float16)fmaf((float)h, -2048.f, x * 2048.f);
+// which the compiler turns into seven.
+__device__ __forceinline__ void c16_split2(const float x0, const float x1, unsigned& h_pair, unsigned& m_pair) {
+    const f32x2 xs = {x0, x1};
+    const c16_f16x2 h2 = __builtin_convertvector(xs, c16_f16x2);
+    const f32x2 xm = xs * 2048.f;
+    const unsigned hp = __builtin_bit_cast(unsigned, h2);
+    const float neg = -2048.f;
+    unsigned mp;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(mp) : "v"(hp), "s"(neg), "v"(xm[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(mp) : "v"(hp), "s"(neg), "v"(xm[1]));
+    h_pair = hp; m_pair = mp;
+}
+__device__ __forceinline__ void c16_split4(const float x0, const float x1, const float x2, const float x3, c16_f16x4& h, c16_f16x4& m) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 hp, mp;
+    unsigned a, b;
+    c16_split2(x0, x1, a, b); hp[0] = a; mp[0] = b;
+    c16_split2(x2, x3, a, b); hp[1] = a; mp[1] = b;
+    h = __builtin_bit_cast(c16_f16x4, hp);
+    m = __builtin_bit_cast(c16_f16x4, mp);
+}
 
 struct C16Args {
     const float* x;
@@ -245,12 +273,11 @@ __global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
                 f32x4 hh[3], cx[3];
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
-                    c16_f16x8 Bh, Bm;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        Bh[e] = (_Float16)v[u][e];
-                        Bm[e] = (_Float16)__builtin_fmaf((float)Bh[e], -2048.f, v[u][e] * 2048.f);
-                    }
+                    c16_f16x4 hl, ml, hu, mu;
+                    c16_split4(v[u][0], v[u][1], v[u][2], v[u][3], hl, ml);
+                    c16_split4(v[u][4], v[u][5], v[u][6], v[u][7], hu, mu);
+                    const c16_f16x8 Bh = __builtin_shufflevector(hl, hu, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const c16_f16x8 Bm = __builtin_shufflevector(ml, mu, 0, 1, 2, 3, 4, 5, 6, 7);
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                     hh[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0h, Bh, b0v, 0, 0, 0);        // (the bias rides in the accumulator)
                     cx[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0h, Bm, z, 0, 0, 0);
@@ -261,14 +288,14 @@ __global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
                     const int i = 3 * g + u;
                     if (wave + 8 * i >= ((ABL & 2) ? 0 : C16_NPIX / 16)) continue;
                     c16_f16x4 h, m;
+                    float o[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float o = hh[u][e] + cx[u][e] * (1.f / 2048.f);
-                        o = fmaxf(o, o * a.slope);
-                        if (!INTERIOR) o = in_image[u] ? o : 0.f;
-                        h[e] = (_Float16)o;
-                        m[e] = (_Float16)__builtin_fmaf((float)h[e], -2048.f, o * 2048.f);
+                        o[e] = hh[u][e] + cx[u][e] * (1.f / 2048.f);
+                        o[e] = fmaxf(o[e], o[e] * a.slope);
+                        if (!INTERIOR) o[e] = in_image[u] ? o[e] : 0.f;
                     }
+                    c16_split4(o[0], o[1], o[2], o[3], h, m);
                     char* dst = sm + C16_IN0 + dst_lane + i * 2048;
                     *reinterpret_cast<c16_f16x4*>(dst) = h;
                     *reinterpret_cast<c16_f16x4*>(dst + 2 * C16_CH) = m;
@@ -285,11 +312,7 @@ __global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(sm + C16_S0 + it * 16);
                 const int rec = it >> 2, g = it & 3;
                 c16_f16x4 h, m;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    h[e] = (_Float16)v[e];
-                    m[e] = (_Float16)__builtin_fmaf((float)h[e], -2048.f, v[e] * 2048.f);
-                }
+                c16_split4(v[0], v[1], v[2], v[3], h, m);
                 char* dst = sm + C16_IN0 + (g >> 1) * C16_CH + rec * 16 + (g & 1) * 8;
                 *reinterpret_cast<c16_f16x4*>(dst) = h;
                 *reinterpret_cast<c16_f16x4*>(dst + 2 * C16_CH) = m;
@@ -316,12 +339,10 @@ __global__ __launch_bounds__(512) void conv3x3_c16pair_kernel(const C16Args a) {
                 c16_f16x4 h, m;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = o[e];
-                    v = fmaxf(v, v * a.slope);
-                    if (!INTERIOR) v = in_image ? v : 0.f;
-                    h[e] = (_Float16)v;
-                    m[e] = (_Float16)__builtin_fmaf((float)h[e], -2048.f, v * 2048.f);
+                    o[e] = fmaxf(o[e], o[e] * a.slope);
+                    if (!INTERIOR) o[e] = in_image ? o[e] : 0.f;
                 }
+                c16_split4(o[0], o[1], o[2], o[3], h, m);
                 char* dst = sm + C16_MID0 + (kq >> 1) * C16_CH + p * 16 + (kq & 1) * 8;
                 *reinterpret_cast<c16_f16x4*>(dst) = h;
                 *reinterpret_cast<c16_f16x4*>(dst + 2 * C16_CH) = m;
