@@ -38,7 +38,10 @@
 // The stride-2 stage costs 42 us of the 123 and is VALU ISSUE (2 waves per SIMD x 6 tiles x 4 cycles an instruction; about 100
 // vector instructions per 16 pixels with the compiler's 3.5-instruction operand split, 131 us; c16_split2 made it 123).  Running it for
 // tile t + 1 BESIDE layer 2 of tile t (waves 0-3 one order, waves 4-7 the other, two barriers per tile) changed nothing
-// (130.8 us): every wave still executes both in series and neither saturates a unit the other needs.
+// (130.8 us): every wave still executes both in series and neither saturates a unit the other needs.  Delaying waves 4-7 by
+// 256 - 900 cycles behind every barrier (so that one wave of a SIMD reads while the other multiplies) ADDS the delay: 126 -> 126 /
+// 128 / 129 us.  The layers are the serial latency of a wave's read -> 14 dependent-pair MFMAs -> epilogue chain at two waves
+// per SIMD, not contention for the LDS or the matrix pipe.
 #pragma once
 #include "pwc_common.h"
 #include <type_traits>

@@ -1,5 +1,3 @@
 mkdir -p gpurun_out/r4h
-timeout 1800 python -m pytest tests/test_gpu_model.py -x -q > gpurun_out/r4h/tests_model.txt 2>&1
-tail -2 gpurun_out/r4h/tests_model.txt
-timeout 300 python scripts/exp_timeline.py 8 2>/dev/null | head -3
-for i in 1 2 3; do python bench.py --steps 30 --warmup 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; done
+for k in 4 8 14; do echo "skew $k"; timeout 300 scripts/exp_c16pair_skew$k.bin 2>&1 | grep "medians" | sed -n '1p;$p'; done
+echo "skew 0"; timeout 300 scripts/exp_c16pair.bin 2>&1 | grep "medians" | sed -n '1p;$p'
