@@ -41,7 +41,9 @@
 // (130.8 us): every wave still executes both in series and neither saturates a unit the other needs.  Delaying waves 4-7 by
 // 256 - 900 cycles behind every barrier (so that one wave of a SIMD reads while the other multiplies) ADDS the delay: 126 -> 126 /
 // 128 / 129 us.  The layers are the serial latency of a wave's read -> 14 dependent-pair MFMAs -> epilogue chain at two waves
-// per SIMD, not contention for the LDS or the matrix pipe.
+// per SIMD, not contention for the LDS or the matrix pipe.  Issuing a wave's NEXT tile's 14 reads behind the matrix
+// instructions of the current one (in front of its epilogue) needs a second fragment set in the allocator's eyes: 256
+// registers + 44 / 54 spilled -- the 28 weight operands (112 registers) leave no room for it.
 #pragma once
 #include "pwc_common.h"
 #include <type_traits>
