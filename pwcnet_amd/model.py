@@ -138,7 +138,7 @@ class PWCDCNet(object):
         # latency-bound coarse levels of one overlap the MFMA-bound layers of another (+4-5 % pairs/s at batch 8,
         # scripts/exp_two_streams.py, profiles/r02_bench_streams2.json).  Same results and the same stream semantics
         # for the caller (the side streams wait for the caller's stream, the caller's stream waits for them).
-        # streams=None (default): 2 for even batches of at least 4 pairs (and for 2 pairs of at least 256x512 pixels), 1 otherwise; streams=1 switches it off
+        # streams=None (default): 2 for even batches of at least 4 pairs of the non-DC network, 1 otherwise; streams=1 switches it off
         # (per-kernel timings -- profilers, HIP events on the caller's stream -- need the single-stream form).
         self.streams = None if streams is None else max(1, int(streams))
         self._side_streams = {}
@@ -208,13 +208,14 @@ class PWCDCNet(object):
 
     def effective_streams(self, shape):
         """Number of sub-batches a batch of this (N, H, W, 3) shape is run as: `streams` if given (and dividing N), else
-        2 for even batches of at least 4 pairs (and for 2 pairs of at least 256x512 pixels), else 1.  (The forward still
-        falls back to 1 when no side stream on a hardware queue of its own exists: side_stream_report.)"""
+        2 for even batches of at least 4 pairs of the non-DC network, else 1 -- what an interleaved A/B of the two forms says
+        since the big layers moved to the F16 pipe (profiles/r04_exp_streams_ab.txt: batch 4 +3.7 %, batch 8 +1-2 %, batch 32
+        +1 %; batch 2 -2.4 %, use_dc=True -2.5 %).  (The forward still falls back to 1 when no side stream on a hardware
+        queue of its own exists: side_stream_report.)"""
         n_batch = int(shape[0]) if len(shape) >= 1 else 0
         k = self.streams
-        if k is None:       # a batch of 2 only at sizes where a single pair fills the GPU (+5 % at 448x1024)
-            hw = int(shape[1]) * int(shape[2]) if len(shape) == 4 else 0
-            k = 2 if (n_batch % 2 == 0 and (n_batch >= 4 or (n_batch == 2 and hw >= 256 * 512))) else 1
+        if k is None:
+            k = 2 if (n_batch % 2 == 0 and n_batch >= 4 and not getattr(self, "use_dc", False)) else 1
         if k > 1 and (n_batch % k != 0 or n_batch < k):
             k = 1
         return k

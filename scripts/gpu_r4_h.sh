@@ -1,3 +1,4 @@
 mkdir -p gpurun_out/r4h
-for k in 4 8 14; do echo "skew $k"; timeout 300 scripts/exp_c16pair_skew$k.bin 2>&1 | grep "medians" | sed -n '1p;$p'; done
-echo "skew 0"; timeout 300 scripts/exp_c16pair.bin 2>&1 | grep "medians" | sed -n '1p;$p'
+timeout 1800 python -m pytest tests/test_gpu_configs.py -x -q > gpurun_out/r4h/tests_configs.txt 2>&1
+tail -3 gpurun_out/r4h/tests_configs.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
