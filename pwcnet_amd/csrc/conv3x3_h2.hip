@@ -48,6 +48,11 @@
 //   (spread, staggered between the waves of a SIMD, issued right behind the barriers, given to half of the waves, s_setprio) or
 //   the weights off the LDS-DMA path (through registers: r04_exp_h2_weights_through_registers.txt) changes the per-tap pattern
 //   and not the time: the matrix pipe is what the loop waits for.
+//   The piece ends were tried as part of the NEXT tile's first tap (that tap pair-major -- hh, cross, cross of pair p, the four
+//   16-byte chunks of pair p + 1's output between them, each pair stored ahead of the instruction that starts its accumulators
+//   again): the register count is unchanged on paper (an old and a new accumulator of a pair never live together), the
+//   compiler's allocation is not -- 256 registers and 201 - 629 spilled in the 128 / 96 / 64 x 16 variants, as a third copy of
+//   the tap and as a predicated form of the fresh tap alike.  It needs the accumulators pinned by hand.
 #pragma once
 #include "pwc_common.h"
 #include <type_traits>
