@@ -53,6 +53,9 @@
 //   again): the register count is unchanged on paper (an old and a new accumulator of a pair never live together), the
 //   compiler's allocation is not -- 256 registers and 201 - 629 spilled in the 128 / 96 / 64 x 16 variants, as a third copy of
 //   the tap and as a predicated form of the fresh tap alike.  It needs the accumulators pinned by hand.
+//   The split in five instructions per value pair instead of seven (conv3x3_c16pair.hip's c16_split2 with plain multiplies)
+//   changes no launch by more than the noise (128 -> 128, 96 -> 64, 64 -> 32, 32 -> 32, d = 16): the split already hides
+//   behind the matrix instructions of its taps.
 #pragma once
 #include "pwc_common.h"
 #include <type_traits>

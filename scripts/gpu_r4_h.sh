@@ -1,4 +1,3 @@
 mkdir -p gpurun_out/r4h
-timeout 1800 python -m pytest tests/test_gpu_configs.py -x -q > gpurun_out/r4h/tests_configs.txt 2>&1
-tail -3 gpurun_out/r4h/tests_configs.txt
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+for sh in 0 3 4 16 20; do for k in 0 1 0 1; do echo "shape $sh split_asm $k: $(timeout 300 scripts/exp_h2_split$k.bin $sh 2>&1 | grep -E "^  F\(2x2\)|entries off" | tail -2 | sed 's/.*F(4x4) f16x2 direct/h2/' | tr '\n' ' ')"; done; done > gpurun_out/r4h/h2_split.txt
+cat gpurun_out/r4h/h2_split.txt
