@@ -52,7 +52,12 @@
 //   16-byte chunks of pair p + 1's output between them, each pair stored ahead of the instruction that starts its accumulators
 //   again): the register count is unchanged on paper (an old and a new accumulator of a pair never live together), the
 //   compiler's allocation is not -- 256 registers and 201 - 629 spilled in the 128 / 96 / 64 x 16 variants, as a third copy of
-//   the tap and as a predicated form of the fresh tap alike.  It needs the accumulators pinned by hand.
+//   the tap and as a predicated form of the fresh tap alike (the allocator keeps the accumulators in two sets of tuples, one per
+//   instantiation of the first tap, and copies between them).  With ONE copy of the first tap -- its accumulate-or-start choice a
+//   uniform branch per instruction, the matrix instructions as inline assembly with the accumulator tied through them -- the
+//   allocation holds (0 - 27 registers spilled), but the launches got slower, 128 -> 128 202 - 212 us against 175 - 180 and
+//   64 -> 32 41 against 39 (a pair-major first tap in EVERY stage, instructions the scheduler cannot see into), before its
+//   results were right.  Left there.
 //   The split in five instructions per value pair instead of seven (conv3x3_c16pair.hip's c16_split2 with plain multiplies)
 //   changes no launch by more than the noise (128 -> 128, 96 -> 64, 64 -> 32, 32 -> 32, d = 16): the split already hides
 //   behind the matrix instructions of its taps.
