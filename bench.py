@@ -58,6 +58,8 @@ KERNEL_PEAK = {"conv3x3_h2_kernel": PEAK_F16_MFMA_TFLOPS, "conv3x3_c16pair_kerne
 def peak_of(kernel):
     return KERNEL_PEAK.get(kernel, PEAK_F32_MFMA_TFLOPS)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
+# the arithmetic the path computes in (a bare "f32" hides the split)
+DTYPE = "f32 via fp16x2-split MFMA (fp32 tensors and accumulation; big stride-1 convs, level-1 extractor and correlation on the F16 pipe)"
 
 CONFIGS = {
     # name -> overrides (BASELINE.json `configs` indices)
@@ -85,6 +87,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget")
     ap.add_argument("--no-op-timing", action="store_true", help="skip the per-launch HIP events")
     ap.add_argument("--no-op-leg", action="store_true", help="skip the op-level correlation/warp leg")
+    ap.add_argument("--op-leg-only", action="store_true",
+                    help="run ONLY the op-level correlation/warp leg (what scripts/gpu_pmc_op_leg.sh profiles with rocprofv3 --pmc "
+                         "to fill roofline_hbm.traffic) and print its object")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the f16x2=False comparison forward (value_fp32_only)")
     ap.add_argument("--mode", choices=("infer", "train"), default="infer",
                     help="train: one optimisation step per bench step (pwcnet_amd.train.Trainer: forward, backward, "
                          "one RCCL all-reduce of the gradients, Adam) -- SURVEY.md 8 f4, not the headline metric")
@@ -246,6 +252,10 @@ def main():
                               streams=args.streams if args.streams > 0 else None)
     net.load_weights(wts)
     eff_streams = 1 if args.persistent_outputs else net.effective_streams((args.batch, args.height, args.width, 3))
+    if args.op_leg_only:
+        if rank == 0:
+            print(json.dumps({"roofline_hbm": corr_warp_op_leg(net, args.batch, args.height, args.width, dev)}))
+        return
 
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
@@ -305,13 +315,18 @@ def main():
     else:
         for _ in range(args.steps):
             out = net(im0, im1)
+    issue_elapsed = time.perf_counter() - t0          # host time to ISSUE the K forwards (the GPU runs behind)
     sync_all()
     elapsed = time.perf_counter() - t0
     del out
+    st_rep = net.status()                             # the kernels' status words (fp16 range / stream-K): nothing may have fired
 
-    stats = gather_stats(dict(pairs=float(B * args.steps), seconds=elapsed), dist, dev)
+    stats = gather_stats(dict(pairs=float(B * args.steps), seconds=elapsed, issue_seconds=issue_elapsed), dist, dev)
     value, ms_per_step, total_pairs, n_ranks = aggregate_throughput(stats, args.steps)
     assert n_ranks == world
+    # every rank's own step time next to the job's (= the slowest rank's): a straggler shows as a rank, not as a mystery
+    per_rank_ms = [1e3 * st["seconds"] / args.steps for st in stats]
+    per_rank_issue_ms = [1e3 * st["issue_seconds"] / args.steps for st in stats]
     used_rccl = dist is not None
     if dist is not None:
         # every rank leaves the process group together, before rank 0's single-GPU legs (op-level leg, CPU baseline)
@@ -337,8 +352,14 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": DTYPE if net.f16x2 else "f32",
+        "timed_region_ms": 1e3 * elapsed,
+        "per_rank_ms_per_step": per_rank_ms,
+        "per_rank_host_issue_ms_per_step": per_rank_issue_ms,
         "data": "synthetic (uniform[0,1) images, seeded glorot-uniform weights; trained weights absent)",
+        "range_status": {"flags": st_rep["flags"], "f16x2_still_on": st_rep["f16x2"], "range_check": net.range_check,
+                         "note": "PWC_STATUS_* bits the F16-pipe kernels raised during the run (0: every operand stayed below "
+                                 "65504, no stream-K timeout); a raised bit would have moved the model to the fp32 kernels"},
         "config": {
             "workload": (f"batch={B} pairs per GPU, {H}x{Wd}, random-init PWC-Net (PWCDCNet use_dc={args.use_dc}) "
                          f"forward on {world}xMI355X"
@@ -378,8 +399,12 @@ def main():
         dd = summ[dominant]
         alg = dd["flops"] / (dd["ms"] * 1e-3) / 1e12
         exe = dd["exec_flops"] / (dd["ms"] * 1e-3) / 1e12
-        roof = {"kernel": dominant, "bound": "mfma", "achieved": exe, "peak": peak_of(dominant),
-                "unit": "TFLOP/s", "frac": exe / peak_of(dominant), "traffic": None,
+        # achieved / frac: ALGORITHMIC flops of the launches (2*M*9*Cin*Cout of the direct convolution) over their
+        # durations, against the peak of the pipe the kernel runs on.  What the pipe EXECUTES for them (three fp16 products per
+        # multiply-add, padded Cin; Winograd's fewer multiplies) is frac_executed -- the pipe's utilisation, not the work done.
+        roof = {"kernel": dominant, "bound": "mfma", "achieved": alg, "peak": peak_of(dominant),
+                "unit": "TFLOP/s", "frac": alg / peak_of(dominant), "frac_algorithmic": alg / peak_of(dominant),
+                "executed_tflops": exe, "frac_executed": exe / peak_of(dominant), "traffic": None,
                 "avg_launch_us": 1e3 * dd["ms"] / dd["launches"],
                 "launches_per_step": dd["launches"] / n_sampled,
                 "flops_per_launch": dd["exec_flops"] / dd["launches"],
@@ -387,10 +412,10 @@ def main():
                 "algorithmic_flops_per_launch": dd["flops"] / dd["launches"],
                 "algorithmic_over_executed": dd["flops"] / dd["exec_flops"],
                 "measured": where,
-                "note": "achieved/frac = multiply-adds the MFMA units execute (Winograd: 16 per 2x2 outputs "
+                "note": "achieved/frac = algorithmic: 2*M*9*Cin*Cout of the direct convolution the launch replaces (SURVEY.md 8d); "
+                        "executed_tflops/frac_executed = multiply-adds the MFMA units execute (Winograd: 16 per 2x2 outputs "
                         "and 36 per 4x4 outputs instead of 9 per output, physical Cin; conv3x3_h2_kernel: three fp16 "
-                        "products per fp32 multiply-add, on the F16 pipe, against the dense F16 peak); algorithmic_* = "
-                        "2*M*9*Cin*Cout of the direct convolution the launch replaces (SURVEY.md 8d)"}
+                        "products per fp32 multiply-add, on the F16 pipe, against the dense F16 peak)"}
         if dominant == "conv3x3_h2_kernel":
             roof["arithmetic"] = ("fp32 in / fp32 out / fp32 accumulation; every operand as h + 2^-11 m' (h = fp16(x), m' = "
                                   "fp16((x - h) 2^11)), products uh vh + 2^-11 (uh vm' + um' vh) on v_mfma_f32_32x32x16_f16: "
@@ -399,7 +424,7 @@ def main():
                 "frac_of_peak": 0.65,
                 "why": "a loop of nothing but v_mfma_f32_32x32x16_f16 on random operands, two waves per SIMD on all 256 CUs, runs "
                        "at 493 ns per 24 instructions = 1.6 PFLOP/s (350 ns on all-zero operands): the clock drops under the "
-                       "matrix pipe's load (profiles/r04_exp_h2_micro.txt); frac against THAT rate = frac / 0.65"}
+                       "matrix pipe's load (profiles/r04_exp_h2_micro.txt); frac_executed against THAT rate = frac_executed / 0.65"}
         caps = {"conv3x3_wino_kernel": 0.83, "conv3x3_wino4_kernel": 0.62}
         if dominant in caps:
             roof["instruction_mix_cap"] = {
@@ -409,7 +434,8 @@ def main():
                        "7 N_dma) of the kernel's main loop (DESIGN.md 3.4)"}
         total_ms = sum(v["ms"] for v in summ.values())
         roof["other_mfma_kernels"] = {
-            k: {"frac": v["exec_flops"] / (v["ms"] * 1e-3) / 1e12 / peak_of(k), "peak": peak_of(k),
+            k: {"frac": v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak_of(k), "peak": peak_of(k),
+                "frac_executed": v["exec_flops"] / (v["ms"] * 1e-3) / 1e12 / peak_of(k),
                 "algorithmic_tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                 "avg_launch_us": 1e3 * v["ms"] / v["launches"], "launches_per_step": v["launches"] / n_sampled,
                 "share_of_kernel_time": v["ms"] / total_ms}
@@ -468,6 +494,36 @@ def main():
 
     if not args.no_op_leg:
         line["roofline_hbm"] = corr_warp_op_leg(net, B, H, Wd, dev)
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc) and (B, H, Wd, args.use_dc) == (8, 448, 1024, False):
+            t = json.load(open(pmc)).get("op_leg")
+            if t:       # HBM-side bytes of the SAME leg from the committed PMC passes (scripts/gpu_pmc_op_leg.sh)
+                hb = line["roofline_hbm"]
+                hb["traffic"] = t["hbm_read_bytes_per_forward"] + t["hbm_write_bytes_per_forward"]
+                hb["traffic_unit"] = "bytes per forward's worth of launches (all five levels)"
+                hb["traffic_read"], hb["traffic_write"] = t["hbm_read_bytes_per_forward"], t["hbm_write_bytes_per_forward"]
+                hb["traffic_over_algorithmic"] = hb["traffic"] / hb["algorithmic_bytes_per_forward"]
+                hb["traffic_per_kernel"] = t.get("per_kernel")
+                hb["traffic_source"] = "profiles/pmc_traffic.json: " + t["source"]
+
+    if not args.no_fp32_leg and world == 1 and net.f16x2:
+        # the same forward with fp32 MFMA everywhere (PWCDCNet(f16x2=False)): what the split arithmetic buys, in the same line
+        net32 = pwcnet_amd.PWCDCNet(use_dc=args.use_dc, persistent_outputs=args.persistent_outputs,
+                                    streams=args.streams if args.streams > 0 else None, f16x2=False)
+        net32.load_weights(wts)
+        for _ in range(max(2, min(args.warmup, 3))):
+            net32(im0, im1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            o32 = net32(im0, im1)
+        torch.cuda.synchronize()
+        e32 = time.perf_counter() - t0
+        line["value_fp32_only"] = B * args.steps / e32
+        line["ms_per_step_fp32_only"] = 1e3 * e32 / args.steps
+        o16 = net(im0, im1)
+        line["max_abs_flow_diff_vs_fp32_only"] = float((o16[0] - o32[0]).abs().max())
+        del net32, o32, o16
 
     if world == 1 and not args.no_cpu_baseline:
         line.update(cpu_baseline_and_parity(net, wts, args, dev))
@@ -497,7 +553,7 @@ def corr_warp_op_leg(net, B, H, Wd, dev, reps=12):
     per_level = {}
     for l, h, w, C in levels:
         # the estimator input buffer of this level, as PWCDCNet lays it out (non-DC geometry)
-        lay = net.of_estimators[l]._layout(81, C, l > 0, list(range(32)) if l > 0 else None)
+        lay = net._est_layout(l, B, h, w, C, l > 0, list(range(32)) if l > 0 else None)
         est_cs = lay.n_phys
         set_bytes = 4 * B * h * w * (3 * C + 2 + est_cs)
         nsets = max(2, int(300e6 // set_bytes) + 1)
@@ -519,7 +575,7 @@ def corr_warp_op_leg(net, B, H, Wd, dev, reps=12):
             v1 = M.View(f1.data_ptr(), C, B, h, w, C)
             Ev = M.View(E.data_ptr(), est_cs, B, h, w, est_cs)
             cv_out = M.sub_view(Ev, lay.offset("cv"), 81)
-            f0_dst = M.sub_view(Ev, lay.offset("f0"), C)
+            f0_dst = M.sub_view(Ev, lay.offset("f0"), C) if "f0" in lay.segments else None
             flv = M.View(fl.data_ptr(), 2, B, h, w, 2)
             net._corr_level(l, v0, v1, flv if l > 0 else None, cv_out, f0_dst, Ev, dev)
 
@@ -530,7 +586,7 @@ def corr_warp_op_leg(net, B, H, Wd, dev, reps=12):
             for r in range(reps):
                 run(sets[r % nsets])
         torch.cuda.synchronize()
-        per_level[l] = dict(h=h, w=w, C=C, sets=nsets)
+        per_level[l] = dict(h=h, w=w, C=C, sets=nsets, est_buffer_channels=est_cs, f0_in_buffer="f0" in lay.segments)
         del sets
     summ = timer.summary()
     ms = sum(d["ms"] for d in summ.values())
@@ -542,10 +598,12 @@ def corr_warp_op_leg(net, B, H, Wd, dev, reps=12):
             "algorithmic_bytes_per_forward": by / reps,
             "per_kernel": {k: {"avg_us": 1e3 * d["ms"] / d["launches"], "gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
                                "launches_per_forward": d["launches"] / reps} for k, d in summ.items()},
+            "per_level": per_level,
             "measured": f"op-level leg: production launch sequence of every pyramid level (batch {B}), flows ~ "
                         f"N(0,3^2) px, {reps} repetitions over operand sets rotating through > 256 MB, HIP events per "
                         "launch; bytes = N*h*w*(2C+81)*4 per cost volume + N*h*w*(2C+2)*4 per warp "
-                        "(N*h*w*(2C+2+81)*4 for a fused launch); concat-copy bytes not counted"}
+                        "(N*h*w*(2C+2+81)*4 for a fused launch); concat-copy bytes not counted (levels whose first conv "
+                        "reads features_0 from the pyramid tensor have no such copy)"}
 
 
 def _physical_cores(cpus):

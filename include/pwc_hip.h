@@ -125,6 +125,18 @@ int pwc_warp_cost_volume_concat_f32(const float* f0, int f0_cs, const float* f1,
                                     pwc_stream_t stream);
 int pwc_warp_cost_volume_concat_supported(int H, int W, int C, int search_range, int f0_cs, int f1_cs,
                                           int flow_cs, int out_cs, int f0_copy_cs);
+/* Round 5: the same launch with the correlation on the F16 matrix pipe: every operand (f0, and the warped f1 after the
+ * fp32 bilinear blend of modules.py:132-135) is used as the two-term fp16 split x = h + 2^-11 m' of pwc_conv3x3_h2_f32,
+ * three v_mfma_f32_16x16x32_f16 per (4x4-pixel block pair, 32 channels), fp32 accumulation -- 27 matrix instructions per
+ * block where the fp32 form has 72 twice as long, and none of them stalls the vector instructions of its SIMD.  Error
+ * against float64: not larger than the fp32 form's (tests).  RANGE: features below 65504 in magnitude (beyond: NaN
+ * outputs, see PWC_STATUS_NONFINITE).  Same support set as the fp32 form. */
+int pwc_warp_cost_volume_concat_h2_f32(const float* f0, int f0_cs, const float* f1, int f1_cs,
+                                       const float* flow, int flow_cs, float flow_scale,
+                                       float* out, int out_cs, int out_pad_writable,
+                                       float* f0_copy, int f0_copy_cs,
+                                       int N, int H, int W, int C, int search_range, float slope,
+                                       pwc_stream_t stream);
 
 /* ---- a4/a5/a6: tf.layers.Conv2D(Cout,(3,3),(s,s),'same',dilation_rate=d) [+
  * tf.nn.leaky_relu(slope)] -- modules.py:62-67,267-268,274,306-324 ----
@@ -233,6 +245,31 @@ int pwc_conv3x3_h2_f32(const float* x, int x_cs, const float* packed_w, const fl
  * tile. */
 size_t pwc_conv3x3_h2_workspace_floats(int N, int H, int W, int Cin_phys, int Cout, int dilation);
 int pwc_conv3x3_h2_supported(int N, int H, int W, int Cin_phys, int Cout, int dilation);
+/* Round 5.  Status words: `status` points at TWO caller-owned uint32 in device memory (8-byte aligned; the caller zeroes
+ * them, launches only OR bits into status[0] / atomic-max status[1]; NULL: no report).
+ *   status[0] & PWC_STATUS_NONFINITE        pwc_resize_bilinear_status_f32 wrote a value that is not finite.  The F16-pipe
+ *                                           kernels (pwc_conv3x3_h2*, pwc_conv3x3_c16pair*, pwc_warp_cost_volume_concat_h2_f32)
+ *                                           turn an operand at or beyond 65504 in magnitude into NaN outputs (inf - inf in the
+ *                                           split), NaN survives every later layer of the network, so the model's LAST launch
+ *                                           sees it: repeat the forward on the fp32 kernels (the reference, plain fp32, has no
+ *                                           such limit).  Watching the operands inside the kernels instead was measured at 2-3 %
+ *                                           of every launch (profiles/r05_timeline_range_tracking_cost.txt).
+ *   status[0] & PWC_STATUS_STREAMK_TIMEOUT  a workgroup of the workspace form of pwc_conv3x3_h2* gave up waiting for a published
+ *                                           partial sum (cannot happen short of a fault); its outputs are NaN and the workspace
+ *                                           may hold stale sums: refill it with 0xFF bytes before its next use
+ *   status[1]                               pwc_absmax_f32: bits of the largest |value| seen (a non-negative float orders like
+ *                                           its bit pattern) -- the debugging aid behind PWCDCNet(track_max=True)
+ * pwc_conv3x3_h2_ex_f32 = pwc_conv3x3_h2_f32 with the status words and with the input channels given as TWO tensors over
+ * the same pixels: physical channels [0, Cin_a_phys) are channels [0, Cin_a_phys) of x (Cin_a_phys % 16 == 0), channels
+ * [Cin_a_phys, Cin_phys) are channels [0, Cin_phys - Cin_a_phys) of x2 (channel stride x2_cs, 16-byte aligned).  This is
+ * how `tf.concat([cv, features_0, flows_up_prev, features_up_prev])` (reference modules.py:261-264) costs nothing for
+ * features_0: the estimator's first layer reads it from the pyramid tensor.  x2 = NULL: all channels from x. */
+#define PWC_STATUS_NONFINITE 1u
+#define PWC_STATUS_STREAMK_TIMEOUT 2u
+int pwc_conv3x3_h2_ex_f32(const float* x, int x_cs, int Cin_a_phys, const float* x2, int x2_cs,
+                          const float* packed_w, const float* bias, float* y, int y_cs, int N, int H, int W,
+                          int Cin_phys, int Cout, int dilation, int apply_act, float slope, float* workspace,
+                          size_t workspace_floats, uint32_t* status, pwc_stream_t stream);
 /* TWO chained 3x3 stride-1 'SAME' convolutions of 16 channels each (16 -> 16 -> 16) with a leaky-relu of slope `slope`
  * behind each, in one launch (csrc/conv3x3_c16pair.hip; reference modules.py:62-67, the `fp_extractor/conv2d_1`,
  * `conv2d_2` pair of pyramid level 1): the intermediate stays in LDS instead of making a round trip through memory.
@@ -308,6 +345,16 @@ int pwc_conv3x3_direct_f32(const float* x, int x_cs, const float* w_hwio, const 
 int pwc_resize_bilinear_f32(const float* x, int x_cs, float* y, int y_cs,
                             int N, int H, int W, int C, int OH, int OW, float mul,
                             pwc_stream_t stream);
+/* The same launch; additionally status[0] |= PWC_STATUS_NONFINITE if any value it writes is not finite (status: two
+ * caller-owned uint32, see pwc_conv3x3_h2_ex_f32; NULL = pwc_resize_bilinear_f32).  The model's last launch -- the x4
+ * upsampling of model.py:127 -- runs through this entry: one compare per output of a launch that waits for memory. */
+int pwc_resize_bilinear_status_f32(const float* x, int x_cs, float* y, int y_cs,
+                                   int N, int H, int W, int C, int OH, int OW, float mul,
+                                   uint32_t* status, pwc_stream_t stream);
+/* status[1] = max(status[1], bits of max |x[p, 0:C]|) over npix pixels (channel stride x_cs); NaN entries are skipped.
+ * Debugging aid (PWCDCNet(track_max=True) runs it on every conv input): how far a network's activations are from the
+ * 65504 of the F16-pipe kernels. */
+int pwc_absmax_f32(const float* x, int x_cs, long npix, int C, uint32_t* status, pwc_stream_t stream);
 
 /* Two resizes of one geometry in one launch (modules.py:283-284: flows_up and features_up of the
  * same level): xa/ya carry 2 channels (8-byte aligned, even channel strides), xb/yb CB channels

@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libpwc_hip.so")
 SOURCES = ["conv3x3_mfma.hip", "conv3x3_wino.hip", "conv3x3_direct.hip", "cost_volume.hip", "pwc_ops.hip",
            "pwc_backward.hip", "conv3x3_wgrad.hip", "conv3x3_h2.hip", "conv3x3_c16pair.hip"]
-HEADERS = ["pwc_common.h", "cost_volume_roll.hip", "cost_volume_mfma.hip", "conv3x3_wino4.hip", os.path.join("..", "..", "include", "pwc_hip.h")]
+HEADERS = ["pwc_common.h", "cost_volume_roll.hip", "cost_volume_mfma.hip", "cost_volume_h2.hip", "conv3x3_wino4.hip", os.path.join("..", "..", "include", "pwc_hip.h")]
 
 _vp, _i, _f, _l, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long, ctypes.c_size_t
 
@@ -33,6 +33,7 @@ SIGNATURES = {
     "pwc_warp_copy_f32": (_i, [_i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "pwc_warp_cost_volume_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_warp_cost_volume_concat_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "pwc_warp_cost_volume_concat_h2_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_warp_cost_volume_concat_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "pwc_conv3x3_packed_floats": (_sz, [_i, _i]),
     "pwc_conv3x3_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -52,6 +53,7 @@ SIGNATURES = {
     "pwc_conv3x3_h2_packed_floats": (_sz, [_i, _i]),
     "pwc_conv3x3_h2_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pwc_conv3x3_h2_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "pwc_conv3x3_h2_ex_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp]),
     "pwc_conv3x3_h2_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "pwc_conv3x3_h2_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "pwc_conv3x3_h2_plan": (_i, [_i, _i, _i, _i, _i, _i]),
@@ -71,6 +73,8 @@ SIGNATURES = {
     "pwc_conv3x3_wino_split_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "pwc_conv3x3_direct_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_resize_bilinear_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "pwc_resize_bilinear_status_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "pwc_absmax_f32": (_i, [_vp, _i, _l, _i, _vp, _vp]),
     "pwc_copy_channels_f32": (_i, [_vp, _i, _vp, _i, _l, _i, _vp]),
     "pwc_device_spin": (_i, [ctypes.c_longlong, _vp]),
     "pwc_device_touch": (_i, [_vp, _vp]),
@@ -92,6 +96,10 @@ SIGNATURES = {
     "pwc_flow_norm_sums_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp]),
 }
 
+# status word bits of the F16-matrix-pipe kernels (include/pwc_hip.h)
+STATUS_NONFINITE = 1
+STATUS_STREAMK_TIMEOUT = 2
+
 _lib = None
 
 
@@ -99,21 +107,48 @@ class PwcHipError(RuntimeError):
     pass
 
 
+def _includes(path, seen=None):
+    """The quoted #include closure of a source (per-object staleness check)."""
+    import re
+    seen = set() if seen is None else seen
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    with open(path, "r", errors="replace") as f:
+        for inc in re.findall(r'^\s*#include\s+"([^"]+)"', f.read(), flags=re.M):
+            _includes(os.path.normpath(os.path.join(os.path.dirname(path), inc)), seen)
+    return seen
+
+
 def build_library(force=False, verbose=False):
-    """hipcc-compile the HIP sources for gfx950 into csrc/libpwc_hip.so (in-tree)."""
+    """hipcc-compile the HIP sources for gfx950 into csrc/libpwc_hip.so (in-tree): one object per source, compiled in
+    parallel and only when the source or something it includes is newer, then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
-    if not force and os.path.exists(LIB_PATH):
-        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
-            return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
     # -fno-slp-vectorize: hipcc otherwise packs the scalar fp32 FMA chains of the
     # correlation kernel into v_pk_fma_f32 pairs (hundreds of v_mov shuffles, VGPR spills)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
-           "-Wno-pass-failed", *srcs, "-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-pass-failed"]
+    jobs, objs = [], []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        newest = max(os.path.getmtime(d) for d in _includes(src))
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+            jobs.append([hipcc, *flags, "-c", src, "-o", obj])
+    if not jobs and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(o) for o in objs):
+        return LIB_PATH
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as pool:
+        list(pool.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH])
     return LIB_PATH
 
 

@@ -65,8 +65,6 @@
 #include "pwc_common.h"
 #include <type_traits>
 
-typedef _Float16 pwc_f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 pwc_f16x4 __attribute__((ext_vector_type(4)));
 typedef float pwc_f32x16 __attribute__((ext_vector_type(16)));
 
 struct H2Args {
@@ -87,6 +85,16 @@ struct H2Args {
     unsigned* dbg;       // harness only
     int stride;          // 1, or 2: only the sums at positions 2 o + off are stored, to an (Ho, Wo) output
     int Ho, Wo, off_y, off_x;
+    // round 5: the input as TWO tensors -- stages c16 < nc16_a are channels [16 c16, 16 c16 + 16) of x, the others channels
+    // [16 (c16 - nc16_a), ...) of x2 (same pixel grid, own channel stride).  The estimator's first layer reads features_0
+    // straight from the pyramid tensor: the concat copy of reference modules.py:264 does not exist.  x2 = null: all of x.
+    const float* x2;
+    int x2_cs, nc16_a;
+    // round 5: caller-owned status words (null: none): PWC_STATUS_STREAMK_TIMEOUT is OR-ed into [0] when a bounded wait runs out.
+    // (The RANGE of the split is not watched here: tracking the largest operand in the split cost every launch 2-3 %
+    // (profiles/r05_timeline_range_tracking_cost.txt).  An operand beyond fp16's range makes NaN outputs, NaN survives every later
+    // layer, and the model's last launch -- pwc_resize_bilinear_status_f32 -- reports non-finite flows.)
+    unsigned* status;
 };
 
 constexpr unsigned H2_OOB = 0x7FFF0000u;
@@ -183,23 +191,38 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
 
     // ---- patch fetch of a stage (tile, c16): piece b = wave + 8 i holds records 16 b .. 16 b + 15 (record = patch pixel, 64 bytes
     // = 16 channels).  The lane offsets (and the image's buffer resource) change with the tile only.
-    unsigned p_voff[C::PPW];
-    __amdgpu_buffer_rsrc_t xrsrc;
+    // (the lane keeps the PIXEL index of each of its records -- H W, one past the image, for records outside it: any channel
+    // stride turns that into an out-of-range offset, which the fetch answers with zeros -- and forms the byte offset for the
+    // tensor a stage reads from when the piece is issued: one v_mad per piece instead of a second set of offsets)
+    unsigned p_pix[C::PPW];
+    const unsigned p_q16 = (unsigned)(lane & 3) * 16u;
+    __amdgpu_buffer_rsrc_t xrsrc, xrsrc2;
+    const bool two = a.x2 != nullptr;                      // uniform
     auto patch_tile = [&](const Tile& tl) {
         const int y0 = tl.by * C::TR, x0 = tl.bx * 32;      // output origin of the tile, in sub-lattice coordinates
         xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)tl.n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
+        xrsrc2 = __builtin_amdgcn_make_buffer_rsrc((void*)(two ? a.x2 + (size_t)tl.n * a.H * a.W * a.x2_cs : a.x), 0,
+                                                   two ? a.H * a.W * a.x2_cs * 4 : 0, 0x00020000);
 #pragma unroll
         for (int i = 0; i < C::PPW; ++i) {
             const int rec = (wave + 8 * i) * 16 + (lane >> 2);
             const int py = rec / C::PW, px = rec - py * C::PW;
             const int yy = tl.ry + dly * (y0 - 1 + py), xx = tl.rx + dlx * (x0 - XS + px);
             const bool ok = rec < C::NREC && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-            p_voff[i] = ok ? (unsigned)(((yy * a.W + xx) * a.x_cs + (lane & 3) * 4) * 4) : H2_OOB;
+            p_pix[i] = ok ? (unsigned)(yy * a.W + xx) : (unsigned)(a.H * a.W);
         }
     };
     auto issue_patch_piece = [&](int i, int c16) {
-        if (!(ABL & 1))
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(sm + C::S0 + (wave + 8 * i) * 1024), 16, (int)p_voff[i], c16 * 64, 0, 0);
+        if (ABL & 1) return;
+        // (locals: see issue_w_piece)
+        const bool second = c16 >= a.nc16_a;               // uniform
+        const int soff = (second ? c16 - a.nc16_a : c16) * 64;
+        const int voff = (int)(p_pix[i] * (unsigned)((second ? a.x2_cs : a.x_cs) * 4) + p_q16);
+        lptr_t dst = (lptr_t)(sm + C::S0 + (wave + 8 * i) * 1024);
+        // ONE fetch instruction on a selected resource (scalar selects), not one per branch: the compiler counts outstanding
+        // fetches along every path, and two paths made its waits conservative (+3-4 % on every launch)
+        const __amdgpu_buffer_rsrc_t rs = second ? xrsrc2 : xrsrc;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, soff, 0, 0);
     };
     // ---- weights of part (c16, r) for cout block cb: NCT cout tiles x 3 taps x 2 KB, contiguous in the packed image; pieces wave,
     // wave + 8, ...
@@ -345,16 +368,22 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
                     u32x4 p4[4];
                     // bounded (~1 s): a sum that never arrives (it cannot, short of a fault) leaves the sentinel -- a NaN -- in the
                     // output instead of hanging the device
+                    bool missing = false;
                     for (int tries = 0; tries < (1 << 20); ++tries) {
-                        bool missing = false;
+                        missing = false;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) p4[q] = __builtin_amdgcn_raw_buffer_load_b128(prs, lane * 16, po + q * 1024, H2_SC1);
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                             missing = missing || p4[q][0] == H2_EMPTY || p4[q][1] == H2_EMPTY || p4[q][2] == H2_EMPTY || p4[q][3] == H2_EMPTY;
-                        if (!__builtin_amdgcn_ballot_w64(missing)) break;
+                        missing = __builtin_amdgcn_ballot_w64(missing) != 0;
+                        if (!missing) break;
                         __builtin_amdgcn_s_sleep(16);
                     }
+                    // the bounded wait ran out: the sentinel (a NaN) goes into the output, and -- round 5 -- the caller is TOLD: a late
+                    // publisher would leave its sums in the slot for the next launch to mistake for its own; the host refills
+                    // the workspace and repeats the forward when it sees the bit
+                    if (missing && a.status && lane == 0) atomicOr(a.status, (unsigned)PWC_STATUS_STREAMK_TIMEOUT);
                     const u32x4 empty = {H2_EMPTY, H2_EMPTY, H2_EMPTY, H2_EMPTY};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -725,11 +754,18 @@ static int h2_launch(H2Args& a, int hs, int ws, float* workspace, size_t workspa
 template <int ABL = 0>
 static int h2_run(const float* x, int x_cs, const float* packed_w, const float* bias, float* y, int y_cs, int N, int H, int W,
                   int Cin_phys, int Cout, int dilation, int apply_act, float slope, pwc_stream_t stream, int variant = 0,
-                  float* workspace = nullptr, size_t workspace_floats = 0, int stride = 1) {
+                  float* workspace = nullptr, size_t workspace_floats = 0, int stride = 1, const float* x2 = nullptr, int x2_cs = 0,
+                  int Cin_a_phys = 0, uint32_t* status = nullptr) {
     if (!x || !packed_w || !bias || !y) return PWC_EINVAL;
+    if (x2) {
+        if (Cin_a_phys <= 0 || Cin_a_phys >= Cin_phys || (Cin_a_phys % 16) || x_cs < Cin_a_phys || x2_cs < Cin_phys - Cin_a_phys) return PWC_EINVAL;
+        if ((x2_cs & 3) || !pwc_aligned16(x2)) return PWC_EALIGN;
+        if ((long)H * W * x2_cs * 4 >= (long)H2_OOB) return PWC_ERANGE;
+    }
+    if (reinterpret_cast<uintptr_t>(status) & 7u) return PWC_EALIGN;
     if (N <= 0 || H <= 0 || W <= 0 || Cin_phys <= 0 || Cout <= 0 || dilation < 1 || (stride != 1 && stride != 2)) return PWC_EINVAL;
     if (Cin_phys % 16 || Cout % 32 || Cout > H2_MAX_COUT || (stride == 2 && dilation != 1)) return PWC_EUNSUPPORTED;
-    if (x_cs < Cin_phys || y_cs < Cout) return PWC_EINVAL;
+    if ((!x2 && x_cs < Cin_phys) || y_cs < Cout) return PWC_EINVAL;
     if ((x_cs & 3) || (y_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(y) || !pwc_aligned16(packed_w) || !pwc_aligned16(bias) ||
         !pwc_aligned16(workspace))
         return PWC_EALIGN;
@@ -740,6 +776,7 @@ static int h2_run(const float* x, int x_cs, const float* packed_w, const float* 
     const H2Geo geo = h2_geometry(H, W, dilation, Cout);
     a.dil_y = geo.dy; a.dil_x = geo.dx;
     a.dbg = h2_debug_counters;
+    a.x2 = x2; a.x2_cs = x2_cs; a.nc16_a = x2 ? Cin_a_phys >> 4 : Cin_phys >> 4; a.status = status;
     a.stride = stride; a.Ho = H; a.Wo = W; a.off_y = a.off_x = 0;
     if (stride == 2) {
         int before = 0;
@@ -784,6 +821,16 @@ extern "C" int pwc_conv3x3_h2_f32(const float* x, int x_cs, const float* packed_
                                   int apply_act, float slope, float* workspace, size_t workspace_floats, pwc_stream_t stream) {
     return h2_run<0>(x, x_cs, packed_w, bias, y, y_cs, N, H, W, Cin_phys, Cout, dilation, apply_act, slope, stream, 0,
                      workspace, workspace_floats);
+}
+
+// Round 5: the same launch with (a) the input given as two tensors -- the first Cin_a_phys physical channels from x, the rest
+// from x2 (null: everything from x) -- and (b) a caller-owned status word pair (null: none), see include/pwc_hip.h.
+extern "C" int pwc_conv3x3_h2_ex_f32(const float* x, int x_cs, int Cin_a_phys, const float* x2, int x2_cs,
+                                     const float* packed_w, const float* bias, float* y, int y_cs, int N, int H, int W,
+                                     int Cin_phys, int Cout, int dilation, int apply_act, float slope, float* workspace,
+                                     size_t workspace_floats, uint32_t* status, pwc_stream_t stream) {
+    return h2_run<0>(x, x_cs, packed_w, bias, y, y_cs, N, H, W, Cin_phys, Cout, dilation, apply_act, slope, stream, 0,
+                     workspace, workspace_floats, 1, x2, x2_cs, Cin_a_phys, status);
 }
 
 // Stride 2 ('SAME', dilation 1: the extractor's down-sampling layers, reference modules.py:57-60): the launch of the stride-1

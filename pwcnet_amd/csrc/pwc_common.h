@@ -7,6 +7,9 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 pwc_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pwc_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 pwc_f16x2 __attribute__((ext_vector_type(2)));
 
 #define PWC_WAVE 64
 
@@ -89,4 +92,31 @@ __device__ __forceinline__ int pwc_xcd_remap(int b, int nblocks) {
     const int xcd = b & 7, k = b >> 3;
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + k;
+}
+
+// ---- the two-term fp16 operand split of the F16-matrix-pipe kernels (conv3x3_h2.hip, conv3x3_c16pair.hip,
+// cost_volume_mfma.hip):  x = h + 2^-11 m',  h = fp16(x),  m' = fp16((x - h) 2^11)  (x - h is exact in fp32; the scaling keeps
+// m' out of fp16's subnormals).  Two values in four vector instructions: v_cvt_pk_f16_f32, v_pk_mul_f32 (x 2^11 of both) and
+// one mixed-precision FMA per value that reads the fp16 half in place and writes its half of the pair -- the same values as
+//   h = (_Float16)x;  m' = (_Float16)fmaf((float)h, -2048.f, x * 2048.f);
+// which the compiler turns into seven.  |x| >= 65504 gives h = inf and a NaN m': the range condition of these kernels.
+__device__ __forceinline__ void pwc_split2(const float x0, const float x1, unsigned& h_pair, unsigned& m_pair) {
+    const f32x2 xs = {x0, x1};
+    const pwc_f16x2 h2 = __builtin_convertvector(xs, pwc_f16x2);
+    const f32x2 xm = xs * 2048.f;
+    const unsigned hp = __builtin_bit_cast(unsigned, h2);
+    const float neg = -2048.f;
+    unsigned mp;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(mp) : "v"(hp), "s"(neg), "v"(xm[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(mp) : "v"(hp), "s"(neg), "v"(xm[1]));
+    h_pair = hp; m_pair = mp;
+}
+__device__ __forceinline__ void pwc_split4(const f32x4 x, pwc_f16x4& h, pwc_f16x4& m) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 hp, mp;
+    unsigned a, b;
+    pwc_split2(x[0], x[1], a, b); hp[0] = a; mp[0] = b;
+    pwc_split2(x[2], x[3], a, b); hp[1] = a; mp[1] = b;
+    h = __builtin_bit_cast(pwc_f16x4, hp);
+    m = __builtin_bit_cast(pwc_f16x4, mp);
 }

@@ -130,13 +130,14 @@ struct ResizeArgs {
     int H, W, C, OH, OW;
     float sy, sx, mul;
     int rows;     // N * OH
+    unsigned* status;   // null, or the status words (PWC_STATUS_NONFINITE)
 };
 
 // VW floats per thread (4, 2 or 1).  grid.y walks the output rows (n, oy) -- their decomposition is
 // wave-uniform -- and grid.x the (ox, channel group) elements of a row with 32-bit math.  (The first
 // version decomposed a flat 64-bit index with four 64-bit divisions per element and was
 // division-bound: 41 us for the 29 MB two-channel x4 upsampling of the final flows.)
-template <int VW>
+template <int VW, bool STATUS = false>
 __global__ __launch_bounds__(256) void resize_kernel(const ResizeArgs a) {
     typedef float vec_t __attribute__((ext_vector_type(VW)));
     const unsigned CV = (unsigned)a.C / VW;
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const ResizeArgs a) {
     const int x0 = (int)floorf(fx);
     const int x1 = min(x0 + 1, a.W - 1);
     const float xl = fx - (float)x0;
+    bool bad = false;
     for (int row = blockIdx.y; row < a.rows; row += gridDim.y) {
         const int n = row / a.OH, oy = row - n * a.OH;
         const float fy = pwc_mul_rounded((float)oy, a.sy);
@@ -162,13 +164,22 @@ __global__ __launch_bounds__(256) void resize_kernel(const ResizeArgs a) {
         const vec_t br = *reinterpret_cast<const vec_t*>(r1 + (size_t)x1 * a.x_cs);
         const vec_t top = tl + (tr - tl) * xl;
         const vec_t bot = bl + (br - bl) * xl;
-        *reinterpret_cast<vec_t*>(a.y + ((size_t)row * a.OW + ox) * a.y_cs + cv * VW) = (top + (bot - top) * yl) * a.mul;
+        const vec_t o = (top + (bot - top) * yl) * a.mul;
+        *reinterpret_cast<vec_t*>(a.y + ((size_t)row * a.OW + ox) * a.y_cs + cv * VW) = o;
+        if (STATUS) {
+            // exponent bits all ones = inf or NaN.  (Not `o - o != 0`: the compiler contracts the subtraction with the multiply
+            // that made o into an fma and gets the product's rounding error -- non-zero for finite values.)
+#pragma unroll
+            for (int k = 0; k < VW; ++k) bad = bad || (__builtin_bit_cast(unsigned, (float)o[k]) & 0x7F800000u) == 0x7F800000u;
+        }
     }
+    if (STATUS && bad) atomicOr(a.status, (unsigned)PWC_STATUS_NONFINITE);
 }
 
-extern "C" int pwc_resize_bilinear_f32(const float* x, int x_cs, float* y, int y_cs, int N, int H, int W,
-                                       int C, int OH, int OW, float mul, pwc_stream_t stream) {
+static int resize_run(const float* x, int x_cs, float* y, int y_cs, int N, int H, int W,
+                      int C, int OH, int OW, float mul, uint32_t* status, pwc_stream_t stream) {
     if (!x || !y) return PWC_EINVAL;
+    if (reinterpret_cast<uintptr_t>(status) & 7u) return PWC_EALIGN;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return PWC_EINVAL;
     if (x_cs < C || y_cs < C) return PWC_EINVAL;
     if ((long)N * OH >= (1L << 31) || (long)OW * C >= (1L << 31)) return PWC_ERANGE;
@@ -177,6 +188,7 @@ extern "C" int pwc_resize_bilinear_f32(const float* x, int x_cs, float* y, int y
     a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW;
     a.sy = (float)H / (float)OH; a.sx = (float)W / (float)OW; a.mul = mul;
     a.rows = N * OH;
+    a.status = status;
     const bool vec4 = (C % 4 == 0) && (x_cs % 4 == 0) && (y_cs % 4 == 0) && pwc_aligned16(x) && pwc_aligned16(y);
     const bool vec2 = (C % 2 == 0) && (x_cs % 2 == 0) && (y_cs % 2 == 0) && ((uintptr_t)x % 8 == 0) &&
                       ((uintptr_t)y % 8 == 0);
@@ -184,6 +196,15 @@ extern "C" int pwc_resize_bilinear_f32(const float* x, int x_cs, float* y, int y
     const unsigned gx = (unsigned)(((long)OW * (C / vw) + 255) / 256);
     const unsigned gy = (unsigned)(a.rows < 65535 ? a.rows : 65535);
     const dim3 grid(gx, gy);
+    if (status) {
+        if (vw == 4)
+            hipLaunchKernelGGL((resize_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else if (vw == 2)
+            hipLaunchKernelGGL((resize_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL((resize_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        return pwc_launch_status();
+    }
     if (vw == 4)
         hipLaunchKernelGGL(resize_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else if (vw == 2)
@@ -192,6 +213,40 @@ extern "C" int pwc_resize_bilinear_f32(const float* x, int x_cs, float* y, int y
         hipLaunchKernelGGL(resize_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
     return pwc_launch_status();
 }
+
+extern "C" int pwc_resize_bilinear_f32(const float* x, int x_cs, float* y, int y_cs, int N, int H, int W,
+                                       int C, int OH, int OW, float mul, pwc_stream_t stream) {
+    return resize_run(x, x_cs, y, y_cs, N, H, W, C, OH, OW, mul, nullptr, stream);
+}
+
+extern "C" int pwc_resize_bilinear_status_f32(const float* x, int x_cs, float* y, int y_cs, int N, int H, int W,
+                                              int C, int OH, int OW, float mul, uint32_t* status, pwc_stream_t stream) {
+    return resize_run(x, x_cs, y, y_cs, N, H, W, C, OH, OW, mul, status, stream);
+}
+
+// status[1] = max(status[1], bits of max |x|) -- see include/pwc_hip.h
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int x_cs, long npix, int C, unsigned* status) {
+    float m = 0.f;
+    const long total = npix * C;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        const long p = i / C;
+        const int c = (int)(i - p * C);
+        m = fmaxf(m, fabsf(x[p * x_cs + c]));             // (fmaxf drops a NaN operand)
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(status + 1, __builtin_bit_cast(unsigned, m));
+}
+
+extern "C" int pwc_absmax_f32(const float* x, int x_cs, long npix, int C, uint32_t* status, pwc_stream_t stream) {
+    if (!x || !status || npix <= 0 || C <= 0 || x_cs < C) return PWC_EINVAL;
+    if (reinterpret_cast<uintptr_t>(status) & 7u) return PWC_EALIGN;
+    long blocks = (npix * C + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_cs, npix, C, status);
+    return pwc_launch_status();
+}
+
 
 // Two resizes of the same geometry in one launch: the 2-channel flows and the feature map that
 // the estimator hands to the next pyramid level (modules.py:283-284) -- at the coarse levels each

@@ -17,6 +17,7 @@ TF graph.  Inside ``__call__`` the modules' zero-copy ``_run`` forms are compose
     warp + cost-volume launches of rounds 1-2.
 """
 import collections
+import warnings
 
 import torch
 
@@ -92,7 +93,8 @@ def _pick_side_streams(dev, main, count):
 class PWCDCNet(object):
     def __init__(self, num_levels=6, search_range=4, warp_type="bilinear", use_dc=False,
                  output_level=4, name="pwcdcnet", seed=0, fuse_warp=False, use_plans=True, winograd=True,
-                 coarse_cv=True, persistent_outputs=False, max_plans=4, streams=None, concat_cv=True, winograd4=True, f16x2=True):
+                 coarse_cv=True, persistent_outputs=False, max_plans=4, streams=None, concat_cv=True, winograd4=True, f16x2=True,
+                 range_check="lazy", track_max=False):
         self.num_levels = num_levels
         self.s_range = search_range
         self.warp_type = warp_type
@@ -113,10 +115,36 @@ class PWCDCNet(object):
         # Upscale factors from deep -> shallow level (reference model.py:93)
         self.scales = list(SCALES)
 
-        for mod in [self.fp_extractor, self.context] + self.of_estimators:
+        self._mods = [self.fp_extractor, self.context, self.cv_layer] + self.of_estimators
+        for mod in self._mods:
             mod.winograd = bool(winograd)
             mod.winograd4 = bool(winograd4)
             mod.f16x2 = bool(f16x2)
+            mod.status = None
+            mod.track_max = False
+        # F16-pipe kernels (f16x2) compute with operands split into fp16 pairs: exact to 22 bits, but only below 65504 in
+        # magnitude -- beyond it they produce NaN, NaN survives every later layer, and the forward's last launch (the x4
+        # upsampling of model.py:127) sets PWC_STATUS_NONFINITE in `status` (two uint32 in device memory; include/pwc_hip.h)
+        # when it writes a value that is not finite.  The reference is plain fp32 (nothing bounds its activations; test.py:31
+        # only divides the frames by 255), so a flagged forward is REPEATED on the fp32 kernels into the very tensors it
+        # returned, with a warning, and the model stays on fp32 from then on (frames that are not finite themselves take the
+        # same path once and come out as non-finite as the reference's would):
+        #   range_check="lazy" (default): the words are copied to the host behind every forward (8 bytes, asynchronous) and
+        #       looked at when the next forward is called, or by status() / synchronize() -- no host synchronisation is added
+        #       to a forward, and a caller who reads results after torch.cuda.synchronize() without calling status() would see
+        #       the NaN of a flagged forward (never a wrong number);
+        #   range_check="sync": every call ends with status(): results are right when it returns (the CLIs use this);
+        #   range_check="off": no status words at all.
+        # track_max: every operand of an F16-pipe kernel is also scanned for its largest magnitude (pwc_absmax_f32, one small
+        # launch each: slower) -> status()["max_abs"] -- for the first person with trained weights to see the margin in one run.
+        assert range_check in ("lazy", "sync", "off")
+        self.range_check = range_check
+        self.track_max = bool(track_max)
+        self.two_operand = True             # features_0 read from the pyramid tensor where the first conv allows (_est_layout)
+        self.f16x2 = bool(f16x2)
+        self._status = {}                   # device -> (device words, pinned host copy)
+        self._pending = None                # the last forward's record: (event, host words, inputs, outputs, device)
+        self.fallback_reason = None         # set when the model left the F16-pipe kernels
         _lib.lib()  # fail now, loudly, if the HIP library is missing
         self.store = VariableStore(seed=seed)
         # launch plans (one per input shape, device, stream): the forward is recorded once and
@@ -196,15 +224,95 @@ class PWCDCNet(object):
         """(flows_final, flows_pyramid[, pyramid_0]) as reference model.py:95-134.  The returned
         tensors are new on every call unless the model was built with persistent_outputs=True
         (then they are the launch plan's own tensors, overwritten by the next call of that shape)."""
+        checking = (self.range_check != "off" and self.f16x2 and _m._RECORDER is None and isinstance(images_0, torch.Tensor)
+                    and images_0.is_cuda and not torch.cuda.is_current_stream_capturing())
+        if checking:
+            self._examine(wait=False)                       # the previous forward's words, if they have arrived
+            self._attach_status(images_0.device)
+        out = self._dispatch(images_0, images_1, with_features)
+        if checking and self.f16x2:
+            self._record(images_0, images_1, out)
+            if self.range_check == "sync":
+                self._examine(wait=True)
+        return out
+
+    def _dispatch(self, images_0, images_1, with_features, into=None):
         k = self.effective_streams(getattr(images_0, "shape", (0, 0, 0, 0)))
         if k > 1:
             self.max_plans = max(self.max_plans, k + 1)     # a plan per sub-batch stream + the whole-batch one
         if (k > 1 and self.use_plans and not self.persistent_outputs and not with_features and _m._RECORDER is None
                 and not torch.cuda.is_current_stream_capturing()):
-            out = self._call_on_side_streams(images_0, images_1, k)
+            out = self._call_on_side_streams(images_0, images_1, k, into=into)
             if out is not None:
                 return out
-        return self._call_one(images_0, images_1, with_features)
+        return self._call_one(images_0, images_1, with_features, into=into)
+
+    # ------------------------------------------------------------------ status words of the F16-pipe kernels
+    def _attach_status(self, dev):
+        key = str(dev)
+        if key not in self._status:
+            words = torch.zeros(2, dtype=torch.int32, device=dev)
+            host = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._status[key] = (words, host)
+        words = self._status[key][0]
+        for mod in self._mods:
+            mod.status = words
+            mod.track_max = self.track_max
+
+    def _record(self, images_0, images_1, out):
+        words, host = self._status[str(images_0.device)]
+        host.copy_(words, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending = (ev, host, images_0, images_1, out, images_0.device)
+
+    def _examine(self, wait):
+        """Look at the last forward's status words (wait=False: only if their copy has arrived).  A range violation or a
+        stream-K timeout: warn, leave the F16-pipe kernels for good, and repeat that forward on the fp32 kernels into the
+        tensors it returned (stream-ordered on the current stream)."""
+        pend = self._pending
+        if pend is None:
+            return 0
+        ev, host, im0, im1, out, dev = pend
+        if not wait and not ev.query():
+            return 0
+        ev.synchronize()
+        self._pending = None
+        flags = int(host[0].item())
+        if not flags:
+            return 0
+        why = []
+        if flags & _lib.STATUS_NONFINITE:
+            why.append("the flows are not finite: an activation left fp16's range (|x| >= 65504) in a kernel that splits its "
+                       "operands into fp16 pairs (or the frames are not finite)")
+        if flags & _lib.STATUS_STREAMK_TIMEOUT:
+            why.append("a stream-K workgroup gave up waiting for a partial sum")
+            _m.h2_workspaces_refill()
+        self.fallback_reason = "; ".join(why)
+        warnings.warn(f"PWCDCNet: {self.fallback_reason}: the affected forward is repeated on the fp32 kernels and the model "
+                      "stays on them (f16x2=False) from now on", RuntimeWarning, stacklevel=3)
+        self._set_f16x2(False)
+        self._status[str(dev)][0][0] = 0
+        with torch.cuda.device(dev):
+            self._dispatch(im0, im1, len(out) == 3, into=(out[0], list(out[1])))
+        return flags
+
+    def _set_f16x2(self, on):
+        self.f16x2 = bool(on)
+        for mod in self._mods:
+            mod.f16x2 = bool(on)
+        self._plans.clear()                                  # recorded launches name the kernels
+        self._eager_buffers.clear()
+        self._warm.clear()
+
+    def status(self):
+        """Synchronise with the last forward's status words and act on them (see __init__).  Returns
+        {"flags", "f16x2", "fallback_reason"[, "max_abs"]}."""
+        flags = self._examine(wait=True)
+        rep = {"flags": flags, "f16x2": self.f16x2, "fallback_reason": self.fallback_reason}
+        if self.track_max:
+            rep["max_abs"] = max([float(w[1:2].view(torch.float32).item()) for w, _ in self._status.values()], default=0.0)
+        return rep
 
     def effective_streams(self, shape):
         """Number of sub-batches a batch of this (N, H, W, 3) shape is run as: `streams` if given (and dividing N), else
@@ -220,7 +328,7 @@ class PWCDCNet(object):
             k = 1
         return k
 
-    def _call_on_side_streams(self, images_0, images_1, k):
+    def _call_on_side_streams(self, images_0, images_1, k, into=None):
         _, images_0 = as_view(images_0, "images_0")
         _, images_1 = as_view(images_1, "images_1")
         dev = images_0.device
@@ -236,9 +344,12 @@ class PWCDCNet(object):
         streams = self._side_streams[skey]
         if streams is None or len(streams) != k - 1:
             return None                                      # no vetted side stream: the caller runs single-stream
-        final = torch.empty((N, H, W, 2), dtype=torch.float32, device=dev)
-        pyr = [torch.empty((N, H >> (self.num_levels - l), W >> (self.num_levels - l), 2), dtype=torch.float32, device=dev)
-               for l in range(self.output_level + 1)]
+        if into is not None:
+            final, pyr = into
+        else:
+            final = torch.empty((N, H, W, 2), dtype=torch.float32, device=dev)
+            pyr = [torch.empty((N, H >> (self.num_levels - l), W >> (self.num_levels - l), 2), dtype=torch.float32, device=dev)
+                   for l in range(self.output_level + 1)]
         # First call of a (sub-batch shape, weight version): sub-batch 0 runs FIRST and alone, on the caller's stream.  It packs
         # every layer's weights there (the per-module caches are filled by whoever launches a layer first, with no event
         # between the pack kernel and a consumer on another stream) and owns the packed tensors' allocator blocks; the
@@ -375,15 +486,18 @@ class PWCDCNet(object):
                 is_out = (l == self.output_level)
 
                 if nxt is None:
-                    lay = est._layout((2 * self.s_range + 1) ** 2, C, l > 0, fu_map)
+                    lay = self._est_layout(l, N, h, w, C, l > 0, fu_map)
                     E_t, E_off, cx = self._level_buffer(l, lay, N, h, w, dev, is_out)
                 else:
                     E_t, E_off, lay, cx = nxt
                 E = View(E_t.data_ptr() + 4 * E_off, E_t.shape[3], N, h, w, lay.n_phys)
 
-                # Warping + cost volume (model.py:105-112)
+                # Warping + cost volume (model.py:105-112).  features_0 either has its segment of the estimator buffer (the
+                # correlation launch copies it there) or stays where it is: the first conv then reads it from the pyramid
+                # tensor (_est_layout)
+                f0_ext = f0 if "f0" in lay.external else None
                 cv_out = sub_view(E, lay.offset("cv"), (2 * self.s_range + 1) ** 2)
-                f0_dst = sub_view(E, lay.offset("f0"), C)
+                f0_dst = sub_view(E, lay.offset("f0"), C) if f0_ext is None else None
                 flow_v = sub_view(E, lay.offset("flow"), 2) if l > 0 else None
                 self._corr_level(l, f0, f1, flow_v, cv_out, f0_dst, E, dev)
 
@@ -397,12 +511,12 @@ class PWCDCNet(object):
                         est._run(E, lay, flows_v)
                         feat_v, nfu = View(E.ptr, E.cs, N, h, w, lay.n_phys), list(lay.phys2log)
                     else:
-                        feat_v, _feat_t = est._run(E, lay, flows_v)
+                        feat_v, _feat_t = est._run(E, lay, flows_v, f0_ext=f0_ext)
                         nfu = list(range(feat_v.C))
                     Fn = stacked[l + 1]
                     _, h2, w2, C2 = Fn.shape
                     assert (h2, w2) == (2 * h, 2 * w), "pyramid levels must double in size"
-                    nlay = self.of_estimators[l + 1]._layout((2 * self.s_range + 1) ** 2, C2, True, nfu)
+                    nlay = self._est_layout(l + 1, N, h2, w2, C2, True, nfu)
                     nE_t, nE_off, ncx = self._level_buffer(l + 1, nlay, N, h2, w2, dev,
                                                            l + 1 == self.output_level)
                     nE = View(nE_t.data_ptr() + 4 * nE_off, nE_t.shape[3], N, h2, w2, nlay.n_phys)
@@ -424,22 +538,35 @@ class PWCDCNet(object):
                     est._run(E, lay, ctx_flow)
                 else:
                     est._run(E, lay, ctx_flow,
-                             feat_out=sub_view(CX, cx_lay.offset("features"), est.filters[-1]))
+                             feat_out=sub_view(CX, cx_lay.offset("features"), est.filters[-1]), f0_ext=f0_ext)
                 self.context._run(CX, cx_lay, flows_v)
                 flows_pyramid.append(flows_t)
                 upscale = 2 ** (self.num_levels - self.output_level)
                 flows_final = torch.empty((N, h * upscale, w * upscale, 2), dtype=torch.float32, device=dev)
                 _keep(flows_final)
-                _resize(flows_v, View(flows_final.data_ptr(), 2, N, h * upscale, w * upscale, 2), mul=20.0)
+                # (the last launch also reports non-finite flows: see __init__, range_check)
+                _resize(flows_v, View(flows_final.data_ptr(), 2, N, h * upscale, w * upscale, 2), mul=20.0,
+                        status=self.context.status)
                 if with_features:
                     return flows_final, flows_pyramid, pyramid_0
                 else:
                     return flows_final, flows_pyramid
 
+    def _est_layout(self, l, N, h, w, C, has_flow, fu_map):
+        """Layout of the estimator buffer of level l.  Where the first conv of the (non-DC) estimator runs on the F16-pipe
+        kernel, features_0 is NOT part of the buffer (round 5): that kernel takes the channels of a second tensor behind the
+        buffer's, so `tf.concat([cv, features_0, ...])` (reference modules.py:261-264) moves no byte of features_0 --
+        29 MB written and read again at level 4 of a batch of 8."""
+        est = self.of_estimators[l]
+        cvc = (2 * self.s_range + 1) ** 2
+        ext = self.two_operand and est.two_operand_ok(N, h, w, cvc, C, has_flow, fu_map)
+        return est._layout(cvc, C, has_flow, fu_map, f0_external=ext)
+
     def _corr_level(self, l, f0, f1, flow_v, cv_out, f0_dst, E, dev):
         """Warping + cost volume of pyramid level l (reference model.py:105-112) plus the
         features_0 part of the estimator input's concat (modules.py:264): f1 is warped by
-        flow_v * scales[l] (l > 0) and correlated with f0 into cv_out; f0 is copied to f0_dst."""
+        flow_v * scales[l] (l > 0) and correlated with f0 into cv_out; f0 is copied to f0_dst (None: the estimator reads
+        features_0 from the pyramid tensor, nothing to copy)."""
         N, h, w, C = f0.N, f0.H, f0.W, f0.C
         if self.coarse_cv and self.cv_layer.coarse_ok(f0) and (l == 0 or self.warp_type == "bilinear"):
             # coarse levels: warp + cost volume + the f0 part of the concat in ONE launch
@@ -454,7 +581,7 @@ class PWCDCNet(object):
             self.cv_layer._run(f0, f1, cv_out, flow=flow_v, flow_scale=self.scales[l] if l > 0 else 1.0,
                                f0_copy=f0_dst, concat=True, out_pad_writable=True)
             return
-        copied = False
+        copied = f0_dst is None
         if l == 0:
             self.cv_layer._run(f0, f1, cv_out)
         elif self.warp_type == "bilinear" and self.fuse_warp:
@@ -464,11 +591,11 @@ class PWCDCNet(object):
             _keep(f1w_t)
             f1w = View(f1w_t.data_ptr(), C, N, h, w, C)
             # the f0 part of the concat rides in the warp launch
-            fuse_copy = C % 4 == 0 and E.cs % 4 == 0
+            fuse_copy = C % 4 == 0 and E.cs % 4 == 0 and f0_dst is not None
             self.warp_layer._run(f1, flow_v, f1w, flow_scale=self.scales[l],
                                  copy=(f0, f0_dst) if fuse_copy else None)
             self.cv_layer._run(f0, f1w, cv_out)
-            copied = fuse_copy
+            copied = copied or fuse_copy
         if not copied:
             _copy_channels(f0, f0_dst, C)
 

@@ -249,6 +249,7 @@ class _ConvRunner:
             cache[key] = packed
         _keep(packed, y_t)
         M = x.N * x.H * x.W
+        _track_max(self.owner, x)
         _launch(L.pwc_conv3x3_c16pair_f32,
                 (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(b1.value.data_ptr()), _p(b2.value.data_ptr()), _p(y.ptr), y.cs,
                  x.N, x.H, x.W, float(slope), s),
@@ -294,6 +295,8 @@ class _ConvRunner:
         va = image_views[0]
         vb = image_views[1] if len(image_views) == 2 else None
         M = n_tot * Ho * Wo
+        for v in image_views:
+            _track_max(self.owner, v)
         _launch(L.pwc_conv3x3_c3c16pair_f32,
                 (_p(va.ptr), va.N, _p(vb.ptr) if vb is not None else None, vb.N if vb is not None else 0, _p(packed.data_ptr()),
                  _p(bs[0].value.data_ptr()), _p(bs[1].value.data_ptr()), _p(bs[2].value.data_ptr()), _p(y.ptr), y.cs,
@@ -305,9 +308,11 @@ class _ConvRunner:
         return y, y_t
 
     def conv(self, x, cout, y=None, stride=1, dilation=1, slope=0.1, cin_map=None,
-             cin_logical=None, residual=None, tile=-1, split=0):
+             cin_logical=None, residual=None, tile=-1, split=0, x2=None):
         """x: View over the PHYSICAL input channels.  cin_map: physical->logical map (or
-        None = identity).  Returns (View y, tensor or None)."""
+        None = identity).  x2 (round 5): a second View over the same pixels whose channels follow x's in the physical order
+        (cin_map covers both) -- only the F16-pipe kernel takes it: the caller asks h2_two_operand_ok first.
+        Returns (View y, tensor or None)."""
         name = self.scope + "/conv2d" + ("" if self.k == 0 else f"_{self.k}")
         self.k += 1
         cin = x.C if cin_logical is None else cin_logical
@@ -323,6 +328,7 @@ class _ConvRunner:
         s = _lib.current_stream()
         act = 0 if slope is None else 1
         sl = 0.0 if slope is None else float(slope)
+        c_phys = x.C + (x2.C if x2 is not None else 0)
         use_mfma = (cout % 16 == 0 and x.C % 16 == 0 and x.cs % 4 == 0 and x.ptr % 16 == 0
                     and residual is None)
         cache = self.owner._cache
@@ -332,37 +338,46 @@ class _ConvRunner:
                      and L.pwc_conv3x3_wino4_supported(x.N, x.H, x.W, x.C, cout, dilation))
         use_h2 = (use_mfma and getattr(self.owner, "f16x2", True) and stride == 1 and tile < 0 and split == 0
                   and cout % 32 == 0 and y.cs % 4 == 0 and y.ptr % 16 == 0
-                  and L.pwc_conv3x3_h2_supported(x.N, x.H, x.W, x.C, cout, dilation))
+                  and L.pwc_conv3x3_h2_supported(x.N, x.H, x.W, c_phys, cout, dilation))
+        if x2 is not None and not use_h2:
+            raise _lib.PwcHipError(f"{name}: a two-operand input needs the F16-pipe kernel (h2_two_operand_ok)")
         use_h2s2 = (use_mfma and getattr(self.owner, "f16x2", True) and stride == 2 and dilation == 1 and tile < 0 and split == 0
                     and cout % 32 == 0 and y.cs % 4 == 0 and y.ptr % 16 == 0
                     and L.pwc_conv3x3_h2_stride2_supported(x.N, x.H, x.W, x.C, cout))
         if use_h2 or use_h2s2:
             # direct convolution on the F16 matrix pipe, fp32 operands as two-term fp16 splits (conv3x3_h2.hip); stride 2 = the
             # stride-1 launch that stores every second sum
-            key = (name, "h2", x.C, None if cin_map is None else cin_map.tobytes(), self.store.version)
+            key = (name, "h2", c_phys, None if cin_map is None else cin_map.tobytes(), self.store.version)
             packed = cache.get(key)
             if packed is None:
-                nfl = L.pwc_conv3x3_h2_packed_floats(x.C, cout)
+                nfl = L.pwc_conv3x3_h2_packed_floats(c_phys, cout)
                 packed = torch.empty((nfl,), dtype=torch.float32, device=kern.value.device)
                 cm = None
                 if cin_map is not None:
-                    assert len(cin_map) == x.C
+                    assert len(cin_map) == c_phys
                     cm = torch.from_numpy(np.ascontiguousarray(cin_map, np.int32)).to(kern.value.device)
                 _lib.check(L.pwc_conv3x3_h2_pack_f32(_p(kern.value.data_ptr()),
                                                      _p(cm.data_ptr()) if cm is not None else None,
-                                                     cin, x.C, cout, _p(packed.data_ptr()), s), "conv3x3 h2 pack")
+                                                     cin, c_phys, cout, _p(packed.data_ptr()), s), "conv3x3 h2 pack")
                 cache[key] = packed
             _keep(packed, y_t)
             # more tiles than CUs: one workgroup per CU with an equal share of the (tile, stage) sequence (stream-K)
-            wsf = L.pwc_conv3x3_h2_workspace_floats(x.N, x.H, x.W, x.C, cout, dilation)
+            wsf = L.pwc_conv3x3_h2_workspace_floats(x.N, x.H, x.W, c_phys, cout, dilation)
             ws = _h2_workspace(kern.value.device, wsf) if wsf and getattr(self.owner, "f16x2_stream_k", True) else None
             if ws is not None:
                 _keep(ws)
             wsa = (_p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0)
+            status = getattr(self.owner, "status", None)      # the model's status words (stream-K timeout)
+            if status is not None:
+                _keep(status)
+            _track_max(self.owner, x)
+            if x2 is not None:
+                _track_max(self.owner, x2)
             if use_h2:
-                fn = L.pwc_conv3x3_h2_f32
-                args = (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
-                        x.N, x.H, x.W, x.C, cout, dilation, act, sl) + wsa + (s,)
+                fn = L.pwc_conv3x3_h2_ex_f32
+                args = (_p(x.ptr), x.cs, x.C if x2 is not None else 0, _p(x2.ptr) if x2 is not None else None,
+                        x2.cs if x2 is not None else 0, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
+                        x.N, x.H, x.W, c_phys, cout, dilation, act, sl) + wsa + (_p(status.data_ptr()) if status is not None else None, s)
             else:
                 fn = L.pwc_conv3x3_h2_stride2_f32
                 args = (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
@@ -370,7 +385,7 @@ class _ConvRunner:
             _launch(fn, args, f"conv3x3_h2 {name}", "conv3x3_h2_kernel",
                     2.0 * x.N * Ho * Wo * 9 * cin * cout, 4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout),
                     # executed: three fp16 products per multiply-add of the stride-1 launch, per physical input channel
-                    exec_flops=3.0 * 2.0 * x.N * x.H * x.W * 9 * x.C * cout)
+                    exec_flops=3.0 * 2.0 * x.N * x.H * x.W * 9 * c_phys * cout)
         elif use_wino4:
             # F(4x4,3x3): 36 multiplies per 4x4 outputs (the big full-resolution layers)
             key = (name, "wino4", x.C, None if cin_map is None else cin_map.tobytes(), self.store.version)
@@ -476,6 +491,15 @@ class _ConvRunner:
         return y, y_t
 
 
+def _track_max(owner, v):
+    """PWCDCNet(track_max=True): the largest |value| of an operand of an F16-pipe kernel goes into the model's status words
+    (pwc_absmax_f32) -- a debugging aid, one small launch per operand."""
+    if getattr(owner, "track_max", False) and getattr(owner, "status", None) is not None:
+        _keep(owner.status)
+        _launch(_lib.lib().pwc_absmax_f32, (_p(v.ptr), v.cs, v.N * v.H * v.W, v.C, _p(owner.status.data_ptr()), _lib.current_stream()),
+                "absmax", "absmax_kernel", 0.0, 4.0 * v.N * v.H * v.W * v.C)
+
+
 _WS = {}
 # tap-split scratch is only ever used for small outputs; cap what is kept around
 _WS_CAP_FLOATS = 64 << 20
@@ -493,18 +517,28 @@ def _workspace(device, want_floats):
     return ws
 
 
-_H2_WS = {}
+_H2_WS = collections.OrderedDict()
+_H2_WS_MAX = 8
 
 
 def _h2_workspace(device, want_floats):
     """Caller-owned workspace of pwc_conv3x3_h2_f32's stream-K form: one per device AND stream (launches that may run
     concurrently must not share it), every byte 0xFF when created (= "nothing published"; the kernel leaves it so)."""
-    key = (device, torch.cuda.current_stream().cuda_stream)
-    ws = _H2_WS.get(key)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _H2_WS.pop(key, None)
     if ws is None or ws.numel() < want_floats:
         ws = torch.full((int(want_floats),), -1, dtype=torch.int32, device=device).view(torch.float32)
-        _H2_WS[key] = ws
+    _H2_WS[key] = ws                                  # (most recently used last)
+    while len(_H2_WS) > _H2_WS_MAX:                   # callers that come with a new stream every time: up to 32 MB each
+        _H2_WS.pop(next(iter(_H2_WS)))
     return ws
+
+
+def h2_workspaces_refill():
+    """Every stream-K workspace back to "nothing published" (0xFF bytes) -- after a launch reported
+    PWC_STATUS_STREAMK_TIMEOUT a late publisher may have left sums in a slot."""
+    for ws in _H2_WS.values():
+        ws.view(torch.int32).fill_(-1)
 
 
 def _wino_pays(L, N, H, W, cout, dilation):
@@ -563,7 +597,15 @@ def _copy_channels(src, dst, C):
             "copy_channels", "copy_channels_kernel", 0.0, 8.0 * npix * C)
 
 
-def _resize(src, dst, mul=1.0):
+def _resize(src, dst, mul=1.0, status=None):
+    """status: the model's status words -- the launch then reports a non-finite output (pwc_resize_bilinear_status_f32)."""
+    if status is not None:
+        _keep(status)
+        _launch(_lib.lib().pwc_resize_bilinear_status_f32,
+                (_p(src.ptr), src.cs, _p(dst.ptr), dst.cs, src.N, src.H, src.W, src.C, dst.H, dst.W, float(mul),
+                 _p(status.data_ptr()), _lib.current_stream()),
+                "resize_bilinear", "resize_kernel", 0.0, 4.0 * src.C * src.N * (src.H * src.W + dst.H * dst.W))
+        return
     _launch(_lib.lib().pwc_resize_bilinear_f32,
             (_p(src.ptr), src.cs, _p(dst.ptr), dst.cs, src.N, src.H, src.W, src.C, dst.H, dst.W, float(mul),
              _lib.current_stream()),
@@ -722,14 +764,18 @@ class CostVolumeLayer(_Module):
         npix = f0.N * f0.H * f0.W
         flops = 2.0 * npix * D * f0.C
         if concat:
-            _launch(L.pwc_warp_cost_volume_concat_f32,
-                    (_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(flow.ptr) if flow is not None else None,
-                     flow.cs if flow is not None else 0, float(flow_scale), _p(out.ptr), out.cs,
-                     1 if out_pad_writable else 0,
-                     _p(f0_copy.ptr) if f0_copy is not None else None, f0_copy.cs if f0_copy is not None else 0,
-                     f0.N, f0.H, f0.W, f0.C, self.s_range, 0.1, s),
+            h2 = getattr(self, "f16x2", True)        # correlation on the F16 matrix pipe (two-term operand splits), round 5
+            if h2:
+                _track_max(self, f0)
+                _track_max(self, f1)
+            args = (_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(flow.ptr) if flow is not None else None,
+                    flow.cs if flow is not None else 0, float(flow_scale), _p(out.ptr), out.cs,
+                    1 if out_pad_writable else 0,
+                    _p(f0_copy.ptr) if f0_copy is not None else None, f0_copy.cs if f0_copy is not None else 0,
+                    f0.N, f0.H, f0.W, f0.C, self.s_range, 0.1)
+            _launch(L.pwc_warp_cost_volume_concat_h2_f32 if h2 else L.pwc_warp_cost_volume_concat_f32, args + (s,),
                     "warp_cost_volume_concat" if flow is not None else "cost_volume_concat",
-                    f"cost_volume_mfma_kernel<C{f0.C}{',warp' if flow is not None else ''}>", flops,
+                    f"cost_volume_mfma_kernel<C{f0.C}{',warp' if flow is not None else ''}{',f16x2' if h2 else ''}>", flops,
                     # (2C+81) or fused (2C+2+81) bytes per pixel; the f0 concat copy is not credited
                     4.0 * npix * (2 * f0.C + D + (2 if flow is not None else 0)))
             return
@@ -781,13 +827,18 @@ class OpticalFlowEstimator_custom(_Module):
         self.use_dc = use_dc
 
     # -- layout of the buffer holding the (growing) `features` tensor
-    def _layout(self, c_cv, c_f0, has_flow, fu_map):
+    def _layout(self, c_cv, c_f0, has_flow, fu_map, f0_external=False):
+        """f0_external (round 5, non-DC): features_0 keeps its place in the concat order (reference modules.py:261-264) but
+        stays in the pyramid tensor -- the first conv reads it through a second operand pointer (two_operand_ok)."""
         lay = ChannelLayout()
         if self.use_dc:
             for k in reversed(range(len(self.filters))):
                 lay.add(f"conv{k}", self.filters[k])
         lay.add("cv", c_cv)
-        if c_f0:
+        if c_f0 and f0_external:
+            assert not self.use_dc
+            lay.reserve("f0", c_f0)
+        elif c_f0:
             lay.add("f0", c_f0)
         if has_flow:
             lay.add("flow", 2)
@@ -795,10 +846,19 @@ class OpticalFlowEstimator_custom(_Module):
             lay.add("feat_up", len(fu_map), log_map=list(fu_map))
         return lay.finish(16)
 
-    def _run(self, buf, lay, flows_out, feat_out=None):
+    def two_operand_ok(self, N, h, w, c_cv, c_f0, has_flow, fu_map):
+        """True where the first conv of this (non-DC) estimator can read features_0 from the pyramid tensor: its launch goes
+        to the F16-pipe kernel (the one with a second operand pointer) at the channel count the two-operand layout gives."""
+        if self.use_dc or not getattr(self, "f16x2", True) or not c_f0 or c_f0 % 16:
+            return False
+        lay = self._layout(c_cv, c_f0, has_flow, fu_map, f0_external=True)
+        return bool(_lib.lib().pwc_conv3x3_h2_supported(N, h, w, lay.n_phys + c_f0, self.filters[0], 1))
+
+    def _run(self, buf, lay, flows_out, feat_out=None, f0_ext=None):
         """buf: View of the (N,h,w,lay.n_phys) buffer whose cv/f0/flow/feat_up segments
         are already filled (padding channels zero).  Writes `flows` (2 ch) to flows_out.
-        non-DC: the 32-channel features go to feat_out (a View) -- DC: they are `buf`."""
+        non-DC: the 32-channel features go to feat_out (a View) -- DC: they are `buf`.
+        f0_ext: the features_0 View where the layout keeps it external (_layout(f0_external=True))."""
         run = _ConvRunner(self)
         res = sub_view(buf, lay.offset("flow"), 2) if "flow" in lay.segments else None
         if self.use_dc:
@@ -818,11 +878,15 @@ class OpticalFlowEstimator_custom(_Module):
         x = View(buf.ptr, buf.cs, buf.N, buf.H, buf.W, lay.n_phys)
         keep = []
         cm, cl = lay.cin_map(0, 0), lay.n_logical
+        x2 = None
+        if "f0" in lay.external:
+            assert f0_ext is not None and f0_ext.C == lay.external["f0"][1]
+            cm, x2 = lay.cin_map_with("f0"), f0_ext
         for k, f in enumerate(self.filters):
             y = feat_out if (k == len(self.filters) - 1 and feat_out is not None) else None
-            x, t = run.conv(x, f, y=y, cin_map=cm, cin_logical=cl)
+            x, t = run.conv(x, f, y=y, cin_map=cm, cin_logical=cl, x2=x2)
             keep.append(t)
-            cm, cl = None, None
+            cm, cl, x2 = None, None, None
         run.conv(x, 2, y=flows_out, slope=None, residual=res)
         return x, keep[-1]
 

@@ -113,6 +113,7 @@ class ChannelLayout:
     def __init__(self):
         self.phys2log = []
         self.segments = {}      # name -> (phys offset, logical length)
+        self.external = {}      # name -> (first logical channel, length): segments that live in ANOTHER tensor
         self.n_logical = 0
 
     def add(self, name, length, log_map=None):
@@ -129,6 +130,19 @@ class ChannelLayout:
         pad = _round_up(len(self.phys2log), 4) - len(self.phys2log)
         self.phys2log += [-1] * pad
         return off
+
+    def reserve(self, name, length):
+        """A segment of the concat that stays in the tensor it comes from (round 5: the estimator's first conv reads
+        features_0 from the pyramid tensor through a second operand pointer): it takes its place in the LOGICAL order and no
+        physical channels of this buffer."""
+        self.external[name] = (self.n_logical, length)
+        self.n_logical += length
+
+    def cin_map_with(self, name):
+        """cin_map() of the whole buffer followed by the logical channels of the external segment `name`: the physical
+        channel order of a two-operand conv (buffer channels, then the other tensor's)."""
+        first, length = self.external[name]
+        return np.concatenate([self.cin_map(0, 0), np.arange(first, first + length, dtype=np.int32)])
 
     def finish(self, multiple=16):
         pad = _round_up(len(self.phys2log), multiple) - len(self.phys2log)

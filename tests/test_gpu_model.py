@@ -373,13 +373,20 @@ def test_bench_json_contract(pa):
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["unit"] == "pairs/s" and d["scaling"] == "weak" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["unit"] == "pairs/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"].startswith("f32") and "fp16x2" in d["dtype"]          # the arithmetic is named, not just the tensor type
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_algorithmic", "frac_executed"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9
+    assert r["frac"] == r["frac_algorithmic"] and abs(r["achieved"] - r["algorithmic_tflops"]) <= 1e-9
+    for k in ("timed_region_ms", "per_rank_ms_per_step", "value_fp32_only", "range_status", "roofline_hbm"):
+        assert k in d, k
+    assert d["range_status"]["flags"] == 0 and len(d["per_rank_ms_per_step"]) == 1
+    assert abs(d["timed_region_ms"] - 3 * d["ms_per_step"]) <= 1e-6 * d["timed_region_ms"]
+    assert "traffic" in d["roofline_hbm"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -463,6 +470,70 @@ def test_f16x2_layers_leave_the_flows_where_fp32_puts_them(pa):
     err_f = float(np.abs(b[:1].cpu().numpy() - e_final).max())
     print(f"f16x2 layers: max |flow| {mag:.2f} px, vs fp32 kernels {float((a - b).abs().max()):.2e}, vs oracle {err_h:.2e} (fp32 kernels: {err_f:.2e})")
     assert err_h <= 1e-3 / 3 and err_h <= 2.0 * err_f + 1e-6, (err_h, err_f)
+
+
+@pytest.mark.parametrize("mode,streams", [("sync", 1), ("lazy", 1), ("lazy", None)])
+def test_out_of_range_frames_fall_back_to_fp32_kernels(pa, mode, streams):
+    """the F16-pipe kernels split their operands into fp16 pairs and turn |x| >= 65504 into NaN; the reference
+    is plain fp32 and nothing bounds its inputs (test.py:31 only divides by 255).  Frames scaled by 1e7: the model notices
+    (status words of the kernels), warns, repeats the forward on the fp32 kernels INTO THE TENSORS IT RETURNED and stays on
+    them -- range_check="sync" before the call returns, "lazy" at status() / the next call.  The result equals what a
+    f16x2=False model gives, bit for bit; in-range frames never trip it and never leave the fast kernels."""
+    import warnings
+    w = util.model_weights(False)
+    im0, im1 = util.smooth_images(4, 192, 256, seed=31, shift=(2, -1))     # (sub-batches of 2 still reach the F16-pipe correlation)
+    ref = pa.PWCDCNet(f16x2=False, streams=streams)       # (the same sub-batches: the same tile plans, bit for bit)
+    ref.load_weights(w)
+    net = pa.PWCDCNet(range_check=mode, streams=streams, track_max=True)
+    net.load_weights(w)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        a, pyr = net(gpu(im0), gpu(im1))
+        rep = net.status()
+    assert rep["flags"] == 0 and rep["f16x2"] is True and rep["fallback_reason"] is None
+    assert 0.05 <= rep["max_abs"] < 65504.0, rep
+    b, _ = ref(gpu(im0), gpu(im1))
+    assert float((a - b).abs().max()) <= 1e-4
+    big0, big1 = gpu(im0 * 1e7), gpu(im1 * 1e7)        # (at this size the frames enter through fp32 kernels: the activations must overflow)
+    want, want_pyr = ref(big0, big1)
+    assert bool(torch.isfinite(want).all())
+    with pytest.warns(RuntimeWarning, match="fp16's range"):       # (the flows came out non-finite)
+        got, got_pyr = net(big0, big1)
+        rep = net.status()
+    assert rep["f16x2"] is False and "65504" in rep["fallback_reason"]
+    torch.cuda.synchronize()
+
+    def same(x, y):
+        return torch.equal(x, y)
+    assert same(got, want) and all(same(g, e) for g, e in zip(got_pyr, want_pyr))
+    with warnings.catch_warnings():                              # the model stays on the fp32 kernels: no second warning
+        warnings.simplefilter("error")
+        again, _ = net(big0, big1)
+        assert net.status()["flags"] == 0
+    assert same(again, want)
+
+
+def test_two_operand_first_conv_matches_the_concat_copy(pa):
+    """Round 5: the estimator's first conv reads features_0 from the pyramid tensor (second operand pointer of the F16-pipe
+    kernel) at the levels that run on it, instead of a copy in the estimator buffer.  Same channels in another order of
+    16-channel stages: the flows agree to fp32 summation order with the copy form, and with the oracle."""
+    w = util.model_weights(False, gain=1.3)
+    im0, im1 = util.smooth_images(8, 448, 1024, seed=96, shift=(3, -2))
+    net_a = pa.PWCDCNet(streams=1)
+    net_a.load_weights(w)
+    net_b = pa.PWCDCNet(streams=1)
+    net_b.load_weights(w)
+    net_b.two_operand = False
+    from pwcnet_amd.profiler import OpTimer
+    a, _ = net_a(gpu(im0), gpu(im1))
+    b, _ = net_b(gpu(im0), gpu(im1))
+    lay4 = net_a._est_layout(4, 8, 112, 256, 32, True, list(range(32)))
+    lay0 = net_a._est_layout(0, 8, 7, 16, 192, False, None)
+    assert "f0" in lay4.external and lay4.n_phys == 128 and "f0" in lay0.segments
+    assert "f0" in net_b._est_layout(4, 8, 112, 256, 32, True, list(range(32))).segments
+    assert float((a - b).abs().max()) <= 2e-5, float((a - b).abs().max())
+    e_final, _ = orc.OraclePWCDCNet(w)(im0[:1], im1[:1])
+    assert float(np.abs(a[:1].cpu().numpy() - e_final).max()) <= 1e-3 / 3
 
 
 def test_channel_split_launches_do_not_change_the_flows(pa, monkeypatch):

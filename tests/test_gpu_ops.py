@@ -450,6 +450,77 @@ def test_conv_c3_c16_pair_vs_oracle(pa, Na, Nb, H0, W0, ycs):
     assert L.pwc_conv3x3_c3c16pair_f32(_p(xo), 1, None, 0, _p(packed), _p(b0g), _p(b1g), _p(b2g), _p(y), ycs, 32, 62, 0.1, None) == -4
 
 
+@pytest.mark.parametrize("N,H,W,ca,cb,cout,with_ws", [(2, 24, 40, 128, 32, 128, False), (1, 33, 47, 48, 16, 64, False),
+                                                         (8, 112, 256, 128, 32, 128, True)])
+def test_conv_f16x2_two_operand_and_status(pa, N, H, W, ca, cb, cout, with_ws):
+    """pwc_conv3x3_h2_ex_f32 (round 5): the input channels given as TWO tensors (the estimator's first conv reading features_0
+    from the pyramid tensor) give bit for bit what one tensor holding both gives; the third case is BASELINE configs[1]'s
+    level-4 shape through the stream-K form.  The status words stay clear (they only ever carry a stream-K timeout); an operand
+    of EITHER tensor beyond fp16's range gives NaN at exactly the pixels that read it, and pwc_resize_bilinear_status_f32 --
+    the launch a forward ends with -- turns a NaN into PWC_STATUS_NONFINITE; pwc_absmax_f32 records the largest magnitude."""
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    cs_a, cs_b = ca + 16, cb + 8                      # both tensors are channel slices of wider ones
+    xa = torch.randn((N, H, W, cs_a), generator=g, device="cuda")
+    xb = torch.randn((N, H, W, cs_b), generator=g, device="cuda")
+    one = torch.cat([xa[..., :ca], xb[..., :cb]], dim=3).contiguous()
+    cin = ca + cb
+    k = gpu(rnd((3, 3, cin, cout), 272) * float(1.0 / np.sqrt(9 * cin)))
+    b = gpu(rnd((cout,), 273) * 0.1)
+    packed = torch.empty(L.pwc_conv3x3_h2_packed_floats(cin, cout), device="cuda")
+    _lib.check(L.pwc_conv3x3_h2_pack_f32(_p(k), None, cin, cin, cout, _p(packed), None))
+    ws = None
+    if with_ws:
+        n = L.pwc_conv3x3_h2_workspace_floats(N, H, W, cin, cout, 1)
+        assert n > 0
+        ws = torch.full((n,), -1, dtype=torch.int32, device="cuda").view(torch.float32)
+    wsa = (None, 0) if ws is None else (_p(ws), ws.numel())
+
+    def run(two, status, xa_=xa, xb_=xb):
+        y = torch.full((N, H, W, cout), -7.0, device="cuda")
+        if two:
+            rc = L.pwc_conv3x3_h2_ex_f32(_p(xa_), cs_a, ca, _p(xb_), cs_b, _p(packed), _p(b), _p(y), cout, N, H, W, cin, cout, 1,
+                                         1, 0.1, *wsa, _p(status) if status is not None else None, None)
+        else:
+            rc = L.pwc_conv3x3_h2_ex_f32(_p(one), cin, 0, None, 0, _p(packed), _p(b), _p(y), cout, N, H, W, cin, cout, 1,
+                                         1, 0.1, *wsa, _p(status) if status is not None else None, None)
+        _lib.check(rc)
+        torch.cuda.synchronize()
+        return y
+    status = torch.zeros(2, dtype=torch.int32, device="cuda")
+    y1, y2 = run(False, None), run(True, status)
+    assert torch.equal(y1, y2)
+    if N * H * W <= 4096:
+        close(y2, orc.conv3x3(one.cpu().numpy(), k.cpu().numpy(), b.cpu().numpy(), 1, 1, 0.1))
+    assert int(status[0].item()) == 0
+    _lib.check(L.pwc_absmax_f32(_p(xa), cs_a, N * H * W, ca, _p(status), None))
+    _lib.check(L.pwc_absmax_f32(_p(xb), cs_b, N * H * W, cb, _p(status), None))
+    torch.cuda.synchronize()
+    assert float(status[1:2].view(torch.float32).item()) == float(one.abs().max())
+    if with_ws:
+        assert bool((ws.view(torch.int32) == -1).all())           # the launch leaves the workspace clean
+    # a value beyond fp16's range in the SECOND tensor
+    xb2 = xb.clone()
+    xb2[N - 1, H // 2, W // 3, 1] = 7.0e4
+    y3 = run(True, status, xb_=xb2)
+    assert bool(torch.isnan(y3[N - 1, H // 2, W // 3]).all()) and not bool(torch.isnan(y3[0, 0, 0]).any())
+    up = torch.empty((N, 2 * H, 2 * W, cout), device="cuda")
+    for src, want in ((y2, 0), (y3, _lib.STATUS_NONFINITE)):
+        _lib.check(L.pwc_resize_bilinear_status_f32(_p(src), cout, _p(up), cout, N, H, W, cout, 2 * H, 2 * W, 20.0, _p(status), None))
+        torch.cuda.synchronize()
+        assert int(status[0].item()) == want
+    ref_up = torch.empty_like(up)
+    _lib.check(L.pwc_resize_bilinear_f32(_p(y3), cout, _p(ref_up), cout, N, H, W, cout, 2 * H, 2 * W, 20.0, None))
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(up, nan=-1.0), torch.nan_to_num(ref_up, nan=-1.0))
+    # argument checks: the first tensor's share must be whole stages
+    assert L.pwc_conv3x3_h2_ex_f32(_p(xa), cs_a, ca - 8, _p(xb), cs_b, _p(packed), _p(b), _p(y1), cout, N, H, W, cin, cout, 1,
+                                   1, 0.1, None, 0, None, None) == -1
+    assert L.pwc_conv3x3_h2_ex_f32(_p(xa), cs_a, ca, _p(xb), cb - 4, _p(packed), _p(b), _p(y1), cout, N, H, W, cin, cout, 1,
+                                   1, 0.1, None, 0, None, None) == -1
+
+
 def test_conv_f16x2_direct_physical_layout_range_and_plan(pa):
     """Padded / permuted physical input channels through cin_map (the estimator buffers); operands of very different
     magnitudes (the split is relative, not absolute); an input beyond fp16's range poisons exactly the outputs that
@@ -932,8 +1003,9 @@ def test_coarse_cost_volume_kernel_vs_oracle(pa, N, H, W, C, with_flow):
 
 
 # ------------------------------------------------------------------ matrix-pipe fused kernel (cost_volume_mfma.hip)
-def _run_concat(pa, f0, f1, flow, flow_scale, ecs, copy, pad, fill=-3.0, flow_cs=4):
-    """pwc_warp_cost_volume_concat_f32 into an estimator-style buffer [cv 81 | pad 3 | f0 C | rest]; returns E."""
+def _run_concat(pa, f0, f1, flow, flow_scale, ecs, copy, pad, fill=-3.0, flow_cs=4, f16x2=True):
+    """pwc_warp_cost_volume_concat_f32 (f16x2=False) / pwc_warp_cost_volume_concat_h2_f32 (the F16-pipe kernel of round 5,
+    cost_volume_h2.hip) into an estimator-style buffer [cv 81 | pad 3 | f0 C | rest]; returns E."""
     from pwcnet_amd.modules import View, sub_view
     N, H, W, C = f0.shape
     g0, g1 = gpu(f0), gpu(f1)
@@ -944,6 +1016,7 @@ def _run_concat(pa, f0, f1, flow, flow_scale, ecs, copy, pad, fill=-3.0, flow_cs
     E = torch.full((N, H, W, ecs), fill, device="cuda")
     Ev = View(E.data_ptr(), ecs, N, H, W, ecs)
     layer = pa.CostVolumeLayer(4)
+    layer.f16x2 = f16x2
     v0, v1 = View(g0.data_ptr(), C, N, H, W, C), View(g1.data_ptr(), C, N, H, W, C)
     fv = View(fl.data_ptr(), flow_cs, N, H, W, 2) if fl is not None else None
     cpy = sub_view(Ev, 84, C) if copy else None
@@ -959,7 +1032,8 @@ def _run_concat(pa, f0, f1, flow, flow_scale, ecs, copy, pad, fill=-3.0, flow_cs
     (3, 9, 21, 32, True, True, False), (1, 5, 3, 32, True, False, False), (1, 17, 10, 64, False, True, True),
     (2, 8, 8, 96, True, False, True), (1, 30, 60, 64, True, True, True), (1, 15, 30, 96, False, False, False),
     (1, 4, 16, 32, True, True, True), (2, 33, 17, 32, False, True, False)])
-def test_concat_cost_volume_kernel_vs_oracle(pa, N, H, W, C, with_flow, copy, pad):
+@pytest.mark.parametrize("f16x2", [True, False])
+def test_concat_cost_volume_kernel_vs_oracle(pa, N, H, W, C, with_flow, copy, pad, f16x2):
     """pwc_warp_cost_volume_concat_f32 (correlation on the matrix pipe): warp + cost volume + f0 copy in one launch
     into channel slices of a wider buffer; ragged block rows / strips (H % 4, W % 16 != 0), single-block images,
     every supported C, flows with far outliers, every combination of the optional parts.  Nothing outside the
@@ -969,7 +1043,7 @@ def test_concat_cost_volume_kernel_vs_oracle(pa, N, H, W, C, with_flow, copy, pa
     f1w = orc.warp(f1, flow, "bilinear", flow_scale=5.0) if with_flow else f1
     exp = orc.cost_volume(f0, f1w, 4)
     ecs = 84 + C + 8
-    E, g0 = _run_concat(pa, f0, f1, flow if with_flow else None, 5.0, ecs, copy, pad)
+    E, g0 = _run_concat(pa, f0, f1, flow if with_flow else None, 5.0, ecs, copy, pad, f16x2=f16x2)
     close(E[..., :81], exp, rel=4e-6, floor=4e-7)
     if copy:
         assert torch.equal(E[..., 84:84 + C], g0)
@@ -982,25 +1056,27 @@ def test_concat_cost_volume_kernel_vs_oracle(pa, N, H, W, C, with_flow, copy, pa
     assert float(E[..., 84 + C:].min()) == -3.0 and float(E[..., 84 + C:].max()) == -3.0
 
 
-def test_concat_cost_volume_known_answers(pa):
+@pytest.mark.parametrize("f16x2", [True, False])
+def test_concat_cost_volume_known_answers(pa, f16x2):
     """Zero flow = plain cost volume; a constant integer flow = the cost volume of the shifted map (edge
     replication from the warp's clipping, zeros outside from the cost volume's padding); the centre channel is
     lrelu(mean_c f0 * f1w)."""
     N, H, W, C = 1, 24, 40, 32
     f0, f1 = rnd((N, H, W, C), 71), rnd((N, H, W, C), 72)
     zero = np.zeros((N, H, W, 2), np.float32)
-    E, _ = _run_concat(pa, f0, f1, zero, 5.0, 128, False, True)
+    E, _ = _run_concat(pa, f0, f1, zero, 5.0, 128, False, True, f16x2=f16x2)
     close(E[..., :81], orc.cost_volume(f0, f1, 4), rel=4e-6, floor=4e-7)
     flow = zero.copy(); flow[..., 0], flow[..., 1] = 2.0 / 5.0, -3.0 / 5.0
     shifted = f1[:, np.clip(np.arange(H) - 3, 0, H - 1)][:, :, np.clip(np.arange(W) + 2, 0, W - 1)]
-    E, _ = _run_concat(pa, f0, f1, flow, 5.0, 128, False, True)
+    E, _ = _run_concat(pa, f0, f1, flow, 5.0, 128, False, True, f16x2=f16x2)
     close(E[..., :81], orc.cost_volume(f0, shifted, 4), rel=4e-6, floor=4e-7)
     centre = (f0 * shifted).mean(axis=3)
     centre = np.maximum(centre, 0.1 * centre)
     close(E[..., 40], centre, rel=4e-6, floor=4e-7)
 
 
-def test_concat_cost_volume_full_size_vs_separate_launches(pa):
+@pytest.mark.parametrize("f16x2", [True, False])
+def test_concat_cost_volume_full_size_vs_separate_launches(pa, f16x2):
     """BASELINE configs[1] level-4 geometry (8 x 112 x 256 x 32, estimator channel stride 160), flows ~ N(0, 3^2)
     px with outliers: the one-launch kernel against warp + cost volume as separate launches, every entry."""
     from pwcnet_amd.modules import View, sub_view
@@ -1015,6 +1091,7 @@ def test_concat_cost_volume_full_size_vs_separate_launches(pa):
     v0, v1 = View(f0.data_ptr(), C, N, H, W, C), View(f1.data_ptr(), C, N, H, W, C)
     fv = View(fl.data_ptr(), 2, N, H, W, 2)
     layer = pa.CostVolumeLayer(4)
+    layer.f16x2 = f16x2
     layer._run(v0, v1, sub_view(Ev, 0, 81), flow=fv, flow_scale=5.0, f0_copy=sub_view(Ev, 84, C), concat=True,
                out_pad_writable=True)
     f1w = pa.WarpingLayer("bilinear")(f1, fl * 5.0)
@@ -1024,7 +1101,8 @@ def test_concat_cost_volume_full_size_vs_separate_launches(pa):
     assert float(E[..., 116:].abs().max()) == 0.0
 
 
-def test_concat_cost_volume_full_size_vs_oracle(pa):
+@pytest.mark.parametrize("f16x2", [True, False])
+def test_concat_cost_volume_full_size_vs_oracle(pa, f16x2):
     """the one-launch kernel at BASELINE configs[1]'s level-4 geometry (8 x 112 x 256 x 32) against
     orc.cost_volume(orc.warp(...)) DIRECTLY (not against other HIP launches), images 0 and 7, every entry; flows ~ N(0, 3^2)
     px with far outliers."""
@@ -1032,7 +1110,7 @@ def test_concat_cost_volume_full_size_vs_oracle(pa):
     f0, f1 = rnd((N, H, W, C), 91), rnd((N, H, W, C), 92)
     flow = (np.random.RandomState(93).randn(N, H, W, 2) * (3.0 / 5.0)).astype(np.float32)
     flow[0, 0, 0], flow[7, 111, 255, 0], flow[7, 50, 100] = (60.0, -60.0), -45.0, (11.3, 7.7)
-    E, g0 = _run_concat(pa, f0, f1, flow, 5.0, 160, True, True, fill=0.0)
+    E, g0 = _run_concat(pa, f0, f1, flow, 5.0, 160, True, True, fill=0.0, f16x2=f16x2)
     for i in (0, N - 1):
         f1w = orc.warp(f1[i:i + 1], flow[i:i + 1], "bilinear", flow_scale=5.0)
         close(E[i:i + 1, ..., :81], orc.cost_volume(f0[i:i + 1], f1w, 4), rel=4e-6, floor=4e-7)
@@ -1056,6 +1134,44 @@ def test_concat_cost_volume_rejects_what_it_does_not_support(pa):
     rc = L.pwc_warp_cost_volume_concat_f32(_p(y), 32, _p(y), 32, None, 0, 1.0, _p(out), 84, 1, None, 0,
                                            1, 8, 8, 32, 2, 0.1, None)
     assert rc == -4
+
+
+def test_concat_cost_volume_f16x2_error_and_status(pa):
+    """The F16-pipe correlation against a float64 cost volume: not further from it than the fp32 matrix-pipe kernel is
+    (features of 1e-3 .. 300 in magnitude); a feature beyond fp16's range gives NaN where it is read (never a wrong number)."""
+    from pwcnet_amd import _lib
+    from pwcnet_amd.modules import View, sub_view
+    N, H, W, C = 2, 24, 48, 64
+    for scale in (1e-3, 1.0, 300.0):
+        f0, f1 = rnd((N, H, W, C), 201) * scale, rnd((N, H, W, C), 202) * scale
+        flow = util.flow_field(N, H, W, seed=203) / 5.0
+        f1w = orc.warp(f1, flow, "bilinear", flow_scale=5.0).astype(np.float64)
+        pad1 = np.zeros((N, H + 8, W + 8, C))
+        pad1[:, 4:-4, 4:-4] = f1w
+        ref = np.stack([(f0.astype(np.float64) * pad1[:, 4 + v:4 + v + H, 4 + h:4 + h + W]).mean(axis=3)
+                        for v in range(-4, 5) for h in range(-4, 5)], axis=3)
+        ref = np.maximum(ref, 0.1 * ref)
+        errs = {}
+        for f16x2 in (True, False):
+            E, _ = _run_concat(pa, f0, f1, flow, 5.0, 160, False, True, fill=0.0, f16x2=f16x2)
+            errs[f16x2] = float(np.abs(E[..., :81].double().cpu().numpy() - ref).max())
+        assert errs[True] <= 1.25 * errs[False] + 1e-12 * scale * scale, (scale, errs)
+    # range
+    f0, f1 = rnd((1, 16, 32, 32), 211), rnd((1, 16, 32, 32), 212)
+    layer = pa.CostVolumeLayer(4)
+    for big in (None, 70000.0):
+        g0, g1 = gpu(f0), gpu(f1)
+        if big is not None:
+            g1[0, 7, 9, 3] = big
+        E = torch.zeros((1, 16, 32, 128), device="cuda")
+        Ev = View(E.data_ptr(), 128, 1, 16, 32, 128)
+        layer._run(View(g0.data_ptr(), 32, 1, 16, 32, 32), View(g1.data_ptr(), 32, 1, 16, 32, 32), sub_view(Ev, 0, 81),
+                   concat=True, out_pad_writable=True)
+        torch.cuda.synchronize()
+        nan = torch.isnan(E[..., :81])
+        assert bool(torch.isfinite(E[..., :81]).all()) == (big is None)
+        if big is not None:       # exactly the 81 (pixel, displacement) pairs that meet pixel (7, 9) of f1
+            assert int(nan.sum()) == 81 and bool(nan[0, 3:12, 5:14].any(dim=2).all())
 
 
 def test_coarse_cost_volume_rejects_other_search_ranges(pa):
