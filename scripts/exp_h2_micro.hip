@@ -58,7 +58,37 @@ static void run(const char* name) {
     (void)hipFree(out);
 }
 
-int main() {
+// `long` mode (round 5): the MFMA-only loop for ~3 s per operand set (zeros, then the pattern above) so that a
+// 10 Hz log of the clocks and the power (scripts/gpu_clock_log.sh) brackets it; prints the sustained rate of each phase.
+template <int ZERO>
+static void run_long(const char* name, float seconds) {
+    float* out; (void)hipMalloc(&out, 4096);
+    unsigned long long* tk; (void)hipMalloc(&tk, 8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tap_kernel<0, 12, 8, ZERO>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int iters = 20000;
+    double total_ms = 0; long launches = 0;
+    while (total_ms < seconds * 1e3) {
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((tap_kernel<0, 12, 8, ZERO>), dim3(256), dim3(512), 163840, 0, out, iters, tk);
+        (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); total_ms += ms; ++launches;
+    }
+    const double taps = 2.0 * iters * launches;
+    const double pf = taps * 24 * 32768.0 * 1024 / (total_ms * 1e-3) / 1e15;
+    printf("%-40s %.2f s, %.1f ns per tap = %.3f PFLOP/s executed (24 v_mfma_f32_32x32x16_f16 per SIMD and tap, 1024 SIMDs)\n", name, total_ms * 1e-3,
+           total_ms * 1e6 / taps, pf);
+    fflush(stdout);
+    (void)hipFree(out);
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1) {
+        run_long<1>("MFMA only, all operands zero", 3.f);
+        run_long<0>("MFMA only, operand pattern", 3.f);
+        run_long<1>("MFMA only, all operands zero (again)", 2.f);
+        return 0;
+    }
     run<0, 12, 8>("MFMA only");
     run<0, 12, 8, 1>("MFMA only, all operands zero");
     run<8, 12, 8, 1>("MFMA + reads, all operands zero");
