@@ -13,28 +13,30 @@
 // per 4 x 4-pixel block at C = 32 where the fp32 form has 72 of 32 cycles, and an F16-pipe instruction does not
 // keep the SIMD's vector instructions out.  Range of the split: |x| < 65504 (beyond: NaN outputs; PWC_STATUS_NONFINITE).
 //
-// Schedule.  What bound the round-3 kernel was not arithmetic: a step (one Q block row) issued its gather loads and needed them
-// a few hundred cycles later, so every step paid one full memory latency (two at C = 64, three at C = 96: the batches reuse the
-// registers) -- 10 steps x (2 us of instructions + 2 us of latency) at level 4, measured 38 us with either arithmetic
-// (profiles/r05_exp_cv4_*.txt).  It could not issue them earlier: three generations of accumulators (108 registers) left no
-// room to hold 48 registers of corners across a step.  Here
-//   * a P block row is computed in ONE step against the three Q rows it meets, which all sit in LDS (a ring of three Q-row
-//     images): 9 accumulator tiles = 36 registers, no generations, no unrolled slot rotation;
-//   * the corners of Q row p+3 are requested in step p and blended in step p+1 -- a whole step of latency budget, with every
-//     wave of the CU holding 12 KB in flight all the time;
-//   * a wave's stores (the copy-out of its P row, the f0 copy) are the LAST memory instructions of a step: a load is never
-//     waited for with a fresh store in front of it in the queue (one counter serves both).
-// Per step p (P block row p; Q rows p-1, p, p+1 in ring slots; everything else ahead of time):
-//     request f0 row p+1, flow of Q row p+4
-//     tiles by = -1                                   <- image of Q row p-1
-//     barrier                                         (that image is free)
-//     corners of Q row p+2 (requested in step p-1): blend, split -> the freed image
-//     request the corners of Q row p+3                (table of row p+3: built in step p-1)
-//     tiles by = 0, by = +1; all nine -> stage (per-wave, 84-float pixel records)
-//     split f0 row p+1 (+ its concat copy); corner table of Q row p+4
-//     copy-out of P row p: stage -> leaky-relu -> contiguous 16-byte stores
-//     barrier
-// Three fill steps (p = pb0-3 .. pb0-1) run the same code with the tile work switched off.
+// Organisation.  A workgroup is EIGHT waves, one workgroup per CU:
+//   waves 0-3  "consumers", one per 4-pixel block column of the 16-column strip: matrix instructions, stage, copy-out.  A P block
+//              row is computed in ONE step against the three Q rows it meets, which all sit in LDS (ring of three Q-row images):
+//              9 accumulator tiles = 36 registers -- no three generations of accumulators (108 registers in cost_volume_mfma.hip),
+//              no unrolled slot rotation.  The 18 operand reads of a step (C = 32) go out together at its top.  The f0 rows are
+//              requested two steps before they are split.
+//   waves 4-7  "producers": nothing but the gather -- flows, corner tables, the corner requests of Q row p+3 in step p, blend +
+//              split + Q-row image of row p+2 (requested a step earlier), so a trip to memory has a whole step.
+// Per step p two barriers: A (every consumer has read the image of Q row p-1: the producers may overwrite it with row p+2) and B
+// (row p+2 and the next table are complete).  Three fill steps (p = pb0-3 .. pb0-1) run with the tile work switched off.
+//
+// What was measured on the way (batch 8, cold operands, iid N(0, 3^2) px flows; profiles/r05_exp_cv*.txt), level 4 / 3 / 2, us:
+//   cost_volume_mfma.hip (fp32 MFMA), with / without the f0 copy        46.7 / 40.5    31.4 / 28.0    21.4 / 19.5
+//   the same kernel with F16-pipe products only                          44.5 / 38.4    26.9 / 24.7    19.0 / 17.8
+//   ring of Q images, one step per P row, gathers a step ahead (4 waves) 46.3 / 36.5    25.9 / 24.3    19.9 / 18.8
+//   + producer / consumer waves (this file)                              47.6 / 33.4    22.6 / 20.2    17.5 / 16.8
+// and what did NOT move it: the corners requested three steps ahead instead of one (34.6 at level 4), the copy-out given to the
+// producers (37.2), the f0 operands fetched and split by the producers and handed over through LDS (34.6), lane-dependent
+// addresses instead of execution-mask branches in the stage writes.  The skeleton without corner requests and stores takes 21-23
+// us at level 4 in EVERY form -- about 3000 cycles per step for the ~250 instructions of a consumer: the step is a chain of LDS
+// round trips and dependent matrix / vector instructions at one consumer wave per SIMD, and the memory system's own floor for this
+// traffic pattern (58.7 MB of 128-byte reads + 77 MB written as 336 bytes of every 512 / 640: scripts/exp_membw.hip) is 25 - 32 us.
+// One thing the compiler forces: a wave that waits for ANY load waits for ALL of its stores (loads and stores share one counter and
+// the waits are not counted across the two kinds) -- the consumers' f0 wait drains their copy-out stores once per step.
 //
 // Lane roles, LDS layouts, the stage and the copy-out are those of cost_volume_mfma.hip (see there); the Q-row image holds, per
 // 32 channels, a plane of h slots [row 4][pixel 24][quad kq: 8 fp16 = channels 4 kq..+3 and 16 + 4 kq..+3] and a plane of m'
@@ -45,15 +47,15 @@
 template <int CG>
 struct CvhGeom {
     using M = CvmGeom<CG>;
-    static constexpr int RING = 3;
-    static constexpr int LDS_F = RING * M::BUF * 4 + M::NW * M::WSTG + RING * M::TAB;
-    static constexpr int WGPC = LDS_F * 4 * 2 <= 160 * 1024 ? 2 : 1;
+    static constexpr int RING = 3;                                      // Q-row images
+    static constexpr int TRING = 3;                                     // corner tables: row r's is written in step r-4, read in steps r-3 (requests) and r-2 (blend)
+    static constexpr int LDS_F = RING * M::BUF * 4 + M::NW * M::WSTG + TRING * M::TAB;
     static_assert(LDS_F * 4 <= 160 * 1024, "does not fit the LDS");
 };
 
 // ABL (scripts/exp_cv5.hip only; 0 in the library): 1 = no MFMAs, 2 = no gather loads, 4 = no stores, 8 = s_memtime stamps
 template <int CG, bool WARP, bool PAD, int ABL = 0>
-__global__ __launch_bounds__(256, CvhGeom<CG>::WGPC) void cost_volume_h2_kernel(const CvmArgs a) {
+__global__ __launch_bounds__(512, 1) void cost_volume_h2_kernel(const CvmArgs a) {
     using G = CvmGeom<CG>;
     using GH = CvhGeom<CG>;
     constexpr int RS = G::RS, PLANE = G::PLANE, BUF = G::BUF, ITEMS = G::ITEMS, NP = CG / 2;
@@ -61,10 +63,11 @@ __global__ __launch_bounds__(256, CvhGeom<CG>::WGPC) void cost_volume_h2_kernel(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* qimg = reinterpret_cast<f32x4*>(smem);                       // ring of 3 Q-row images of BUF slots
     float* stg_all = smem + GH::RING * BUF * 4;
-    float* tabf = stg_all + G::NW * G::WSTG;                            // ring of 3 corner tables of TAB dwords
+    float* tabf = stg_all + G::NW * G::WSTG;                            // ring of corner tables of TAB dwords
 
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);            // block column of the strip
+    const int t = threadIdx.x & 255, lane = t & 63;                     // thread index inside its role
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);            // block column of the strip (consumers)
+    const bool consumer = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0;      // wave-uniform
     float* stg = stg_all + wave * G::WSTG;
 
     // ---- work item: (image, strip, segment); XCD-aware order (neighbouring strips meet in one L2)
@@ -254,9 +257,9 @@ __global__ __launch_bounds__(256, CvhGeom<CG>::WGPC) void cost_volume_h2_kernel(
     };
 
     // ---- f0 operand of a P row: global -> registers in MFMA layout; split (and copied out) one step later
-    f32x4 A[CG];
+    f32x4 A2[2][CG];                                                    // raw rows in flight: requested TWO steps ahead
     pwc_f16x8 AH[NP], AM[NP];
-    auto load_A = [&](int pb) {
+    auto load_A = [&](f32x4* A, int pb) {
         const bool ok = a_in && pb >= pb0 && pb < pb1 && 4 * pb + mrow < a.H;
         const unsigned vo = ok ? (a_rel + (unsigned)(4 * pb * a.W)) * (unsigned)(a.f0_cs * 4) + (unsigned)(kq * 16) : CVM_OOB;
 #pragma unroll
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256, CvhGeom<CG>::WGPC) void cost_volume_h2_kernel(
             A[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r0, (int)(ok ? vo : CVM_OOB), g * 64, CVM_F0_AUX));
     };
     // (k slot e of lane quarter kq = channel 32 j + 4 kq + e for e < 4, 32 j + 16 + 4 kq + e - 4 else: what the image holds)
-    auto split_A = [&](int pb) {
+    auto split_A = [&](const f32x4* A, int pb) {
         const bool ok = a_in && pb >= pb0 && pb < pb1 && 4 * pb + mrow < a.H && !(ABL & 4);
         const unsigned vo = ok ? (a_rel + (unsigned)(4 * pb * a.W)) * (unsigned)(a.f0_copy_cs * 4) + (unsigned)(kq * 16) : CVM_OOB;
 #pragma unroll
@@ -282,9 +285,23 @@ __global__ __launch_bounds__(256, CvhGeom<CG>::WGPC) void cost_volume_h2_kernel(
 
     // ---- the three tiles of one vertical block offset: per 32 channels cross = AH x BM' + AM' x BH, hh = AH x BH
     f32x4 acc[3][3];                                                    // [by + 1][bx + 1]
-    auto group = [&](auto byi_c, int is) {
+    // B operands of one vertical offset (image slot `is`): reads(); its nine (C = 32) matrix instructions: mfmas().  The three
+    // images a step reads are complete when it starts, so the reads of a later group can be in flight under an earlier one's
+    // instructions (C = 32: all eighteen at the top of the step).
+    pwc_f16x8 Lh[3][NP][3], Lm[3][NP][3];
+    auto reads = [&](auto byi_c, int is) {
         constexpr int byi = decltype(byi_c)::value;
         const pwc_f16x8* imgh = reinterpret_cast<const pwc_f16x8*>(qimg + is * BUF);
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+#pragma unroll
+            for (int bx = 0; bx < 3; ++bx) {
+                Lh[byi][j][bx] = imgh[(2 * j) * PLANE + bslot + (bx - 1) * 16];
+                Lm[byi][j][bx] = imgh[(2 * j + 1) * PLANE + bslot + (bx - 1) * 16];
+            }
+    };
+    auto mfmas = [&](auto byi_c) {
+        constexpr int byi = decltype(byi_c)::value;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         if (ABL & 1) {
 #pragma unroll
@@ -294,18 +311,12 @@ __global__ __launch_bounds__(256, CvhGeom<CG>::WGPC) void cost_volume_h2_kernel(
         f32x4 hh[3], xx[3];
         cvm_for<NP>([&](auto j_c) {
             constexpr int j = decltype(j_c)::value;
-            pwc_f16x8 Lh[3], Lm[3];
 #pragma unroll
-            for (int bx = 0; bx < 3; ++bx) {
-                Lh[bx] = imgh[(2 * j) * PLANE + bslot + (bx - 1) * 16];
-                Lm[bx] = imgh[(2 * j + 1) * PLANE + bslot + (bx - 1) * 16];
-            }
+            for (int bx = 0; bx < 3; ++bx) xx[bx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH[j], Lm[byi][j][bx], j == 0 ? zero : xx[bx], 0, 0, 0);
 #pragma unroll
-            for (int bx = 0; bx < 3; ++bx) xx[bx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH[j], Lm[bx], j == 0 ? zero : xx[bx], 0, 0, 0);
+            for (int bx = 0; bx < 3; ++bx) hh[bx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH[j], Lh[byi][j][bx], j == 0 ? zero : hh[bx], 0, 0, 0);
 #pragma unroll
-            for (int bx = 0; bx < 3; ++bx) xx[bx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AM[j], Lh[bx], xx[bx], 0, 0, 0);
-#pragma unroll
-            for (int bx = 0; bx < 3; ++bx) hh[bx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH[j], Lh[bx], j == 0 ? zero : hh[bx], 0, 0, 0);
+            for (int bx = 0; bx < 3; ++bx) xx[bx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AM[j], Lh[byi][j][bx], xx[bx], 0, 0, 0);
         });
 #pragma unroll
         for (int bx = 0; bx < 3; ++bx)
@@ -358,48 +369,74 @@ __global__ __launch_bounds__(256, CvhGeom<CG>::WGPC) void cost_volume_h2_kernel(
         }
     };
 
-    // ---- prologue: tables of Q rows pb0-1 and pb0; the corners of row pb0-1 requested; no operand yet
-    auto slot = [](int r) { return ((r % 3) + 3) % 3; };
-    if (WARP) {
-        float g0, g1;
-        flow_issue(pb0 - 1, fl0, fl1);
-        flow_issue(pb0, g0, g1);
-        table_write(pb0 - 1, slot(pb0 - 1), fl0, fl1);
-        table_write(pb0, slot(pb0), g0, g1);
-    }
+    auto slot = [](int r) { return ((r % 3) + 3) % 3; };                // ring slot of Q row r (images and tables alike)
+    if (consumer) {
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) { AH[j] = pwc_f16x8{}; AM[j] = pwc_f16x8{}; }
-    cvm_barrier();
-    g_issue(pb0 - 1, slot(pb0 - 1));
-
-    for (int p = pb0 - 3; p < pb1; ++p) {
-        const bool real = p >= pb0;                                     // uniform: fill steps compute nothing
-        const int s_m = slot(p - 1), s_0 = slot(p), s_p = slot(p + 1);
-        stamp();
-        load_A(p + 1);
-        if (WARP) flow_issue(p + 4, fl0, fl1);
-        if (real) group(std::integral_constant<int, 0>{}, s_m);         // by = -1
-        stamp();
-        cvm_barrier();                                                  // every wave has read the image of Q row p-1
-        stamp();
-        g_commit(slot(p + 2), s_m);                                     // Q row p+2 takes its place (requested a step ago)
-        stamp();
-        g_issue(p + 3, slot(p + 3));
-        if (real) {
-            group(std::integral_constant<int, 1>{}, s_0);
-            group(std::integral_constant<int, 2>{}, s_p);
-            cvm_wave_sync();                                            // the previous copy-out has read the stage
-            to_stage();
+        for (int j = 0; j < NP; ++j) { AH[j] = pwc_f16x8{}; AM[j] = pwc_f16x8{}; }
+        int s_m = slot(pb0 - 4), s_0 = slot(pb0 - 3), s_p = slot(pb0 - 2);          // ring slots of Q rows p-1, p, p+1
+        // one step; PAR = which of the two f0 buffers receives row p+2 (the other one holds row p+1, requested a step ago)
+        auto cstep = [&](auto par_c, int p) {
+            constexpr int PAR = decltype(par_c)::value;
+            const bool real = p >= pb0;                                 // uniform: fill steps compute nothing
+            stamp();
+            load_A(A2[PAR], p + 2);
+            if (real) {
+                reads(I0{}, s_m);
+                if constexpr (NP == 1) { reads(I1{}, s_0); reads(I2{}, s_p); }
+            }
+            stamp();
+            cvm_barrier();                                              // A: the image of Q row p-1 has been read
+            stamp();
+            if (real) {
+                if constexpr (NP > 1) reads(I1{}, s_0);
+                mfmas(I0{});
+                if constexpr (NP > 1) reads(I2{}, s_p);
+                mfmas(I1{});
+                mfmas(I2{});
+                cvm_wave_sync();                                        // the previous copy-out has read the stage
+                to_stage();
+            }
+            stamp();
+            split_A(A2[1 - PAR], p + 1);                                // (+ its concat copy: stores)
+            stamp();
+            cvm_wave_sync();
+            // Always executed (rows outside the segment store nothing: out-of-range offsets)
+            copy_out(p);
+            stamp();
+            cvm_barrier();                                              // B: Q row p+2 and the table of row p+4 are complete
+            stamp();
+            stamp();
+            const int s_n = s_m; s_m = s_0; s_0 = s_p; s_p = s_n;      // (the freed image is Q row p+2's)
+        };
+        cvm_barrier();                                                  // (the producers' first tables)
+        load_A(A2[1], pb0 - 2);                                         // (no such row: zeros)
+        for (int p = pb0 - 3; p < pb1; p += 2) {
+            cstep(I0{}, p);
+            if (p + 1 < pb1) cstep(I1{}, p + 1);
         }
-        stamp();
-        split_A(p + 1);                                                 // (+ its concat copy: stores)
-        if (WARP) table_write(p + 4, slot(p + 4), fl0, fl1);
-        stamp();
-        cvm_wave_sync();
-        copy_out(p);
-        stamp();
+    } else {
+        // tables of Q rows pb0-1 and pb0, the corners of row pb0-1 requested; then per step: flow of row p+4, [A], blend of row
+        // p+2, requests of row p+3, table of row p+4, [B]
+        if (WARP) {
+            float g0, g1;
+            flow_issue(pb0 - 1, fl0, fl1);
+            flow_issue(pb0, g0, g1);
+            table_write(pb0 - 1, slot(pb0 - 1), fl0, fl1);
+            table_write(pb0, slot(pb0), g0, g1);
+        }
         cvm_barrier();
-        stamp();
+        g_issue(pb0 - 1, slot(pb0 - 1));
+        for (int p = pb0 - 3; p < pb1; ++p) {
+            if (WARP) flow_issue(p + 4, fl0, fl1);
+            cvm_barrier();                                              // A
+            g_commit(slot(p + 2), slot(p - 1));                         // Q row p+2 (requested a step ago) -> the freed image
+            g_issue(p + 3, slot(p + 3));
+            if (WARP) table_write(p + 4, slot(p + 4), fl0, fl1);
+            cvm_barrier();                                              // B
+        }
     }
 }
 
@@ -412,10 +449,10 @@ static int cvh_launch_t(CvmArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_volume_h2_kernel<CG, WARP, PAD, 0>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    cvm_plan(a.N, a.H, a.W, GH::WGPC, &a.nstrips, &a.nseg, &a.seg_brows);
+    cvm_plan(a.N, a.H, a.W, 1, &a.nstrips, &a.nseg, &a.seg_brows);
     const long items = (long)a.N * a.nstrips * a.nseg;
     if (items >= (1L << 31)) return PWC_ERANGE;
-    hipLaunchKernelGGL((cost_volume_h2_kernel<CG, WARP, PAD, 0>), dim3((unsigned)items), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((cost_volume_h2_kernel<CG, WARP, PAD, 0>), dim3((unsigned)items), dim3(512), lds, s, a);
     return pwc_launch_status();
 }
 

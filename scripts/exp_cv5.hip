@@ -1,4 +1,6 @@
-// Round 5: the harness of exp_cv3.hip for cost_volume_h2.hip (F16 pipe, gathers a step ahead) beside the fp32 kernel of round 3.
+// Round 5: the harness of exp_cv3.hip for cost_volume_h2.hip (F16 pipe, producer / consumer waves) beside the fp32 kernel of round 3.
+// (The intermediate forms of the round -- the F16 products inside the round-3 kernel: scripts/exp_cv4.hip at commit c50e90d; the ring
+// kernel with four one-role waves, deeper request pipelines, other divisions of the roles: profiles/r05_exp_cv5_*.txt.)
 // Microbenchmark + correctness harness: fused warp + cost volume + concat copy on the matrix pipe
 // (pwcnet_amd/csrc/cost_volume_mfma.hip) against the production pair of round 2 (warp_kernel + concat copy, then the
 // rolling / tile cost-volume kernel).  Not part of the library.
@@ -31,10 +33,10 @@ static void launch_cvm_t(CvmArgs a) {
         const size_t lds = (size_t)GH::LDS_F * sizeof(float);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_volume_h2_kernel<CG, WARP, PAD, ABL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (a.seg_brows <= 0) cvm_plan(a.N, a.H, a.W, GH::WGPC, &a.nstrips, &a.nseg, &a.seg_brows);
+        if (a.seg_brows <= 0) cvm_plan(a.N, a.H, a.W, 1, &a.nstrips, &a.nseg, &a.seg_brows);
         else { a.nstrips = (a.W + 15) / 16; a.nseg = (a.nbrows + a.seg_brows - 1) / a.seg_brows; }
         const long items = (long)a.N * a.nstrips * a.nseg;
-        hipLaunchKernelGGL((cost_volume_h2_kernel<CG, WARP, PAD, ABL>), dim3((unsigned)items), dim3(256), lds, 0, a);
+        hipLaunchKernelGGL((cost_volume_h2_kernel<CG, WARP, PAD, ABL>), dim3((unsigned)items), dim3(512), lds, 0, a);
         return;
     } else {
     launch_cvm_old<CG, WARP, PAD>(a);
