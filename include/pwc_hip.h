@@ -299,12 +299,21 @@ int pwc_conv3x3_c3c16pair_f32(const float* x_a, int N_a, const float* x_b, int N
                               const float* bias0, const float* bias1, const float* bias2, float* y, int y_cs,
                               int H0, int W0, float slope, pwc_stream_t stream);
 int pwc_conv3x3_c3c16pair_supported(int N, int H0, int W0);
-/* Stride 2 ('SAME', dilation 1; the extractor's down-sampling layers, reference modules.py:57-60) through the same
- * kernel: the launch of the stride-1 convolution over the (H, W) input that stores only the sums a stride-2 convolution
- * has.  y is (N, ceil(H/2), ceil(W/2)) with channel stride y_cs; everything else as pwc_conv3x3_h2_f32 (packed_w from
- * the same pack function; workspace sized by pwc_conv3x3_h2_workspace_floats(N, H, W, Cin_phys, Cout, 1)).  Four times
- * the matrix work of a strided kernel: measured 10-15 % SLOWER than pwc_conv3x3_f32 on the extractor's layers, so
- * pwc_conv3x3_h2_stride2_supported returns 0 for every shape today and the host never routes to it. */
+/* Stride 2 ('SAME', dilation 1, EVEN H and W; the extractor's down-sampling layers, reference modules.py:57-60) through the
+ * same kernel (round 5).  With the input seen as its four parity planes x_ab[y', x'] = x[2 y' + a, 2 x' + b] the strided
+ * convolution is a stride-1 one with taps at 0 / +1 on each plane: a channel stage of the kernel is (16 channels, parity), fetched
+ * from the pixels of its plane, and four of a stage's nine tap slots carry matrix instructions -- 16 Cin products per output
+ * (a strided convolution needs 9 Cin; round 4's "stride-1 launch storing every second sum" executed 36 Cin and lost to the fp32
+ * kernel).  y is (N, H / 2, W / 2) at channel stride y_cs.  packed_w: pwc_conv3x3_h2_stride2_pack_f32 (same arguments as
+ * pwc_conv3x3_h2_pack_f32: cin_map over the input's Cin_phys physical channels; pwc_conv3x3_h2_stride2_packed_floats floats);
+ * workspace: pwc_conv3x3_h2_stride2_workspace_floats (0: none), rules of pwc_conv3x3_h2_f32.  Odd sizes: PWC_EUNSUPPORTED
+ * (pwc_conv3x3_f32 takes them).  _supported: 1 where it is the faster kernel: inputs of up to 32 channels whose output is a
+ * shape pwc_conv3x3_h2_supported takes at 4 Cin_phys channels (measured: 16 -> 32 and 32 -> 64 of the extractor; from 64 input
+ * channels on the per-stage fixed cost of 4 x as many stages outweighs the matrix pipe's rate). */
+size_t pwc_conv3x3_h2_stride2_packed_floats(int Cin_phys, int Cout);
+int pwc_conv3x3_h2_stride2_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin, int Cin_phys,
+                                    int Cout, float* packed_w, pwc_stream_t stream);
+size_t pwc_conv3x3_h2_stride2_workspace_floats(int N, int H, int W, int Cin_phys, int Cout);
 int pwc_conv3x3_h2_stride2_f32(const float* x, int x_cs, const float* packed_w, const float* bias,
                                float* y, int y_cs, int N, int H, int W, int Cin_phys, int Cout,
                                int apply_act, float slope, float* workspace, size_t workspace_floats,

@@ -59,6 +59,9 @@ SIGNATURES = {
     "pwc_conv3x3_h2_plan": (_i, [_i, _i, _i, _i, _i, _i]),
     "pwc_conv3x3_h2_stride2_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "pwc_conv3x3_h2_stride2_supported": (_i, [_i, _i, _i, _i, _i]),
+    "pwc_conv3x3_h2_stride2_packed_floats": (_sz, [_i, _i]),
+    "pwc_conv3x3_h2_stride2_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "pwc_conv3x3_h2_stride2_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),
     "pwc_conv3x3_c16pair_packed_floats": (_sz, []),
     "pwc_conv3x3_c16pair_pack_f32": (_i, [_vp, _vp, _vp, _vp]),
     "pwc_conv3x3_c16pair_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),

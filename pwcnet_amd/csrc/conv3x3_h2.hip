@@ -83,8 +83,7 @@ struct H2Args {
     float* ws_partial;   // stream-K: one partial tile (32 CT WCG couts x PT WPG x 32 pixels, fp32) per workgroup, words 0xFFFFFFFF
                          // while nothing is published; null = every workgroup owns whole tiles
     unsigned* dbg;       // harness only
-    int stride;          // 1, or 2: only the sums at positions 2 o + off are stored, to an (Ho, Wo) output
-    int Ho, Wo, off_y, off_x;
+    int Ho, Wo;          // output size: (H, W), or (H / 2, W / 2) of the stride-2 form (S2)
     // round 5: the input as TWO tensors -- stages c16 < nc16_a are channels [16 c16, 16 c16 + 16) of x, the others channels
     // [16 (c16 - nc16_a), ...) of x2 (same pixel grid, own channel stride).  The estimator's first layer reads features_0
     // straight from the pyramid tensor: the concat copy of reference modules.py:264 does not exist.  x2 = null: all of x.
@@ -132,7 +131,15 @@ template <int CT, int PT, int WCG, int XS = 1> struct H2Cfg {
 // ABL (harness only): 1 = no patch DMA, 2 = no weight DMA, 4 = no MFMA, 8 = m' = 0, 16 = no split at all, 32 = no fragment reads,
 // 64 = the published sums are replaced by position tags and checked by the reader (self-test of the exchange), 2048 = s_memtime
 // totals of the waits, barriers and piece ends per wave
-template <int CT, int PT, int WCG, int ABL = 0, int XS = 1>
+// S2 (round 5): stride 2, 'SAME', even H and W -- the extractor's down-sampling layers (reference modules.py:57-60).  With the input
+// seen as its four PARITY planes x_ab[y', x'] = x[2 y' + a, 2 x' + b] the strided convolution is a stride-1 one with taps at 0 / +1:
+//     y[oy, ox] = sum_{a,b} sum_{ty,tx in {0,1}} w[2 ty + a, 2 tx + b] x_ab[oy + ty, ox + tx]        (w = 0 beyond index 2),
+// i.e. a channel stage here is (16 channels, parity) -- stage s = (2 a + b) (C / 16) + channel group, Cin_phys = 4 C -- fetched from the
+// pixels of ITS plane (the lane's pixel index + a W + b), and of the nine tap slots of a stage the four with tap row >= 1 and tap
+// column >= 1 carry matrix instructions (weights: h2_pack with S2; the others keep their fetch / split / barrier duties, so the
+// pipeline is the stride-1 one).  16 C products per output against the 9 C a strided convolution needs and the 36 C of "the
+// stride-1 launch that stores every second sum" (round 4: slower than the fp32 kernel).
+template <int CT, int PT, int WCG, int ABL = 0, int XS = 1, bool S2 = false>
 __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     typedef H2Cfg<CT, PT, WCG, XS> C;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -207,7 +214,8 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         for (int i = 0; i < C::PPW; ++i) {
             const int rec = (wave + 8 * i) * 16 + (lane >> 2);
             const int py = rec / C::PW, px = rec - py * C::PW;
-            const int yy = tl.ry + dly * (y0 - 1 + py), xx = tl.rx + dlx * (x0 - XS + px);
+            const int yy = S2 ? 2 * (y0 - 1 + py) : tl.ry + dly * (y0 - 1 + py);     // (S2: the pixel of plane (0, 0))
+            const int xx = S2 ? 2 * (x0 - 1 + px) : tl.rx + dlx * (x0 - XS + px);
             const bool ok = rec < C::NREC && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
             p_pix[i] = ok ? (unsigned)(yy * a.W + xx) : (unsigned)(a.H * a.W);
         }
@@ -215,9 +223,14 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     auto issue_patch_piece = [&](int i, int c16) {
         if (ABL & 1) return;
         // (locals: see issue_w_piece)
-        const bool second = c16 >= a.nc16_a;               // uniform
-        const int soff = (second ? c16 - a.nc16_a : c16) * 64;
-        const int voff = (int)(p_pix[i] * (unsigned)((second ? a.x2_cs : a.x_cs) * 4) + p_q16);
+        const bool second = !S2 && c16 >= a.nc16_a;        // uniform
+        // S2: stage = parity * (channel groups) + channel group -- the 16-channel groups that share a 128-byte line of a pixel are
+        // consecutive stages; the same pixel of parity plane (a, b).  (H and W are even: a pixel of plane (0, 0) inside the image
+        // has its three neighbours inside too; the marker H W of a pixel outside stays out of range.)
+        const int ncc = nc16 >> 2, par = S2 ? c16 / ncc : 0, cc = S2 ? c16 - par * ncc : 0;
+        const int soff = S2 ? cc * 64 : (second ? c16 - a.nc16_a : c16) * 64;
+        const unsigned ppix = S2 ? p_pix[i] + (unsigned)((par >> 1) * a.W + (par & 1)) : p_pix[i];
+        const int voff = (int)(ppix * (unsigned)((second ? a.x2_cs : a.x_cs) * 4) + p_q16);
         lptr_t dst = (lptr_t)(sm + C::S0 + (wave + 8 * i) * 1024);
         // ONE fetch instruction on a selected resource (scalar selects), not one per branch: the compiler counts outstanding
         // fetches along every path, and two paths made its waits conservative (+3-4 % on every launch)
@@ -350,10 +363,9 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
             (void*)(a.y + (size_t)tl.n * a.Ho * a.Wo * a.y_cs), 0, a.Ho * a.Wo * a.y_cs * 4, 0x00020000);
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-            const int py = tl.ry + dly * (y0 + PT * pg + pt), px = tl.rx + dlx * (x0 + ln);
-            // stride 2: the stride-1 sum at input position 2 o + off IS output o (off = 1 - the SAME padding in front)
-            const bool inside = py < a.H && px < a.W && (a.stride == 1 || ((((py - a.off_y) | (px - a.off_x)) & 1) == 0 && py >= a.off_y && px >= a.off_x));
-            const int opy = a.stride == 1 ? py : (py - a.off_y) >> 1, opx = a.stride == 1 ? px : (px - a.off_x) >> 1;
+            const int py = tl.ry + dly * (y0 + PT * pg + pt), px = tl.rx + dlx * (x0 + ln);      // (S2: dly = dlx = 1, output coordinates)
+            const bool inside = py < a.Ho && px < a.Wo;
+            const int opy = py, opx = px;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 f32x4 o4[4];
@@ -462,6 +474,7 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     auto tap = [&](auto Rc, auto DXc, int g, int buf, bool more, bool fresh) {
         constexpr int R = decltype(Rc)::value, DX = decltype(DXc)::value;
         constexpr int NR = DX < 2 ? R : (R + 1) % 3, NDX = (DX + 1) % 3;
+        constexpr int NMU = (!S2 || (R >= 1 && DX >= 1)) ? NM : 0;       // S2: taps 0 / +1 of the parity plane only
         const int nbuf = (R == 2 && DX == 2) ? (buf ^ 1) : buf;
         const bool do_load = !(R == 2 && DX == 2) || more;
         // Placement of the fetch pieces, measured with per-tap s_memtime stamps (profiles/r04_exp_h2_tap_timeline*.txt): all weight
@@ -481,12 +494,12 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         constexpr int NEXA = DX == 0 ? C::APW : 0;
         constexpr int NEXP = (R == 2 && DX == 1) ? C::PPW : 0;
         constexpr int NEX = NEXA + NEXP > NEXC ? NEXA + NEXP : NEXC;
-        constexpr int NSLOT = NM > NL + NEX ? NM : NL + NEX;
+        constexpr int NSLOT = NMU > NL + NEX ? NMU : NL + NEX;
         f32x4 cvv[3];
         if (do_p && c2 == 0) patch_tile(t2);
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
-            if (i < NM) mfma_i(cur, i, fresh);
+            if (i < NMU) mfma_i(cur, i, fresh);
             if (i < NEXC && do_cv) cvv[i] = cv_read(CV0 + i);
             if (i < NL) {
                 if (do_load) load_i(nxt, i, nbuf, NR, NDX);
@@ -530,7 +543,7 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         H2_BAR();                          // ... everybody's; every wave is done with slot 2
         if (ABL & 2048) tk_bar += __builtin_readcyclecounter() - tk0;
         H2_STAMP(1);
-        if (fresh0) tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, g, buf, more, true);
+        if (fresh0 && !S2) tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, g, buf, more, true);
         else tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, g, buf, more, false);
         H2_STAMP(2);
         tap(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, g, buf, more, false);
@@ -545,7 +558,8 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         H2_STAMP(5);
         tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, g, buf, more, false);
         H2_STAMP(6);
-        tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, g, buf, more, false);
+        if (fresh0 && S2) tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, g, buf, more, true);      // (its first tap with products)
+        else tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, g, buf, more, false);
         H2_STAMP(7);
         tap(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, g, buf, more, false);
         H2_STAMP(8);
@@ -595,8 +609,11 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
 // ---------------------------------------------------------------- weight split + packing
 // packed[c16][tap row 3][cout tile of 32][dx 3][chunk 4: uh ch 0-7, uh 8-15, um' 0-7, um' 8-15][cout 32][8 fp16];
 // uh = fp16(w), um' = fp16((w - uh) * 2^11), both round-to-nearest; cin_map as in pwc_conv3x3_pack_f32.
+// s2: the stride-2 form -- Cin_phys = 4 x (the input's physical channels), stage = parity (channel groups) + channel group, tap (R, DX) of
+// parity (a, b) = w[2 (R - 1) + a, 2 (DX - 1) + b] (zero where R or DX is 0 or the index passes 2); cin_map over the INPUT's
+// physical channels.
 __global__ void conv3x3_h2_pack_kernel(const float* __restrict__ w, const int32_t* __restrict__ cin_map, int Cin,
-                                       int Cin_phys, int Cout, int nct, unsigned short* __restrict__ packed) {
+                                       int Cin_phys, int Cout, int nct, unsigned short* __restrict__ packed, int s2) {
     const size_t total = (size_t)(Cin_phys >> 4) * nct * 9 * 32 * 16;     // one thread per (c16, ct, tap, cout, channel)
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
@@ -608,11 +625,17 @@ __global__ void conv3x3_h2_pack_kernel(const float* __restrict__ w, const int32_
         r /= 9;
         const int ct = (int)(r % nct);
         const int c16 = (int)(r / nct);
-        const int cphys = c16 * 16 + ch;
+        const int ncc = Cin_phys >> 6, par = s2 ? c16 / ncc : 0;          // (s2: stage = parity * channel groups + channel group)
+        const int cphys = s2 ? (c16 - par * ncc) * 16 + ch : c16 * 16 + ch;
         const int clog = cin_map ? cin_map[cphys] : (cphys < Cin ? cphys : -1);
         const int co = ct * 32 + i;
+        int wtap = tap;
+        if (s2) {
+            const int R = tap / 3, DX = tap - 3 * R, dy = 2 * (R - 1) + (par >> 1), dx = 2 * (DX - 1) + (par & 1);
+            wtap = (R >= 1 && DX >= 1 && dy <= 2 && dx <= 2) ? dy * 3 + dx : -1;
+        }
         float u = 0.f;
-        if (clog >= 0 && clog < Cin && co < Cout) u = w[((size_t)tap * Cin + clog) * Cout + co];
+        if (wtap >= 0 && clog >= 0 && clog < Cin && co < Cout) u = w[((size_t)wtap * Cin + clog) * Cout + co];
         const _Float16 h = (_Float16)u;
         const _Float16 m = (_Float16)((u - (float)h) * 2048.f);
         const int tr = tap / 3, dx = tap - 3 * tr;
@@ -636,7 +659,24 @@ extern "C" int pwc_conv3x3_h2_pack_f32(const float* w_hwio, const int32_t* cin_m
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(conv3x3_h2_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, cin_map,
-                       Cin, Cin_phys, Cout, nct, reinterpret_cast<unsigned short*>(packed));
+                       Cin, Cin_phys, Cout, nct, reinterpret_cast<unsigned short*>(packed), 0);
+    return pwc_launch_status();
+}
+
+// Weights of the stride-2 form (pwc_conv3x3_h2_stride2_f32): Cin_phys = the input's physical channels (cin_map over them).
+extern "C" size_t pwc_conv3x3_h2_stride2_packed_floats(int Cin_phys, int Cout) {
+    return pwc_conv3x3_h2_packed_floats(4 * Cin_phys, Cout);
+}
+extern "C" int pwc_conv3x3_h2_stride2_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin, int Cin_phys,
+                                               int Cout, float* packed, pwc_stream_t stream) {
+    if (!w_hwio || !packed || Cin <= 0 || Cout <= 0 || Cin_phys < Cin) return PWC_EINVAL;
+    if (Cin_phys % 16) return PWC_EALIGN;
+    const int nct = (Cout + 31) / 32;
+    const size_t total = (size_t)(Cin_phys >> 2) * nct * 9 * 32 * 16;        // (4 Cin_phys / 16 stages)
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv3x3_h2_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, cin_map,
+                       Cin, 4 * Cin_phys, Cout, nct, reinterpret_cast<unsigned short*>(packed), 1);
     return pwc_launch_status();
 }
 
@@ -724,7 +764,7 @@ extern "C" int pwc_conv3x3_h2_supported(int N, int H, int W, int Cin_phys, int C
 
 static unsigned* h2_debug_counters = nullptr;      // harness only
 
-template <int CT, int PT, int WCG, int ABL, int XS = 1>
+template <int CT, int PT, int WCG, int ABL, int XS = 1, bool S2 = false>
 static int h2_launch(H2Args& a, int hs, int ws, float* workspace, size_t workspace_floats, hipStream_t stream) {
     typedef H2Cfg<CT, PT, WCG, XS> C;
     a.tiles_x = (ws + 31) / 32; a.tiles_y = (hs + C::TR - 1) / C::TR; a.ncb = a.Cout / (32 * C::NCT);
@@ -743,10 +783,10 @@ static int h2_launch(H2Args& a, int hs, int ws, float* workspace, size_t workspa
     }
     static PwcDevOnce attr_once;
     if (pwc_first_on_device(&attr_once)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2_kernel<CT, PT, WCG, ABL, XS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2_kernel<CT, PT, WCG, ABL, XS, S2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     }
-    hipLaunchKernelGGL((conv3x3_h2_kernel<CT, PT, WCG, ABL, XS>), dim3((unsigned)grid), dim3(512), C::LDS, stream, a);
+    hipLaunchKernelGGL((conv3x3_h2_kernel<CT, PT, WCG, ABL, XS, S2>), dim3((unsigned)grid), dim3(512), C::LDS, stream, a);
     return pwc_launch_status();
 }
 
@@ -764,31 +804,37 @@ static int h2_run(const float* x, int x_cs, const float* packed_w, const float* 
     }
     if (reinterpret_cast<uintptr_t>(status) & 7u) return PWC_EALIGN;
     if (N <= 0 || H <= 0 || W <= 0 || Cin_phys <= 0 || Cout <= 0 || dilation < 1 || (stride != 1 && stride != 2)) return PWC_EINVAL;
-    if (Cin_phys % 16 || Cout % 32 || Cout > H2_MAX_COUT || (stride == 2 && dilation != 1)) return PWC_EUNSUPPORTED;
+    if (Cin_phys % 16 || Cout % 32 || Cout > H2_MAX_COUT || (stride == 2 && (dilation != 1 || (H & 1) || (W & 1) || x2))) return PWC_EUNSUPPORTED;
     if ((!x2 && x_cs < Cin_phys) || y_cs < Cout) return PWC_EINVAL;
     if ((x_cs & 3) || (y_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(y) || !pwc_aligned16(packed_w) || !pwc_aligned16(bias) ||
         !pwc_aligned16(workspace))
         return PWC_EALIGN;
-    if ((long)H * W * x_cs * 4 >= (long)H2_OOB || (long)H * W * y_cs * 4 >= (long)H2_OOB) return PWC_ERANGE;
+    if (((long)H * W + W + 2) * x_cs * 4 >= (long)H2_OOB || (long)H * W * y_cs * 4 >= (long)H2_OOB) return PWC_ERANGE;
     H2Args a;
     a.x = x; a.wp = packed_w; a.bias = bias; a.y = y; a.x_cs = x_cs; a.y_cs = y_cs;
     a.N = N; a.H = H; a.W = W; a.Cin_phys = Cin_phys; a.Cout = Cout; a.apply_act = apply_act; a.slope = slope;
-    const H2Geo geo = h2_geometry(H, W, dilation, Cout);
+    // stride 2: the launch is laid out over the OUTPUT (H / 2 x W / 2) and walks 4 x Cin_phys / 16 (channel group, parity) stages
+    const bool s2 = stride == 2;
+    a.Ho = s2 ? H / 2 : H; a.Wo = s2 ? W / 2 : W;
+    if (s2) a.Cin_phys = 4 * Cin_phys;
+    const H2Geo geo = h2_geometry(a.Ho, a.Wo, dilation, Cout);
     a.dil_y = geo.dy; a.dil_x = geo.dx;
     a.dbg = h2_debug_counters;
-    a.x2 = x2; a.x2_cs = x2_cs; a.nc16_a = x2 ? Cin_a_phys >> 4 : Cin_phys >> 4; a.status = status;
-    a.stride = stride; a.Ho = H; a.Wo = W; a.off_y = a.off_x = 0;
-    if (stride == 2) {
-        int before = 0;
-        pwc_same_pad(H, 2, 1, &a.Ho, &before); a.off_y = 1 - before;
-        pwc_same_pad(W, 2, 1, &a.Wo, &before); a.off_x = 1 - before;
-    }
+    a.x2 = x2; a.x2_cs = x2_cs; a.nc16_a = x2 ? Cin_a_phys >> 4 : a.Cin_phys >> 4; a.status = status;
     const int hs = geo.hs, ws = geo.ws;
-    if (variant == 0) variant = h2_plan(N, H, W, Cin_phys, Cout, dilation, nullptr);
+    if (variant == 0) variant = h2_plan(N, a.Ho, a.Wo, a.Cin_phys, Cout, dilation, nullptr);
     if (variant < 1 || variant > 5) return PWC_EUNSUPPORTED;
     if (Cout % h2_variant(variant).couts) return PWC_EUNSUPPORTED;
+    if (s2) {
+        switch (variant) {
+            case 1: return h2_launch<2, 2, 2, ABL, 1, true>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);
+            case 2: return h2_launch<2, 2, 1, ABL, 1, true>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);
+            case 3: return h2_launch<3, 1, 1, ABL, 1, true>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);
+            case 4: return h2_launch<1, 2, 1, ABL, 1, true>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);
+            default: return h2_launch<1, 2, 2, ABL, 1, true>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);
+        }
+    }
     if (geo.xs == 2) {
-        if (stride != 1) return PWC_EUNSUPPORTED;
         switch (variant) {
             case 1: return h2_launch<2, 2, 2, ABL, 2>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);
             case 3: return h2_launch<3, 1, 1, ABL, 2>(a, hs, ws, workspace, workspace_floats, (hipStream_t)stream);
@@ -833,15 +879,23 @@ extern "C" int pwc_conv3x3_h2_ex_f32(const float* x, int x_cs, int Cin_a_phys, c
                      workspace, workspace_floats, 1, x2, x2_cs, Cin_a_phys, status);
 }
 
-// Stride 2 ('SAME', dilation 1: the extractor's down-sampling layers, reference modules.py:57-60): the launch of the stride-1
-// convolution over the (H, W) input that stores only the sums a stride-2 convolution has (y is (N, ceil(H/2), ceil(W/2), y_cs)).
-// Four times the matrix work of a strided kernel: measured in the forward (batch 8, 16 -> 32 at 224 x 512 / 32 -> 64 at 112 x 256 /
-// 64 -> 96 at 56 x 128, 16 images each) 73.7 / 63.0 / 48.7 us against 64.0 / 59.4 / 42.9 us of pwc_conv3x3_f32 -- NOT the faster
-// one, so _supported says 0 everywhere and nothing routes to it; the entry point is correct (tests) and stays for the strided
-// operand image that would make it pay (even and odd columns in separate planes: DESIGN.md section 8).
+// Stride 2 ('SAME', dilation 1, even H and W: the extractor's down-sampling layers, reference modules.py:57-60): the kernel's S2
+// form (parity planes, see the kernel).  packed_w: pwc_conv3x3_h2_stride2_pack_f32; y is (N, H / 2, W / 2) at channel stride
+// y_cs; workspace: pwc_conv3x3_h2_stride2_workspace_floats.  _supported: 1 where it is the faster kernel for the shape.  Measured
+// in the forward (batch 8 = 16 images; profiles/r05_timeline_stride2.txt), us, S2 against pwc_conv3x3_f32 (fp32 MFMA):
+//     16 -> 32 at 224 x 512: 61.0 - 62.3 / 64.8     32 -> 64 at 112 x 256: 45.7 - 47.0 / 57.8
+//     64 -> 96 at  56 x 128: 49.4 - 50.3 / 42.9     96 -> 128 at 28 x 64:  31.7 - 32.2 / 30.5
+// A stage carries 4 taps of matrix instructions instead of 9 and costs its fixed 5 - 6 us all the same (three parts, each waiting
+// for weights that were requested one -- now nearly empty -- part earlier): with 4 C / 16 stages per tile the form pays only while
+// the channel loop is short.  So: inputs of up to 32 channels.
 extern "C" int pwc_conv3x3_h2_stride2_supported(int N, int H, int W, int Cin_phys, int Cout) {
-    (void)N; (void)H; (void)W; (void)Cin_phys; (void)Cout;
-    return 0;
+    if (H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cin_phys % 16 || Cin_phys > 32) return 0;
+    return pwc_conv3x3_h2_supported(N, H / 2, W / 2, 4 * Cin_phys, Cout, 1);
+}
+
+extern "C" size_t pwc_conv3x3_h2_stride2_workspace_floats(int N, int H, int W, int Cin_phys, int Cout) {
+    if ((H & 1) || (W & 1)) return 0;
+    return pwc_conv3x3_h2_workspace_floats(N, H / 2, W / 2, 4 * Cin_phys, Cout, 1);
 }
 
 extern "C" int pwc_conv3x3_h2_stride2_f32(const float* x, int x_cs, const float* packed_w, const float* bias, float* y,

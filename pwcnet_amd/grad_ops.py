@@ -161,9 +161,9 @@ def conv3x3_raw(x, w_hwio, bias, y, stride=1, dilation=1, slope=None, keep=None)
     use_mfma = cout % 16 == 0 and x.C % 16 == 0 and x.cs % 4 == 0 and x.ptr % 16 == 0
     h2_ok = use_mfma and F16X2 and cout % 32 == 0 and y.cs % 4 == 0 and y.ptr % 16 == 0
     if h2_ok and stride == 2 and dilation == 1 and L.pwc_conv3x3_h2_stride2_supported(x.N, x.H, x.W, x.C, cout):
-        packed = torch.empty((L.pwc_conv3x3_h2_packed_floats(x.C, cout),), dtype=torch.float32, device=dev)
-        _lib.check(L.pwc_conv3x3_h2_pack_f32(_p(w_hwio.data_ptr()), None, x.C, x.C, cout, _p(packed.data_ptr()), s), "h2 pack")
-        wsf = L.pwc_conv3x3_h2_workspace_floats(x.N, x.H, x.W, x.C, cout, 1)
+        packed = torch.empty((L.pwc_conv3x3_h2_stride2_packed_floats(x.C, cout),), dtype=torch.float32, device=dev)
+        _lib.check(L.pwc_conv3x3_h2_stride2_pack_f32(_p(w_hwio.data_ptr()), None, x.C, x.C, cout, _p(packed.data_ptr()), s), "h2 stride-2 pack")
+        wsf = L.pwc_conv3x3_h2_stride2_workspace_floats(x.N, x.H, x.W, x.C, cout)
         ws = _h2_workspace(dev, wsf) if wsf else None
         _lib.check(L.pwc_conv3x3_h2_stride2_f32(_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.data_ptr()), _p(y.ptr), y.cs,
                                                 x.N, x.H, x.W, x.C, cout, act, sl,

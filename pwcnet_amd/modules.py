@@ -346,23 +346,24 @@ class _ConvRunner:
                     and L.pwc_conv3x3_h2_stride2_supported(x.N, x.H, x.W, x.C, cout))
         if use_h2 or use_h2s2:
             # direct convolution on the F16 matrix pipe, fp32 operands as two-term fp16 splits (conv3x3_h2.hip); stride 2 = the
-            # stride-1 launch that stores every second sum
-            key = (name, "h2", c_phys, None if cin_map is None else cin_map.tobytes(), self.store.version)
+            # same kernel over the input's four parity planes (round 5)
+            key = (name, "h2s2" if use_h2s2 else "h2", c_phys, None if cin_map is None else cin_map.tobytes(), self.store.version)
             packed = cache.get(key)
             if packed is None:
-                nfl = L.pwc_conv3x3_h2_packed_floats(c_phys, cout)
+                nfl = (L.pwc_conv3x3_h2_stride2_packed_floats if use_h2s2 else L.pwc_conv3x3_h2_packed_floats)(c_phys, cout)
                 packed = torch.empty((nfl,), dtype=torch.float32, device=kern.value.device)
                 cm = None
                 if cin_map is not None:
                     assert len(cin_map) == c_phys
                     cm = torch.from_numpy(np.ascontiguousarray(cin_map, np.int32)).to(kern.value.device)
-                _lib.check(L.pwc_conv3x3_h2_pack_f32(_p(kern.value.data_ptr()),
-                                                     _p(cm.data_ptr()) if cm is not None else None,
-                                                     cin, c_phys, cout, _p(packed.data_ptr()), s), "conv3x3 h2 pack")
+                _lib.check((L.pwc_conv3x3_h2_stride2_pack_f32 if use_h2s2 else L.pwc_conv3x3_h2_pack_f32)(
+                    _p(kern.value.data_ptr()), _p(cm.data_ptr()) if cm is not None else None,
+                    cin, c_phys, cout, _p(packed.data_ptr()), s), "conv3x3 h2 pack")
                 cache[key] = packed
             _keep(packed, y_t)
             # more tiles than CUs: one workgroup per CU with an equal share of the (tile, stage) sequence (stream-K)
-            wsf = L.pwc_conv3x3_h2_workspace_floats(x.N, x.H, x.W, c_phys, cout, dilation)
+            wsf = (L.pwc_conv3x3_h2_stride2_workspace_floats(x.N, x.H, x.W, c_phys, cout) if use_h2s2 else
+                   L.pwc_conv3x3_h2_workspace_floats(x.N, x.H, x.W, c_phys, cout, dilation))
             ws = _h2_workspace(kern.value.device, wsf) if wsf and getattr(self.owner, "f16x2_stream_k", True) else None
             if ws is not None:
                 _keep(ws)
@@ -384,8 +385,9 @@ class _ConvRunner:
                         x.N, x.H, x.W, x.C, cout, act, sl) + wsa + (s,)
             _launch(fn, args, f"conv3x3_h2 {name}", "conv3x3_h2_kernel",
                     2.0 * x.N * Ho * Wo * 9 * cin * cout, 4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout),
-                    # executed: three fp16 products per multiply-add of the stride-1 launch, per physical input channel
-                    exec_flops=3.0 * 2.0 * x.N * x.H * x.W * 9 * c_phys * cout)
+                    # executed: three fp16 products per multiply-add, per physical input channel (stride 2: 16 products per
+                    # output and channel -- four taps on each of the four parity planes)
+                    exec_flops=3.0 * 2.0 * x.N * Ho * Wo * (16 if use_h2s2 else 9) * c_phys * cout)
         elif use_wino4:
             # F(4x4,3x3): 36 multiplies per 4x4 outputs (the big full-resolution layers)
             key = (name, "wino4", x.C, None if cin_map is None else cin_map.tobytes(), self.store.version)

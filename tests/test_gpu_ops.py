@@ -355,30 +355,66 @@ def test_conv_f16x2_direct_stream_k(pa, N, H, W, cin, cout, dil):
         close(first[i:i + 1], orc.conv3x3(x[i:i + 1], k, b, 1, dil, 0.1))
 
 
-@pytest.mark.parametrize("N,H,W,cin,cout", [(2, 64, 96, 16, 32), (1, 33, 47, 32, 64), (2, 50, 70, 64, 96), (16, 112, 256, 32, 64),
-                                            (3, 31, 64, 48, 128)])
+@pytest.mark.parametrize("N,H,W,cin,cout", [(2, 64, 96, 16, 32), (1, 34, 46, 32, 64), (2, 50, 70, 64, 96), (16, 112, 256, 32, 64),
+                                            (3, 30, 64, 48, 128), (16, 224, 512, 16, 32), (1, 2, 2, 16, 32)])
 def test_conv_f16x2_direct_stride2_vs_oracle(pa, N, H, W, cin, cout):
-    """pwc_conv3x3_h2_stride2_f32: TF 'SAME' stride-2 convolution (even sizes pad bottom / right only, odd sizes one pixel on
-    each side) as the stride-1 launch that stores every second sum; strided output with untouched neighbours; with and
-    without the stream-K workspace."""
+    """pwc_conv3x3_h2_stride2_f32 (round 5: the F16-pipe kernel over the input's four parity planes): TF 'SAME' stride-2 convolution
+    of even sizes (pad bottom / right only: the last row / column of taps falls outside) incl. BASELINE configs[1]'s first two
+    down-sampling layers at full size; ragged tiles, strided output with untouched neighbours, with and without the stream-K
+    workspace, padded / permuted input channels; odd sizes are refused (the fp32 kernel takes them)."""
     from pwcnet_amd import _lib
     L = _lib.lib()
     x = rnd((N, H, W, cin), 371)
     k = rnd((3, 3, cin, cout), 372) * float(1.0 / np.sqrt(9 * cin))
     b = rnd((cout,), 373) * 0.1
     xg, kg, bg = gpu(x), gpu(k), gpu(b)
-    packed = torch.empty(L.pwc_conv3x3_h2_packed_floats(cin, cout), device="cuda")
-    _lib.check(L.pwc_conv3x3_h2_pack_f32(_p(kg), None, cin, cin, cout, _p(packed), None))
-    Ho, Wo = -(-H // 2), -(-W // 2)
-    exp = orc.conv3x3(x, k, b, 2, 1, 0.1)
-    assert exp.shape == (N, Ho, Wo, cout)
-    for ws in (None, h2_workspace(N, H, W, cin, cout, 1)):
+    packed = torch.empty(L.pwc_conv3x3_h2_stride2_packed_floats(cin, cout), device="cuda")
+    _lib.check(L.pwc_conv3x3_h2_stride2_pack_f32(_p(kg), None, cin, cin, cout, _p(packed), None))
+    Ho, Wo = H // 2, W // 2
+    big = N * H * W > 200000
+    exp = None if big else orc.conv3x3(x, k, b, 2, 1, 0.1)
+    n_ws = L.pwc_conv3x3_h2_stride2_workspace_floats(N, H, W, cin, cout)
+    wss = [None] + ([torch.full((n_ws,), -1, dtype=torch.int32, device="cuda").view(torch.float32)] if n_ws else [])
+    outs = []
+    for ws in wss:
         y = torch.full((N, Ho, Wo, cout + 8), -7.0, device="cuda")
         wp, wn = (None, 0) if ws is None else (_p(ws), ws.numel())
         _lib.check(L.pwc_conv3x3_h2_stride2_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout + 8, N, H, W, cin, cout, 1, 0.1, wp, wn, None))
         torch.cuda.synchronize()
-        close(y[..., :cout], exp)
+        if big:
+            for i in (0, N - 1):
+                close(y[i:i + 1, ..., :cout], orc.conv3x3(x[i:i + 1], k, b, 2, 1, 0.1))
+            assert bool(torch.isfinite(y).all())
+        else:
+            close(y[..., :cout], exp)
         assert float(y[..., cout:].min()) == -7.0 and float(y[..., cout:].max()) == -7.0
+        outs.append(y)
+    if big:
+        assert len(outs) == 1 or float((outs[0] - outs[1]).abs().max()) <= 1e-5
+    # physical layout: the input's channels padded / permuted (cin_map), channel stride beyond them
+    if not big:
+        cs = cin + 16
+        rs = np.random.RandomState(7)
+        pos = np.sort(rs.choice(cs, cin, replace=False))
+        cmap = np.full((cs,), -1, np.int32)
+        cmap[pos] = np.arange(cin, dtype=np.int32)
+        xp = rnd((N, H, W, cs + 4), 374)
+        xp[..., pos] = x
+        cm = torch.from_numpy(cmap).cuda()
+        packed2 = torch.empty(L.pwc_conv3x3_h2_stride2_packed_floats(cs, cout), device="cuda")
+        _lib.check(L.pwc_conv3x3_h2_stride2_pack_f32(_p(kg), _p(cm), cin, cs, cout, _p(packed2), None))
+        y = torch.full((N, Ho, Wo, cout), -7.0, device="cuda")
+        xpg = gpu(xp)
+        _lib.check(L.pwc_conv3x3_h2_stride2_f32(_p(xpg), cs + 4, _p(packed2), _p(bg), _p(y), cout, N, H, W, cs, cout, 1, 0.1, None, 0, None))
+        torch.cuda.synchronize()
+        close(y, exp)
+    # odd sizes: not this kernel's
+    y = torch.empty((N, (H + 2) // 2, Wo, cout), device="cuda")
+    assert L.pwc_conv3x3_h2_stride2_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout, N, H - 1, W, cin, cout, 1, 0.1, None, 0, None) == -4
+    assert L.pwc_conv3x3_h2_stride2_supported(N, H - 1, W, cin, cout) == 0
+    # the extractor's layers of BASELINE configs[1] (16 images) that go to it, and the one that does not (7 x 16 outputs)
+    assert L.pwc_conv3x3_h2_stride2_supported(16, 224, 512, 16, 32) == 1 and L.pwc_conv3x3_h2_stride2_supported(16, 112, 256, 32, 64) == 1
+    assert L.pwc_conv3x3_h2_stride2_supported(16, 14, 32, 128, 192) == 0 and L.pwc_conv3x3_h2_stride2_supported(16, 56, 128, 64, 96) == 0
 
 
 @pytest.mark.parametrize("N,H,W,xcs,ycs", [(2, 50, 70, 16, 16), (1, 16, 32, 16, 16), (3, 33, 47, 20, 24), (1, 97, 130, 16, 16),

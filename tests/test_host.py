@@ -62,6 +62,52 @@ def test_effective_streams_rule():
     assert rule(four, (8, 64, 64, 3)) == 4 and rule(four, (6, 64, 64, 3)) == 1 and rule(four, (2, 64, 64, 3)) == 1
 
 
+def test_side_stream_probe_inconclusive_falls_back_to_one_stream(monkeypatch):
+    """eight ranks of a node run the side-stream probe at the same time (one per GPU, sharing the host).  When the
+    probe cannot tell -- the spin kernel did not spin, or every candidate looks as if it shared the caller's queue -- the decision
+    must be "single stream" with a report that says why, never an un-vetted side stream and never an exception.  No GPU here: the
+    streams, events and the probe kernels are stand-ins; eight threads run the decision concurrently."""
+    import threading
+    import types
+    import torch
+    from pwcnet_amd import model as M
+
+    class FakeStream:
+        n = 0
+        lock = threading.Lock()
+
+        def __init__(self, device=None):
+            with FakeStream.lock:
+                FakeStream.n += 1
+                self.cuda_stream = 1000 + FakeStream.n
+    fake_cuda = types.SimpleNamespace(Stream=FakeStream, synchronize=lambda *a, **k: None, is_current_stream_capturing=lambda: False)
+    fake_torch = types.SimpleNamespace(cuda=fake_cuda, zeros=lambda n, device=None: torch.zeros(n))
+    monkeypatch.setattr(M, "torch", fake_torch)
+    verdicts = {"stuck": (True, 0.001, 0.001),        # the spin did not spin: no verdict possible
+                "shared": (True, 1.0, 1.0)}           # every candidate finishes behind the spin: all share the caller's queue
+    for kind, answer in verdicts.items():
+        monkeypatch.setattr(M, "_shares_queue", lambda dev, a, b, probe, spin_ticks=0, _a=answer: _a)
+        out = [None] * 8
+        def run(i):
+            out[i] = M._pick_side_streams("cuda:%d" % i, FakeStream(), 1)
+        th = [threading.Thread(target=run, args=(i,)) for i in range(8)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        for i, (picked, report) in enumerate(out):
+            assert picked is None, (kind, i)
+            assert report["verdict"] == "only 0 of 1 vetted: single stream" and report["picked"] == []
+            assert report["rejected"] >= 8 and report["device"] == "cuda:%d" % i and len(report["probes"]) >= 8
+    # ... and a clean probe picks the first candidate
+    monkeypatch.setattr(M, "_shares_queue", lambda dev, a, b, probe, spin_ticks=0: (False, 1.0, 0.01))
+    picked, report = M._pick_side_streams("cuda:0", FakeStream(), 1)
+    assert picked is not None and len(picked) == 1 and report["verdict"] == "vetted"
+    # the model then runs the batch on ONE stream: the forward with no vetted side stream returns None from the side-stream path
+    net = types.SimpleNamespace(_side_streams={}, side_stream_report=None)
+    monkeypatch.setattr(M, "_shares_queue", lambda dev, a, b, probe, spin_ticks=0: (True, 0.001, 0.001))
+    streams, rep = M._pick_side_streams("cuda:0", FakeStream(), 1)
+    assert streams is None and "single stream" in rep["verdict"]
+
+
 def test_product_never_imports_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "pwcnet_amd")):
         for f in files:
@@ -240,8 +286,12 @@ dist.init_process_group("gloo")
 r, w = dist.get_rank(), dist.get_world_size()
 steps, per_gpu_batch = 20, 8
 # what bench.py hands to the gather on every rank: its pairs and ITS elapsed seconds (rank 5 is the slowest)
-mine = {"pairs": float(per_gpu_batch * steps), "seconds": 0.070 + 0.001 * r + (0.010 if r == 5 else 0.0)}
+mine = {"pairs": float(per_gpu_batch * steps), "seconds": 0.070 + 0.001 * r + (0.010 if r == 5 else 0.0),
+        "issue_seconds": 0.010 + 0.001 * r}
 stats = sharding.gather_stats(mine, dist, "cpu")
+# (bench.py prints every rank's ms per step beside the job's: the straggler is rank 5, visibly)
+per_rank_ms = [1e3 * st["seconds"] / steps for st in stats]
+assert len(per_rank_ms) == 8 and max(range(8), key=lambda i: per_rank_ms[i]) == 5
 value, ms_per_step, total, n = sharding.aggregate_throughput(stats, steps)
 assert n == w == 8 and total == 8 * per_gpu_batch * steps
 slowest = 0.070 + 0.005 + 0.010
