@@ -362,7 +362,12 @@ __global__ __launch_bounds__(256) void warp_grad_fix_finish_kernel(const long lo
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long p = i / C;
         const int c = (int)(i - p * C);
-        dx[p * dx_cs + c] += poisoned ? __builtin_nanf("") : (float)((double)fix[i] * (1.0 / 68719476736.0));
+        // a sum at or beyond 2^61 (|dx| >= 2^25 from contributions that are each below 2^26) is where the 64-bit fixed-point
+        // sum wraps: many in-range contributions to one cell can get there without tripping the per-contribution poison
+        //  -- such a cell becomes NaN instead of a finite wrong value
+        const long long v = fix[i];
+        const bool wild = v >= (1LL << 61) || v <= -(1LL << 61);
+        dx[p * dx_cs + c] += (poisoned || wild) ? __builtin_nanf("") : (float)((double)v * (1.0 / 68719476736.0));
     }
 }
 

@@ -10,7 +10,12 @@ import torch
 from . import _lib
 from .modules import View, _p, _wino_pays, _h2_workspace, as_view
 
-F16X2 = True      # training forward + data gradient: route the layers pwc_conv3x3_h2_supported names to conv3x3_h2
+F16X2 = True      # training FORWARD: route the layers pwc_conv3x3_h2_supported names to conv3x3_h2 (activations of order 1)
+# ... and the DATA GRADIENT (dy as the split operand): off by default.  The two-term fp16 split is exact to 22 bits
+# only while both terms are normal fp16 numbers, i.e. for |x| >= ~2^-13; an upstream gradient of 1e-7 splits into subnormals with
+# an absolute floor of ~1.5e-11 -- 3e-4 relative where fp32 carries 6e-8 -- and the reference is plain fp32.  Trainer(f16x2_dgrad=
+# True) (or this flag) turns it on for runs whose gradients are known to stay large (-7 % step time at batch 8).
+F16X2_DGRAD = False
 
 
 def _L():
@@ -144,9 +149,10 @@ def conv3x3_wgrad(x, dy, dw, cin, stride=1, dilation=1, cin_map=None, accumulate
                                        int(dilation), _p(ws.data_ptr()), ws.numel(), _s()), "conv3x3_wgrad")
 
 
-def conv3x3_raw(x, w_hwio, bias, y, stride=1, dilation=1, slope=None, keep=None):
+def conv3x3_raw(x, w_hwio, bias, y, stride=1, dilation=1, slope=None, keep=None, f16x2=None):
     """y = conv3x3_same(x, w_hwio) [+ bias] [leaky_relu] on the forward kernels; w_hwio (3,3,x.C,y.C) is given in
-    the PHYSICAL channel order of x.  Packed weights are temporaries (appended to `keep`)."""
+    the PHYSICAL channel order of x.  Packed weights are temporaries (appended to `keep`).  f16x2: may the F16-pipe kernels
+    take it (None: the module's F16X2)."""
     L = _L()
     s = _s()
     dev = w_hwio.device
@@ -159,7 +165,7 @@ def conv3x3_raw(x, w_hwio, bias, y, stride=1, dilation=1, slope=None, keep=None)
     w_hwio = w_hwio.contiguous()
     tmp = [w_hwio, bias]
     use_mfma = cout % 16 == 0 and x.C % 16 == 0 and x.cs % 4 == 0 and x.ptr % 16 == 0
-    h2_ok = use_mfma and F16X2 and cout % 32 == 0 and y.cs % 4 == 0 and y.ptr % 16 == 0
+    h2_ok = use_mfma and (F16X2 if f16x2 is None else f16x2) and cout % 32 == 0 and y.cs % 4 == 0 and y.ptr % 16 == 0
     if h2_ok and stride == 2 and dilation == 1 and L.pwc_conv3x3_h2_stride2_supported(x.N, x.H, x.W, x.C, cout):
         packed = torch.empty((L.pwc_conv3x3_h2_stride2_packed_floats(x.C, cout),), dtype=torch.float32, device=dev)
         _lib.check(L.pwc_conv3x3_h2_stride2_pack_f32(_p(w_hwio.data_ptr()), None, x.C, x.C, cout, _p(packed.data_ptr()), s), "h2 stride-2 pack")
@@ -215,13 +221,13 @@ def conv3x3_dgrad(dy, w_hwio_phys, dx, stride=1, dilation=1, keep=None, dy_tenso
     dev = w_hwio_phys.device
     wt = torch.flip(w_hwio_phys, dims=(0, 1)).permute(0, 1, 3, 2).contiguous()      # (3,3,Cout,Cin_phys)
     if stride == 1:
-        return conv3x3_raw(dy, wt, None, dx, 1, dilation, None, keep)
+        return conv3x3_raw(dy, wt, None, dx, 1, dilation, None, keep, f16x2=F16X2_DGRAD)
     assert stride == 2 and dilation == 1 and dx.H == 2 * dy.H and dx.W == 2 * dy.W, "stride-2 dgrad: even input sizes"
     assert dy_tensor is not None and tuple(dy_tensor.shape) == (dy.N, dy.H, dy.W, dy.C)
     up = torch.zeros((dy.N, dx.H, dx.W, dy.C), dtype=torch.float32, device=dev)
     up.view(dy.N, dy.H, 2, dy.W, 2, dy.C)[:, :, 1, :, 1, :] = dy_tensor
     uv = View(up.data_ptr(), dy.C, dy.N, dx.H, dx.W, dy.C)
-    tmp = conv3x3_raw(uv, wt, None, dx, 1, 1, None, keep)
+    tmp = conv3x3_raw(uv, wt, None, dx, 1, 1, None, keep, f16x2=F16X2_DGRAD)
     if keep is not None:
         keep.append(up)
     return tmp + [up]

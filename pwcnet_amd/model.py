@@ -395,7 +395,9 @@ class PWCDCNet(object):
             while len(self._eager_buffers) > self.max_plans:
                 self._eager_buffers.popitem(last=False)
             return self._hand_over(self._forward(iv0, iv1, dev, with_features), into)
-        key = (iv0[1:], str(dev), stream, bool(with_features), self.store.version)
+        # (the alignment of the frames is part of the key: the fused level-1 launch of the extractor takes 16-byte aligned
+        # frames only, and a plan recorded with it must not be replayed on a view that is not -- ADVICE r4)
+        key = (iv0[1:], str(dev), stream, bool(with_features), self.store.version, iv0.ptr % 16, iv1.ptr % 16)
         plan = self._plans.get(key)
         if plan is not None:
             self._plans.move_to_end(key)
@@ -430,7 +432,7 @@ class PWCDCNet(object):
                 elif arg.value in out_ptrs:
                     plan.patch.setdefault(out_ptrs[arg.value], []).append((ci, ai))
         plan.outputs = outputs
-        for k in [k for k in self._plans if k[-1] != self.store.version]:
+        for k in [k for k in self._plans if k[4] != self.store.version]:
             del self._plans[k]
         self._plans[key] = plan
         while len(self._plans) > self.max_plans:

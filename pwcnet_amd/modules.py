@@ -777,7 +777,7 @@ class CostVolumeLayer(_Module):
                     f0.N, f0.H, f0.W, f0.C, self.s_range, 0.1)
             _launch(L.pwc_warp_cost_volume_concat_h2_f32 if h2 else L.pwc_warp_cost_volume_concat_f32, args + (s,),
                     "warp_cost_volume_concat" if flow is not None else "cost_volume_concat",
-                    f"cost_volume_mfma_kernel<C{f0.C}{',warp' if flow is not None else ''}{',f16x2' if h2 else ''}>", flops,
+                    f"cost_volume_{'h2' if h2 else 'mfma'}_kernel<C{f0.C}{',warp' if flow is not None else ''}>", flops,
                     # (2C+81) or fused (2C+2+81) bytes per pixel; the f0 concat copy is not credited
                     4.0 * npix * (2 * f0.C + D + (2 if flow is not None else 0)))
             return

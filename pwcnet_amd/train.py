@@ -62,8 +62,11 @@ class Trainer:
 
     def __init__(self, num_levels=6, search_range=4, warp_type="bilinear", use_dc=False, output_level=4,
                  name="pwcdcnet", weights=(0.32, 0.08, 0.02, 0.01, 0.005), gamma=0.0004, lr=1e-4, lr_scheduling=True,
-                 seed=0, device="cuda", dist=None, loss="multiscale", epsilon=0.01, q=0.4):
+                 seed=0, device="cuda", dist=None, loss="multiscale", epsilon=0.01, q=0.4, f16x2=True, f16x2_dgrad=False):
         assert loss in ("multiscale", "robust"), loss
+        # the F16-pipe convolution kernels (operands as fp16 pairs) in the forward / in the data gradient: grad_ops.F16X2,
+        # grad_ops.F16X2_DGRAD (the reasons for the defaults are there); applied at every step()
+        self.f16x2, self.f16x2_dgrad = bool(f16x2), bool(f16x2_dgrad)
         self.use_dc, self.loss, self.epsilon, self.q = bool(use_dc), loss, float(epsilon), float(q)
         assert warp_type == "bilinear", "training needs the bilinear warp"
         assert num_levels == 6 and search_range == 4 and output_level < num_levels
@@ -143,6 +146,7 @@ class Trainer:
 
     def forward(self, images_0, images_1):
         """Returns flows_pyramid (list of 5 (N,h,w,2) tensors, px/20 units) and keeps the activations."""
+        G.F16X2, G.F16X2_DGRAD = self.f16x2, self.f16x2_dgrad
         dev = self.device
         self._keep = []
         N, H, W, _ = images_0.shape
@@ -301,6 +305,7 @@ class Trainer:
     def backward(self, flows_gt):
         """Gradients of the level losses (losses.py:15-32 / :34-48) w.r.t. every variable, into self.grads (the
         gamma * l2_loss term is applied by the optimiser kernel)."""
+        G.F16X2, G.F16X2_DGRAD = self.f16x2, self.f16x2_dgrad
         dev = self.device
         N = flows_gt.shape[0]
         gt = View(flows_gt.data_ptr(), 2, N, flows_gt.shape[1], flows_gt.shape[2], 2)

@@ -44,6 +44,7 @@ if len(sys.argv) > 2:
                      "a whole batch-8 launch); calibration profiles/r04_pmc_calibration.txt",
            "kernels": {k: {"launches": v[0], "hbm_read_bytes_per_launch": v[1] / v[0], "hbm_write_bytes_per_launch": v[2] / v[0]}
                        for k, v in fam.items()}}
-    if "mfma_busy" in old:
-        out["mfma_busy"] = old["mfma_busy"]
+    for k, v in old.items():            # (the other tables of the file: mfma_busy, op_leg, ...)
+        if k not in out:
+            out[k] = v
     json.dump(out, open(sys.argv[2], "w"), indent=1)

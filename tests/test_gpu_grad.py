@@ -233,6 +233,34 @@ def test_conv_wgrad_and_dgrad(go, stride, dil, H, W, cin, cout):
         close(dx, xt.grad, rel=3e-5)
 
 
+@pytest.mark.parametrize("scale", [1.0, 1e-6, 1e-8])
+def test_conv_dgrad_of_small_gradients(go, scale):
+    """upstream gradients of 1e-6 .. 1e-8 (what a multiscale loss averaged over a batch hands to the deep layers) at a
+    shape the F16-pipe kernel would take (8 x 56 x 128, 128 -> 128).  The data gradient runs on the fp32 kernels by default
+    (grad_ops.F16X2_DGRAD = False) and meets a float64 convolution at fp32 accuracy at every scale; with the split kernel
+    switched on the error grows as the scale falls (the fp16 pairs leave the normal range): recorded, not asserted to be small."""
+    N, H, W, cin, cout = 8, 56, 128, 128, 128
+    k = rnd((3, 3, cin, cout), 24) * 0.05
+    dy = rnd((N, H, W, cout), 26) * scale
+    wt = np.flip(k, (0, 1)).transpose(0, 1, 3, 2).copy()
+    ref = tr.conv3x3_same(t64(dy[:1], False), t64(wt, False), None, 1, 1).numpy()
+    gdy, gk = gpu(dy), gpu(k)
+    errs = {}
+    for flag in (False, True):
+        go.F16X2_DGRAD = flag
+        try:
+            dx = torch.zeros((N, H, W, cin), device="cuda")
+            go.conv3x3_dgrad(V(gdy), gk, V(dx), 1, 1, keep=[], dy_tensor=gdy)
+            torch.cuda.synchronize()
+        finally:
+            go.F16X2_DGRAD = False
+        errs[flag] = float(np.abs(dx[:1].double().cpu().numpy() - ref).max()) / float(np.abs(ref).max())
+    print(f"dgrad at |dy| ~ {scale:g}: relative error fp32 kernels {errs[False]:.2e}, F16-pipe split {errs[True]:.2e}")
+    assert errs[False] <= 3e-5, errs
+    if scale == 1.0:
+        assert errs[True] <= 3e-5, errs
+
+
 @pytest.mark.parametrize("N,dil,H,W,cin,cout", [
     (2, 1, 64, 128, 128, 128), (2, 4, 64, 128, 96, 64), (4, 1, 50, 70, 40, 36), (1, 16, 112, 256, 96, 64),
     (2, 2, 33, 47, 64, 100), (3, 1, 28, 64, 160, 32), (8, 8, 24, 20, 32, 32), (2, 1, 96, 160, 16, 16), (1, 1, 130, 77, 16, 16), (1, 1, 32, 64, 2112, 64)])

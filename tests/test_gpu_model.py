@@ -513,6 +513,30 @@ def test_out_of_range_frames_fall_back_to_fp32_kernels(pa, mode, streams):
     assert same(again, want)
 
 
+def test_misaligned_frames_after_an_aligned_plan(pa):
+    """the extractor's fused level-1 launch takes 16-byte aligned frames only.  A forward of aligned frames records a
+    launch plan with it; the same shape arriving as a view that starts 4 bytes into an allocation must get a plan of its own
+    (the per-layer path) and the same flows, not PWC_EALIGN out of a replayed launch."""
+    w = util.model_weights(False)
+    net = pa.PWCDCNet(streams=1)
+    net.load_weights(w)
+    im0, im1 = util.smooth_images(8, 448, 1024, seed=41)
+    a0, a1 = gpu(im0), gpu(im1)
+    ref, _ = net(a0, a1)
+    ref = ref.clone()
+
+    def shifted(t):
+        buf = torch.empty(t.numel() + 1, device="cuda")
+        v = buf[1:].view(t.shape)
+        v.copy_(t)
+        assert v.data_ptr() % 16 == 4
+        return v
+    got, _ = net(shifted(a0), shifted(a1))
+    assert float((got - ref).abs().max()) <= 1e-4
+    again, _ = net(a0, a1)
+    assert torch.equal(again, ref)
+
+
 def test_two_operand_first_conv_matches_the_concat_copy(pa):
     """Round 5: the estimator's first conv reads features_0 from the pyramid tensor (second operand pointer of the F16-pipe
     kernel) at the levels that run on it, instead of a copy in the estimator buffer.  Same channels in another order of
