@@ -35,6 +35,7 @@ Extra objects in the line:
                  that the flows, and with them the warps, are several pixels.
 """
 import argparse
+import collections
 import json
 import os
 import socket
@@ -549,7 +550,7 @@ def corr_warp_op_leg(net, B, H, Wd, dev, reps=12):
     for l in range(net.output_level + 1):
         h, w = H >> (net.num_levels - l), Wd >> (net.num_levels - l)
         levels.append((l, h, w, chans[l]))
-    timer = OpTimer()
+    totals = collections.OrderedDict()
     per_level = {}
     for l, h, w, C in levels:
         # the estimator input buffer of this level, as PWCDCNet lays it out (non-DC geometry)
@@ -582,26 +583,66 @@ def corr_warp_op_leg(net, B, H, Wd, dev, reps=12):
         for s in sets[:2]:
             run(s)
         torch.cuda.synchronize()
-        with timer:
+        lt = OpTimer()
+        with lt:
             for r in range(reps):
                 run(sets[r % nsets])
         torch.cuda.synchronize()
-        per_level[l] = dict(h=h, w=w, C=C, sets=nsets, est_buffer_channels=est_cs, f0_in_buffer="f0" in lay.segments)
+        lsum = lt.summary()
+        ev_ms = sum(d["ms"] for d in lsum.values())
+        # the same launches as ONE captured chain over every operand set (a graph replay: no host in the loop, no event
+        # between launches -- an event pair around a single small launch adds the pipeline drain and refill around it,
+        # 5-10 us on a 6 us kernel); one event pair around the replay, median of 5
+        chain_us = None
+        try:
+            n_chain = max(nsets, 24)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for r in range(n_chain):
+                    run(sets[r % nsets])
+            graph.replay()
+            ts = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                graph.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3 / n_chain)
+            chain_us = sorted(ts)[2]
+            del graph
+        except RuntimeError as e:      # capture refused (a launch path that allocates): the event pairs stay the measure
+            print(f"op leg level {l}: no graph capture ({e}); event pairs per launch only", file=sys.stderr)
+        level_us = chain_us if chain_us is not None else 1e3 * ev_ms / reps
+        for k, d in lsum.items():
+            share = d["ms"] / ev_ms if ev_ms > 0 else 1.0 / len(lsum)
+            t = totals.setdefault(k, dict(us=0.0, bytes=0.0, launches=0.0, ev_us=0.0))
+            t["us"] += level_us * share                 # a level of several launches: the chain time split by event-pair shares
+            t["bytes"] += d["bytes"] / reps
+            t["launches"] += d["launches"] / reps
+            t["ev_us"] += 1e3 * d["ms"] / reps
+        per_level[l] = dict(h=h, w=w, C=C, sets=nsets, est_buffer_channels=est_cs, f0_in_buffer="f0" in lay.segments,
+                            us_chain=chain_us, us_event_pairs=1e3 * ev_ms / reps)
         del sets
-    summ = timer.summary()
-    ms = sum(d["ms"] for d in summ.values())
-    by = sum(d["bytes"] for d in summ.values())
-    ach = by / (ms * 1e-3) / 1e9
-    return {"kernel": "+".join(summ), "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+    us = sum(t["us"] for t in totals.values())
+    by = sum(t["bytes"] for t in totals.values())
+    ach = by / (us * 1e-6) / 1e9
+    return {"kernel": "+".join(totals), "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": ach / PEAK_HBM_GBS, "traffic": None,
-            "us_per_forward": 1e3 * ms / reps,
-            "algorithmic_bytes_per_forward": by / reps,
-            "per_kernel": {k: {"avg_us": 1e3 * d["ms"] / d["launches"], "gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
-                               "launches_per_forward": d["launches"] / reps} for k, d in summ.items()},
+            "us_per_forward": us,
+            "us_per_forward_event_pairs": sum(t["ev_us"] for t in totals.values()),
+            "algorithmic_bytes_per_forward": by,
+            "per_kernel": {k: {"avg_us": t["us"] / t["launches"], "avg_us_event_pair": t["ev_us"] / t["launches"],
+                               "gbs": t["bytes"] / (t["us"] * 1e-6) / 1e9,
+                               "launches_per_forward": t["launches"]} for k, t in totals.items()},
             "per_level": per_level,
             "measured": f"op-level leg: production launch sequence of every pyramid level (batch {B}), flows ~ "
-                        f"N(0,3^2) px, {reps} repetitions over operand sets rotating through > 256 MB, HIP events per "
-                        "launch; bytes = N*h*w*(2C+81)*4 per cost volume + N*h*w*(2C+2)*4 per warp "
+                        "N(0,3^2) px, operand sets rotating through > 256 MB; avg_us = a captured chain of the level's "
+                        "launches over all its operand sets (>= 24 launches), one HIP event pair around the graph replay, "
+                        f"median of 5; avg_us_event_pair = an event pair around every launch ({reps} repetitions; what "
+                        "rounds 2-4 reported: includes the pipeline drain and refill around a lone launch); "
+                        "bytes = N*h*w*(2C+81)*4 per cost volume + N*h*w*(2C+2)*4 per warp "
                         "(N*h*w*(2C+2+81)*4 for a fused launch); concat-copy bytes not counted (levels whose first conv "
                         "reads features_0 from the pyramid tensor have no such copy)"}
 

@@ -137,6 +137,25 @@ int pwc_warp_cost_volume_concat_h2_f32(const float* f0, int f0_cs, const float* 
                                        float* f0_copy, int f0_copy_cs,
                                        int N, int H, int W, int C, int search_range, float slope,
                                        pwc_stream_t stream);
+/* Round 5: the same operation for the SMALL pyramid levels -- C in {96, 128, 192} (7 x 16 ... 28 x 64 pixels at 448 x 1024) --
+ * on the F16 matrix pipe (csrc/cost_volume_blk.hip): one 4 x 4-pixel block of f0 per workgroup, its 12 x 12-pixel window
+ * of f1 (all channels, the four bilinear corners) requested at once -- or, where a launch has fewer blocks than the device has
+ * CUs, one of the window's three block rows per workgroup -- so a launch is one chain flow -> corners -> blend -> matrix
+ * instructions -> stores instead of a channel-stage loop of memory round trips (pwc_cost_volume_coarse_f32) or a walk over
+ * block rows (the _h2 form: faster from about 8192 pixels per launch on, where this form's nine-fold re-gather of f1 costs
+ * more than the walk's prologue).  Also takes C = 64 (small batches).  Arithmetic and range as
+ * pwc_warp_cost_volume_concat_h2_f32.  Alignment requirements as pwc_warp_cost_volume_concat_f32;
+ * pwc_warp_cost_volume_concat_blk_supported tells in advance.  pwc_debug_cost_volume_blk_rows(1 | 3) pins the window rows per
+ * workgroup (0: the default choice) -- an experiment knob for scripts/exp_blk_ab.py, process-wide, not for production. */
+int pwc_warp_cost_volume_concat_blk_f32(const float* f0, int f0_cs, const float* f1, int f1_cs,
+                                       const float* flow, int flow_cs, float flow_scale,
+                                       float* out, int out_cs, int out_pad_writable,
+                                       float* f0_copy, int f0_copy_cs,
+                                       int N, int H, int W, int C, int search_range, float slope,
+                                       pwc_stream_t stream);
+int pwc_warp_cost_volume_concat_blk_supported(int H, int W, int C, int search_range, int f0_cs, int f1_cs,
+                                              int flow_cs, int out_cs, int f0_copy_cs);
+int pwc_debug_cost_volume_blk_rows(int rows);
 
 /* ---- a4/a5/a6: tf.layers.Conv2D(Cout,(3,3),(s,s),'same',dilation_rate=d) [+
  * tf.nn.leaky_relu(slope)] -- modules.py:62-67,267-268,274,306-324 ----
@@ -319,6 +338,27 @@ int pwc_conv3x3_h2_stride2_f32(const float* x, int x_cs, const float* packed_w, 
                                int apply_act, float slope, float* workspace, size_t workspace_floats,
                                pwc_stream_t stream);
 int pwc_conv3x3_h2_stride2_supported(int N, int H, int W, int Cin_phys, int Cout);
+
+/* Round 5: 3x3 convolution for SMALL launches (csrc/conv3x3_sk.hip) -- the 7 x 16 and 14 x 32 pyramid levels of a batch of
+ * 8, every level of a single pair -- on the F16 matrix pipe, arithmetic and RANGE of pwc_conv3x3_h2_f32 (two-term fp16
+ * operand splits, fp32 accumulation; |x|, |w| < 65504).  Same operation as pwc_conv3x3_f32 (TF 'SAME' padding, stride 1 | 2,
+ * any dilation, + bias, + leaky_relu when apply_act): the K dimension (9 taps x Cin_phys) of a 16-pixel x 16-channel tile is
+ * dealt to the eight waves of ONE workgroup, every wave requests all its operands at once, the eight partial sums are added
+ * in wave order (launches repeat bitwise) -- one dispatch where the tiled kernels need a tap / channel split over workgroups
+ * plus a reduce launch to fill the device.  Needs Cin_phys % 32 == 0, Cout % 16 == 0, x / y / packed_w / bias 16-byte
+ * aligned, x_cs % 4 == 0, y_cs % 4 == 0, N*H*W*x_cs*4 < 2^31.  packed_w: pwc_conv3x3_sk_pack_f32 (the split halves in
+ * fragment order, pwc_conv3x3_sk_packed_floats floats; cin_map as in pwc_conv3x3_pack_f32).  pwc_conv3x3_sk_supported: 1
+ * where it is the fastest kernel of this library for the shape (launches of up to 1e8 multiply-adds -- output pixels x
+ * Cin_phys x Cout -- and up to 4096 output pixels; beyond that pixel count stride-2 and thin layers only), else 0.
+ * pwc_debug_conv3x3_sk_tile(11 | 21 | 22) pins the workgroup tile (0: default choice) -- an experiment knob, process-wide. */
+size_t pwc_conv3x3_sk_packed_floats(int Cin_phys, int Cout);
+int pwc_conv3x3_sk_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin, int Cin_phys, int Cout,
+                            float* packed_w, pwc_stream_t stream);
+int pwc_conv3x3_sk_f32(const float* x, int x_cs, const float* packed_w, const float* bias, float* y, int y_cs,
+                       int N, int H, int W, int Cin_phys, int Cout, int stride, int dilation, int apply_act,
+                       float slope, pwc_stream_t stream);
+int pwc_conv3x3_sk_supported(int N, int H, int W, int Cin_phys, int Cout, int stride, int dilation);
+int pwc_debug_conv3x3_sk_tile(int tile);
 /* Tile variants of the kernel above (workgroup = couts x rows x 32 columns): 1 = 128 x 8, 2 = 64 x 16, 3 = 96 x 8,
  * 4 = 32 x 16, 5 = 64 x 8.  pwc_conv3x3_h2_plan: the one pwc_conv3x3_h2_f32 launches for a shape (fewest estimated
  * rounds of 256 workgroups x matrix instructions per tap; 0 = the shape is not accepted).  pwc_conv3x3_h2_variant_f32:

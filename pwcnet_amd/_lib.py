@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libpwc_hip.so")
 SOURCES = ["conv3x3_mfma.hip", "conv3x3_wino.hip", "conv3x3_direct.hip", "cost_volume.hip", "pwc_ops.hip",
-           "pwc_backward.hip", "conv3x3_wgrad.hip", "conv3x3_h2.hip", "conv3x3_c16pair.hip"]
-HEADERS = ["pwc_common.h", "cost_volume_roll.hip", "cost_volume_mfma.hip", "cost_volume_h2.hip", "conv3x3_wino4.hip", os.path.join("..", "..", "include", "pwc_hip.h")]
+           "pwc_backward.hip", "conv3x3_wgrad.hip", "conv3x3_h2.hip", "conv3x3_c16pair.hip", "conv3x3_sk.hip"]
+HEADERS = ["pwc_common.h", "cost_volume_roll.hip", "cost_volume_mfma.hip", "cost_volume_h2.hip", "cost_volume_blk.hip", "conv3x3_wino4.hip", os.path.join("..", "..", "include", "pwc_hip.h")]
 
 _vp, _i, _f, _l, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long, ctypes.c_size_t
 
@@ -34,7 +34,10 @@ SIGNATURES = {
     "pwc_warp_cost_volume_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_warp_cost_volume_concat_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_warp_cost_volume_concat_h2_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "pwc_warp_cost_volume_concat_blk_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_warp_cost_volume_concat_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "pwc_warp_cost_volume_concat_blk_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "pwc_debug_cost_volume_blk_rows": (_i, [_i]),
     "pwc_conv3x3_packed_floats": (_sz, [_i, _i]),
     "pwc_conv3x3_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pwc_conv3x3_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
@@ -59,6 +62,11 @@ SIGNATURES = {
     "pwc_conv3x3_h2_plan": (_i, [_i, _i, _i, _i, _i, _i]),
     "pwc_conv3x3_h2_stride2_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "pwc_conv3x3_h2_stride2_supported": (_i, [_i, _i, _i, _i, _i]),
+    "pwc_conv3x3_sk_packed_floats": (_sz, [_i, _i]),
+    "pwc_conv3x3_sk_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "pwc_conv3x3_sk_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "pwc_conv3x3_sk_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "pwc_debug_conv3x3_sk_tile": (_i, [_i]),
     "pwc_conv3x3_h2_stride2_packed_floats": (_sz, [_i, _i]),
     "pwc_conv3x3_h2_stride2_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pwc_conv3x3_h2_stride2_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),

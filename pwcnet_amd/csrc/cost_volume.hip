@@ -28,6 +28,7 @@
 #include "cost_volume_roll.hip"   // rolling-window kernel for C = 32 (static: compiled into this unit)
 #include "cost_volume_mfma.hip"   // matrix-pipe kernel with the warp and the concat copy fused in (static: compiled into this unit)
 #include "cost_volume_h2.hip"     // round 5: the same launch on the F16 matrix pipe, gathers a step ahead (static: compiled into this unit)
+#include "cost_volume_blk.hip"    // round 5: small pyramid levels, one 4 x 4 block per workgroup, F16 matrix pipe (static: compiled into this unit)
 
 struct CvArgs {
     const float* f0;
@@ -809,6 +810,33 @@ extern "C" int pwc_warp_cost_volume_concat_h2_f32(const float* f0, int f0_cs, co
     if (!cvm_eligible(f0, f0_cs, f1, f1_cs, flow, flow_cs, out, out_cs, f0_copy, f0_copy_cs, H, W, C, search_range))
         return ((long)H * W * (long)(out_cs > f0_cs ? out_cs : f0_cs) * 4 >= (1L << 31)) ? PWC_ERANGE : PWC_EALIGN;
     return cvh_launch(f0, f0_cs, f1, f1_cs, flow, flow_cs, flow_scale, out, out_cs, out_pad_writable ? 1 : 0, f0_copy,
+                      f0_copy_cs, N, H, W, C, slope, (hipStream_t)stream);
+}
+
+// Round 5: the same operation for the small pyramid levels (C = 96 / 128 / 192): one 4 x 4 block per workgroup, the whole
+// 12 x 12 window requested at once, correlation on the F16 matrix pipe (cost_volume_blk.hip).
+extern "C" int pwc_warp_cost_volume_concat_blk_supported(int H, int W, int C, int search_range, int f0_cs, int f1_cs,
+                                                         int flow_cs, int out_cs, int f0_copy_cs) {
+    const float* al = reinterpret_cast<const float*>(16);
+    return cvb_eligible(al, f0_cs, al, f1_cs, flow_cs ? al : nullptr, flow_cs, al, out_cs, f0_copy_cs ? al : nullptr,
+                        f0_copy_cs, H, W, C, search_range) ? 1 : 0;
+}
+
+extern "C" int pwc_debug_cost_volume_blk_rows(int rows) { cvb_rows_override = rows; return 0; }
+
+extern "C" int pwc_warp_cost_volume_concat_blk_f32(const float* f0, int f0_cs, const float* f1, int f1_cs,
+                                                   const float* flow, int flow_cs, float flow_scale, float* out,
+                                                   int out_cs, int out_pad_writable, float* f0_copy, int f0_copy_cs,
+                                                   int N, int H, int W, int C, int search_range, float slope,
+                                                   pwc_stream_t stream) {
+    int rc = cv_check(f0, f0_cs, f1, f1_cs, out, out_cs, N, H, W, C, search_range);
+    if (rc) return rc;
+    if ((flow && flow_cs < 2) || (f0_copy && f0_copy_cs < C)) return PWC_EINVAL;
+    if (out_pad_writable && out_cs < 84) return PWC_EINVAL;
+    if (search_range != 4 || !(C == 64 || C == 96 || C == 128 || C == 192)) return PWC_EUNSUPPORTED;
+    if (!cvb_eligible(f0, f0_cs, f1, f1_cs, flow, flow_cs, out, out_cs, f0_copy, f0_copy_cs, H, W, C, search_range))
+        return ((long)H * W * (long)(out_cs > f0_cs ? out_cs : f0_cs) * 4 >= (1L << 31)) ? PWC_ERANGE : PWC_EALIGN;
+    return cvb_launch(f0, f0_cs, f1, f1_cs, flow, flow_cs, flow_scale, out, out_cs, out_pad_writable ? 1 : 0, f0_copy,
                       f0_copy_cs, N, H, W, C, slope, (hipStream_t)stream);
 }
 

@@ -570,6 +570,12 @@ class PWCDCNet(object):
         flow_v * scales[l] (l > 0) and correlated with f0 into cv_out; f0 is copied to f0_dst (None: the estimator reads
         features_0 from the pyramid tensor, nothing to copy)."""
         N, h, w, C = f0.N, f0.H, f0.W, f0.C
+        if self.coarse_cv and self.concat_cv and (l == 0 or self.warp_type == "bilinear") and \
+                self.cv_layer.blk_ok(f0, f1, cv_out, flow=flow_v, f0_copy=f0_dst):
+            # small levels, F16 matrix pipe: one 4 x 4 block per workgroup, its whole window requested at once
+            self.cv_layer._run(f0, f1, cv_out, flow=flow_v, flow_scale=self.scales[l] if l > 0 else 1.0,
+                               f0_copy=f0_dst, concat=True, out_pad_writable=True, blk=True)
+            return
         if self.coarse_cv and self.cv_layer.coarse_ok(f0) and (l == 0 or self.warp_type == "bilinear"):
             # coarse levels: warp + cost volume + the f0 part of the concat in ONE launch
             self.cv_layer._run(f0, f1, cv_out, flow=flow_v, flow_scale=self.scales[l] if l > 0 else 1.0,

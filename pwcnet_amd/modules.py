@@ -339,8 +339,33 @@ class _ConvRunner:
         use_h2 = (use_mfma and getattr(self.owner, "f16x2", True) and stride == 1 and tile < 0 and split == 0
                   and cout % 32 == 0 and y.cs % 4 == 0 and y.ptr % 16 == 0
                   and L.pwc_conv3x3_h2_supported(x.N, x.H, x.W, c_phys, cout, dilation))
+        # small launches (round 5): the K dimension dealt to the waves of one workgroup, ONE dispatch (conv3x3_sk.hip)
+        use_sk = (use_mfma and getattr(self.owner, "f16x2", True) and getattr(self.owner, "small_conv", True) and x2 is None
+                  and tile < 0 and split == 0 and x.C % 32 == 0 and y.cs % 4 == 0 and y.ptr % 16 == 0
+                  and L.pwc_conv3x3_sk_supported(x.N, x.H, x.W, x.C, cout, stride, dilation))
         if x2 is not None and not use_h2:
             raise _lib.PwcHipError(f"{name}: a two-operand input needs the F16-pipe kernel (h2_two_operand_ok)")
+        if use_sk:
+            key = (name, "sk", x.C, None if cin_map is None else cin_map.tobytes(), self.store.version)
+            packed = cache.get(key)
+            if packed is None:
+                packed = torch.empty((L.pwc_conv3x3_sk_packed_floats(x.C, cout),), dtype=torch.float32, device=kern.value.device)
+                cm = None
+                if cin_map is not None:
+                    assert len(cin_map) == x.C
+                    cm = torch.from_numpy(np.ascontiguousarray(cin_map, np.int32)).to(kern.value.device)
+                _lib.check(L.pwc_conv3x3_sk_pack_f32(_p(kern.value.data_ptr()), _p(cm.data_ptr()) if cm is not None else None,
+                                                     cin, x.C, cout, _p(packed.data_ptr()), s), "conv3x3 sk pack")
+                cache[key] = packed
+            _keep(packed, y_t)
+            _track_max(self.owner, x)
+            _launch(L.pwc_conv3x3_sk_f32,
+                    (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
+                     x.N, x.H, x.W, x.C, cout, stride, dilation, act, sl, s),
+                    f"conv3x3_sk {name}", "conv3x3_sk_kernel",
+                    2.0 * x.N * Ho * Wo * 9 * cin * cout, 4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout),
+                    exec_flops=3.0 * 2.0 * x.N * Ho * Wo * 9 * x.C * cout)
+            return y, y_t
         use_h2s2 = (use_mfma and getattr(self.owner, "f16x2", True) and stride == 2 and dilation == 1 and tile < 0 and split == 0
                     and cout % 32 == 0 and y.cs % 4 == 0 and y.ptr % 16 == 0
                     and L.pwc_conv3x3_h2_stride2_supported(x.N, x.H, x.W, x.C, cout))
@@ -754,12 +779,34 @@ class CostVolumeLayer(_Module):
                                                             flow.cs if flow is not None else 0, out.cs,
                                                             f0_copy.cs if f0_copy is not None else 0))
 
-    def _run(self, f0, f1, out, flow=None, flow_scale=1.0, f0_copy=None, coarse=False, concat=False, out_pad_writable=False):
+    # pixels per batch up to which a C = 64 / 96 level goes to the block-per-workgroup kernel (its window is re-gathered by up
+    # to nine workgroups: past this the row-walking kernel, which reads less, is faster.  Measured, graph replays, us per launch,
+    # blk / row-walking: 28x64x96 batch 1: 6.8 / 15.8, batch 4: 10.9 / 16.1, batch 8: 19.5 / 16.4; 56x128x64 batch 1: 8.2 / 11.7,
+    # batch 2: 13.6 / 11.9 -- profiles/r05_exp_blk_ab.txt)
+    BLK_MAX_PIXELS = 8192
+
+    def blk_ok(self, f0, f1, out, flow=None, f0_copy=None):
+        """True if pwc_warp_cost_volume_concat_blk_f32 (F16 matrix pipe, one 4 x 4 block per workgroup: the small pyramid
+        levels) takes this geometry and is the faster launch for it."""
+        if not getattr(self, "f16x2", True) or f0.C not in (64, 96, 128, 192):
+            return False
+        if f0.C <= 96 and f0.N * f0.H * f0.W > self.BLK_MAX_PIXELS:
+            return False
+        if any(v.ptr % 16 for v in (f0, f1, out)) or (f0_copy is not None and f0_copy.ptr % 16) or \
+                (flow is not None and flow.ptr % 4):
+            return False
+        return bool(_lib.lib().pwc_warp_cost_volume_concat_blk_supported(
+            f0.H, f0.W, f0.C, self.s_range, f0.cs, f1.cs, flow.cs if flow is not None else 0, out.cs,
+            f0_copy.cs if f0_copy is not None else 0))
+
+    def _run(self, f0, f1, out, flow=None, flow_scale=1.0, f0_copy=None, coarse=False, concat=False, out_pad_writable=False,
+             blk=False):
         """flow given: f1 is the UN-warped map and the bilinear warp is fused in.
         coarse: one launch of pwc_cost_volume_coarse_f32 (optionally also copying f0 into
         the `f0_copy` view, the features_0 slice of the estimator input).
         concat: one launch of pwc_warp_cost_volume_concat_f32 (same operands; out_pad_writable: channels 81..83 of
-        `out` are padding the kernel may zero)."""
+        `out` are padding the kernel may zero).  blk (with concat): pwc_warp_cost_volume_concat_blk_f32, the F16-pipe
+        kernel of the small levels."""
         L = _lib.lib()
         s = _lib.current_stream()
         D = (2 * self.s_range + 1) ** 2
@@ -775,9 +822,12 @@ class CostVolumeLayer(_Module):
                     1 if out_pad_writable else 0,
                     _p(f0_copy.ptr) if f0_copy is not None else None, f0_copy.cs if f0_copy is not None else 0,
                     f0.N, f0.H, f0.W, f0.C, self.s_range, 0.1)
-            _launch(L.pwc_warp_cost_volume_concat_h2_f32 if h2 else L.pwc_warp_cost_volume_concat_f32, args + (s,),
+            assert h2 or not blk
+            fn = L.pwc_warp_cost_volume_concat_blk_f32 if blk else \
+                L.pwc_warp_cost_volume_concat_h2_f32 if h2 else L.pwc_warp_cost_volume_concat_f32
+            _launch(fn, args + (s,),
                     "warp_cost_volume_concat" if flow is not None else "cost_volume_concat",
-                    f"cost_volume_{'h2' if h2 else 'mfma'}_kernel<C{f0.C}{',warp' if flow is not None else ''}>", flops,
+                    f"cost_volume_{'blk' if blk else 'h2' if h2 else 'mfma'}_kernel<C{f0.C}{',warp' if flow is not None else ''}>", flops,
                     # (2C+81) or fused (2C+2+81) bytes per pixel; the f0 concat copy is not credited
                     4.0 * npix * (2 * f0.C + D + (2 if flow is not None else 0)))
             return

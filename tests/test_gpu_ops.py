@@ -355,6 +355,106 @@ def test_conv_f16x2_direct_stream_k(pa, N, H, W, cin, cout, dil):
         close(first[i:i + 1], orc.conv3x3(x[i:i + 1], k, b, 1, dil, 0.1))
 
 
+@pytest.mark.parametrize("N,H,W,cin,cout,stride,dil", [
+    (8, 7, 16, 288, 128, 1, 1), (8, 7, 16, 128, 128, 1, 1), (8, 7, 16, 128, 96, 1, 1), (8, 7, 16, 96, 64, 1, 1),
+    (8, 7, 16, 64, 32, 1, 1), (8, 14, 32, 256, 128, 1, 1), (16, 14, 32, 128, 192, 2, 1), (16, 7, 16, 192, 192, 1, 1),
+    (1, 5, 3, 32, 16, 1, 1), (2, 9, 21, 64, 48, 1, 2), (1, 13, 30, 96, 32, 2, 1), (2, 11, 7, 32, 32, 1, 4),
+    (1, 1, 1, 64, 16, 1, 1), (1, 56, 128, 128, 96, 1, 1), (3, 8, 8, 352, 32, 1, 1)])
+@pytest.mark.parametrize("tile", [0, 11, 21, 22])
+def test_conv_small_launch_kernel_vs_oracle(pa, N, H, W, cin, cout, stride, dil, tile):
+    """pwc_conv3x3_sk_f32 (round 5, conv3x3_sk.hip: the K dimension of a tile over the eight waves of one workgroup): the
+    estimator / extractor layers of BASELINE configs[1]'s two coarsest levels as they are, stride 2 (even and odd sizes),
+    dilations, ragged blocks, an image smaller than a block, more K steps than one batch of requests holds (352 channels), every
+    workgroup tile; strided output with untouched neighbours; padded / permuted input channels (cin_map); launches repeat
+    bitwise."""
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    if tile == 22 and cout % 32:
+        pytest.skip("the 2 x 2 tile needs C_out % 32 == 0")
+    x = rnd((N, H, W, cin), 471)
+    k = rnd((3, 3, cin, cout), 472) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 473) * 0.1
+    xg, kg, bg = gpu(x), gpu(k), gpu(b)
+    packed = torch.empty(L.pwc_conv3x3_sk_packed_floats(cin, cout), device="cuda")
+    _lib.check(L.pwc_conv3x3_sk_pack_f32(_p(kg), None, cin, cin, cout, _p(packed), None))
+    exp = orc.conv3x3(x, k, b, stride, dil, 0.1)
+    Ho, Wo = exp.shape[1:3]
+    L.pwc_debug_conv3x3_sk_tile(tile)
+    try:
+        ys = []
+        for _ in range(2):
+            y = torch.full((N, Ho, Wo, cout + 8), -7.0, device="cuda")
+            _lib.check(L.pwc_conv3x3_sk_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout + 8, N, H, W, cin, cout, stride, dil, 1, 0.1, None))
+            torch.cuda.synchronize()
+            ys.append(y)
+        close(ys[0][..., :cout], exp)
+        assert float(ys[0][..., cout:].min()) == -7.0 and float(ys[0][..., cout:].max()) == -7.0
+        assert torch.equal(ys[0], ys[1])
+        # no activation
+        y = torch.empty((N, Ho, Wo, cout), device="cuda")
+        _lib.check(L.pwc_conv3x3_sk_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout, N, H, W, cin, cout, stride, dil, 0, 0.0, None))
+        close(y, orc.conv3x3(x, k, b, stride, dil, None))
+        # physical layout: channels padded / permuted, channel stride beyond them
+        cs = cin + 32
+        rs = np.random.RandomState(7)
+        pos = np.sort(rs.choice(cs, cin, replace=False))
+        cmap = np.full((cs,), -1, np.int32)
+        cmap[pos] = np.arange(cin, dtype=np.int32)
+        xp = rnd((N, H, W, cs + 4), 474)
+        xp[..., pos] = x
+        cm = torch.from_numpy(cmap).cuda()
+        packed2 = torch.empty(L.pwc_conv3x3_sk_packed_floats(cs, cout), device="cuda")
+        _lib.check(L.pwc_conv3x3_sk_pack_f32(_p(kg), _p(cm), cin, cs, cout, _p(packed2), None))
+        y = torch.empty((N, Ho, Wo, cout), device="cuda")
+        xpg = gpu(xp)
+        _lib.check(L.pwc_conv3x3_sk_f32(_p(xpg), cs + 4, _p(packed2), _p(bg), _p(y), cout, N, H, W, cs, cout, stride, dil, 1, 0.1, None))
+        close(y, exp)
+    finally:
+        L.pwc_debug_conv3x3_sk_tile(0)
+
+
+def test_conv_small_launch_kernel_error_range_and_rejections(pa):
+    """The small-launch kernel against a float64 convolution: not further from it than the fp32 matrix-pipe kernel; an input
+    beyond fp16's range gives NaN in the outputs that read it; unsupported shapes / alignments are refused."""
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    N, H, W, cin, cout = 2, 7, 16, 128, 64
+    x = rnd((N, H, W, cin), 481) * 3.0
+    k = rnd((3, 3, cin, cout), 482) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 483) * 0.1
+    xg, kg, bg = gpu(x), gpu(k), gpu(b)
+    xp = np.zeros((N, H + 2, W + 2, cin), np.float64)
+    xp[:, 1:-1, 1:-1] = x
+    ref = sum(np.einsum("nhwc,co->nhwo", xp[:, dy:dy + H, dx:dx + W], k[dy, dx].astype(np.float64))
+              for dy in range(3) for dx in range(3)) + b
+    packed = torch.empty(L.pwc_conv3x3_sk_packed_floats(cin, cout), device="cuda")
+    _lib.check(L.pwc_conv3x3_sk_pack_f32(_p(kg), None, cin, cin, cout, _p(packed), None))
+    y = torch.empty((N, H, W, cout), device="cuda")
+    _lib.check(L.pwc_conv3x3_sk_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout, N, H, W, cin, cout, 1, 1, 0, 0.0, None))
+    err_sk = float(np.abs(y.double().cpu().numpy() - ref).max())
+    p32 = torch.empty(L.pwc_conv3x3_packed_floats(cin, cout), device="cuda")
+    _lib.check(L.pwc_conv3x3_pack_f32(_p(kg), None, cin, cin, cout, _p(p32), None))
+    y32 = torch.empty((N, H, W, cout), device="cuda")
+    _lib.check(L.pwc_conv3x3_f32(_p(xg), cin, _p(p32), _p(bg), _p(y32), cout, N, H, W, cin, cout, 1, 1, 0, 0.0, -1, 1, None, 0, None))
+    err_32 = float(np.abs(y32.double().cpu().numpy() - ref).max())
+    assert err_sk <= 1.5 * err_32 + 1e-7, (err_sk, err_32)
+    xg[1, 3, 5, 7] = 70000.0
+    _lib.check(L.pwc_conv3x3_sk_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout, N, H, W, cin, cout, 1, 1, 0, 0.0, None))
+    bad = torch.isnan(y).any(dim=3)
+    idx = torch.nonzero(bad)
+    assert len(idx) == 9 and int(idx[:, 0].min()) == 1 and int((idx[:, 1] - 3).abs().max()) == 1 and int((idx[:, 2] - 5).abs().max()) == 1
+    assert L.pwc_conv3x3_sk_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout, N, H, W, 48, cout, 1, 1, 0, 0.0, None) == -4
+    assert L.pwc_conv3x3_sk_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout, N, H, W, cin, 24, 1, 1, 0, 0.0, None) == -4
+    assert L.pwc_conv3x3_sk_f32(_p(xg), cin + 2, _p(packed), _p(bg), _p(y), cout, N, H, W, cin, cout, 1, 1, 0, 0.0, None) != 0
+    assert L.pwc_conv3x3_sk_supported(8, 7, 16, 288, 128, 1, 1) == 1
+    assert L.pwc_conv3x3_sk_supported(8, 28, 64, 64, 32, 1, 1) == 1
+    assert L.pwc_conv3x3_sk_supported(8, 28, 64, 224, 128, 1, 1) == 0
+    assert L.pwc_conv3x3_sk_supported(16, 14, 32, 128, 128, 1, 1) == 0
+    assert L.pwc_conv3x3_sk_supported(16, 28, 64, 96, 128, 2, 1) == 1
+    assert L.pwc_conv3x3_sk_supported(8, 112, 256, 128, 128, 1, 1) == 0
+    assert L.pwc_conv3x3_sk_supported(8, 7, 16, 48, 128, 1, 1) == 0
+
+
 @pytest.mark.parametrize("N,H,W,cin,cout", [(2, 64, 96, 16, 32), (1, 34, 46, 32, 64), (2, 50, 70, 64, 96), (16, 112, 256, 32, 64),
                                             (3, 30, 64, 48, 128), (16, 224, 512, 16, 32), (1, 2, 2, 16, 32)])
 def test_conv_f16x2_direct_stride2_vs_oracle(pa, N, H, W, cin, cout):
@@ -1039,7 +1139,7 @@ def test_coarse_cost_volume_kernel_vs_oracle(pa, N, H, W, C, with_flow):
 
 
 # ------------------------------------------------------------------ matrix-pipe fused kernel (cost_volume_mfma.hip)
-def _run_concat(pa, f0, f1, flow, flow_scale, ecs, copy, pad, fill=-3.0, flow_cs=4, f16x2=True):
+def _run_concat(pa, f0, f1, flow, flow_scale, ecs, copy, pad, fill=-3.0, flow_cs=4, f16x2=True, blk=False):
     """pwc_warp_cost_volume_concat_f32 (f16x2=False) / pwc_warp_cost_volume_concat_h2_f32 (the F16-pipe kernel of round 5,
     cost_volume_h2.hip) into an estimator-style buffer [cv 81 | pad 3 | f0 C | rest]; returns E."""
     from pwcnet_amd.modules import View, sub_view
@@ -1056,11 +1156,78 @@ def _run_concat(pa, f0, f1, flow, flow_scale, ecs, copy, pad, fill=-3.0, flow_cs
     v0, v1 = View(g0.data_ptr(), C, N, H, W, C), View(g1.data_ptr(), C, N, H, W, C)
     fv = View(fl.data_ptr(), flow_cs, N, H, W, 2) if fl is not None else None
     cpy = sub_view(Ev, 84, C) if copy else None
-    assert layer.concat_ok(v0, v1, sub_view(Ev, 0, 81), flow=fv, f0_copy=cpy)
+    if blk:
+        layer.BLK_MAX_PIXELS = 1 << 30
+        assert layer.blk_ok(v0, v1, sub_view(Ev, 0, 81), flow=fv, f0_copy=cpy)
+    else:
+        assert layer.concat_ok(v0, v1, sub_view(Ev, 0, 81), flow=fv, f0_copy=cpy)
     layer._run(v0, v1, sub_view(Ev, 0, 81), flow=fv, flow_scale=flow_scale, f0_copy=cpy, concat=True,
-               out_pad_writable=pad)
+               out_pad_writable=pad, blk=blk)
     torch.cuda.synchronize()
     return E, g0
+
+
+@pytest.mark.parametrize("N,H,W,C,with_flow,copy,pad", [
+    (8, 7, 16, 192, False, True, True), (8, 14, 32, 128, True, True, True), (2, 28, 64, 96, True, True, True),
+    (2, 14, 32, 128, True, False, False), (3, 9, 21, 96, True, True, False), (1, 5, 3, 192, True, False, True),
+    (1, 17, 10, 128, False, True, False), (2, 8, 8, 192, True, True, True), (1, 1, 1, 128, True, True, True),
+    (1, 4, 4, 96, False, False, True), (1, 13, 30, 192, True, True, True), (1, 56, 128, 64, True, True, True),
+    (2, 6, 9, 64, True, False, False), (1, 28, 64, 96, True, True, True), (8, 28, 64, 96, True, True, True)])
+def test_block_cost_volume_kernel_vs_oracle(pa, N, H, W, C, with_flow, copy, pad):
+    """pwc_warp_cost_volume_concat_blk_f32 (cost_volume_blk.hip, the small pyramid levels on the F16 matrix pipe): the three
+    coarsest levels of BASELINE configs[1] as they are, ragged blocks (H % 4, W % 4 != 0), images smaller than a block and
+    than the search window, every C, flows with far outliers, every combination of the optional parts.  Nothing outside the
+    declared slices may change."""
+    f0, f1 = rnd((N, H, W, C), 61), rnd((N, H, W, C), 62)
+    flow = util.flow_field(N, H, W, seed=63) / 5.0
+    f1w = orc.warp(f1, flow, "bilinear", flow_scale=5.0) if with_flow else f1
+    exp = orc.cost_volume(f0, f1w, 4)
+    ecs = 84 + C + 8
+    E, g0 = _run_concat(pa, f0, f1, flow if with_flow else None, 5.0, ecs, copy, pad, blk=True)
+    close(E[..., :81], exp, rel=4e-6, floor=4e-7)
+    if copy:
+        assert torch.equal(E[..., 84:84 + C], g0)
+    else:
+        assert float(E[..., 84:84 + C].max()) == -3.0 and float(E[..., 84:84 + C].min()) == -3.0
+    if pad:
+        assert float(E[..., 81:84].abs().max()) == 0.0
+    else:
+        assert float(E[..., 81:84].min()) == -3.0 and float(E[..., 81:84].max()) == -3.0
+    assert float(E[..., 84 + C:].min()) == -3.0 and float(E[..., 84 + C:].max()) == -3.0
+
+
+def test_block_cost_volume_error_and_range(pa):
+    """The block kernel against a float64 cost volume: not further from it than the fp32 coarse kernel is (features of
+    1e-3 .. 300 in magnitude); a feature beyond fp16's range gives NaN where it is read."""
+    from pwcnet_amd.modules import View
+    N, H, W, C = 2, 14, 32, 128
+    for scale in (1e-3, 1.0, 300.0):
+        f0, f1 = rnd((N, H, W, C), 201) * scale, rnd((N, H, W, C), 202) * scale
+        flow = util.flow_field(N, H, W, seed=203) / 5.0
+        f1w = orc.warp(f1, flow, "bilinear", flow_scale=5.0).astype(np.float64)
+        pad1 = np.zeros((N, H + 8, W + 8, C))
+        pad1[:, 4:-4, 4:-4] = f1w
+        ref = np.stack([(f0.astype(np.float64) * pad1[:, 4 + v:4 + v + H, 4 + h:4 + h + W]).mean(axis=3)
+                        for v in range(-4, 5) for h in range(-4, 5)], axis=3)
+        ref = np.maximum(ref, 0.1 * ref)
+        E, _ = _run_concat(pa, f0, f1, flow, 5.0, 224, False, True, fill=0.0, blk=True)
+        err_blk = float(np.abs(E[..., :81].double().cpu().numpy() - ref).max())
+        g0, g1, fl = gpu(f0), gpu(f1), gpu(flow)
+        out = torch.zeros((N, H, W, 81), device="cuda")
+        layer = pa.CostVolumeLayer(4)
+        layer._run(View(g0.data_ptr(), C, N, H, W, C), View(g1.data_ptr(), C, N, H, W, C),
+                   View(out.data_ptr(), 81, N, H, W, 81), flow=View(fl.data_ptr(), 2, N, H, W, 2), flow_scale=5.0, coarse=True)
+        err_f32 = float(np.abs(out.double().cpu().numpy() - ref).max())
+        assert err_blk <= 1.25 * err_f32 + 1e-12 * scale * scale, (scale, err_blk, err_f32)
+    f0, f1 = rnd((1, 8, 16, 96), 211), rnd((1, 8, 16, 96), 212)
+    f1[0, 3, 5, 7] = 70000.0
+    E, _ = _run_concat(pa, f0, f1, None, 1.0, 192, False, True, fill=0.0, blk=True)
+    cv = E[0, ..., :81]
+    assert bool(torch.isnan(cv).any())
+    # only entries that read pixel (3, 5) of f1: P pixel (y, x) with |y - 3| <= 4, |x - 5| <= 4
+    bad = torch.isnan(cv).any(dim=2)
+    ys, xs = torch.nonzero(bad, as_tuple=True)
+    assert int((ys - 3).abs().max()) <= 4 and int((xs - 5).abs().max()) <= 4
 
 
 @pytest.mark.parametrize("N,H,W,C,with_flow,copy,pad", [
