@@ -166,7 +166,7 @@ class PWCDCNet(object):
         # latency-bound coarse levels of one overlap the MFMA-bound layers of another (+4-5 % pairs/s at batch 8,
         # scripts/exp_two_streams.py, profiles/r02_bench_streams2.json).  Same results and the same stream semantics
         # for the caller (the side streams wait for the caller's stream, the caller's stream waits for them).
-        # streams=None (default): 2 for even batches of at least 4 pairs of the non-DC network, 1 otherwise; streams=1 switches it off
+        # streams=None (default): 1 since round 5 (effective_streams has the measurements); streams=K asks for K sub-batches
         # (per-kernel timings -- profilers, HIP events on the caller's stream -- need the single-stream form).
         self.streams = None if streams is None else max(1, int(streams))
         self._side_streams = {}
@@ -315,15 +315,16 @@ class PWCDCNet(object):
         return rep
 
     def effective_streams(self, shape):
-        """Number of sub-batches a batch of this (N, H, W, 3) shape is run as: `streams` if given (and dividing N), else
-        2 for even batches of at least 4 pairs of the non-DC network, else 1 -- what an interleaved A/B of the two forms says
-        since the big layers moved to the F16 pipe (profiles/r04_exp_streams_ab.txt: batch 4 +3.7 %, batch 8 +1-2 %, batch 32
-        +1 %; batch 2 -2.4 %, use_dc=True -2.5 %).  (The forward still falls back to 1 when no side stream on a hardware
-        queue of its own exists: side_stream_report.)"""
+        """Number of sub-batches a batch of this (N, H, W, 3) shape is run as: `streams` if given (and dividing N), else 1.
+        Rounds 2-4 cut even batches of at least 4 pairs in two (+4-5 %, later +1-2 %: the latency-bound small levels of one
+        half ran under the matrix-bound layers of the other).  With the small levels on conv3x3_sk.hip / cost_volume_blk.hip
+        (round 5) halving the batch costs what the overlap gains: batch 2 / 4 / 8 / 16 / 32, one stream against two: 2001 /
+        1969, 2598 / 2640, 3094 / 3031, 3441 / 3337, 3566 / 3593 pairs/s (profiles/r05_exp_streams_ab.txt) -- so the default is
+        the single stream, which also keeps per-kernel timings meaningful; streams=2 remains available."""
         n_batch = int(shape[0]) if len(shape) >= 1 else 0
         k = self.streams
         if k is None:
-            k = 2 if (n_batch % 2 == 0 and n_batch >= 4 and not getattr(self, "use_dc", False)) else 1
+            k = 1
         if k > 1 and (n_batch % k != 0 or n_batch < k):
             k = 1
         return k

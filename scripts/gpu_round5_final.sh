@@ -9,7 +9,7 @@ cd $R
 timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/gpu_tests.txt
 timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench_default.json
 timeout 600 python bench.py --steps 120 --warmup 10 --no-cpu-baseline --no-op-leg 2>/dev/null | tail -1 > $O/bench_default_120steps.json
-timeout 600 python bench.py --streams 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_streams1.json
+timeout 600 python bench.py --streams 2 --no-cpu-baseline --no-op-leg 2>/dev/null | tail -1 > $O/bench_streams2.json
 timeout 300 python bench.py --gpus 1 --spawn --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_default_spawn.json
 timeout 600 python bench.py --config configs3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_configs3.json
 timeout 600 python bench.py --config configs4 --gpus 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_configs4_per_gpu.json
@@ -19,15 +19,24 @@ timeout 300 python bench.py --batch 2 --steps 100 --no-cpu-baseline --no-op-leg 
 timeout 300 python bench.py --mode train --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/bench_train.json
 timeout 300 python scripts/exp_timeline.py 8 > $O/timeline_batch8.txt 2>/dev/null
 timeout 200 python scripts/exp_host.py 1 > $O/exp_host_issue_vs_graph_b1.txt 2>&1
-timeout 300 ./scripts/exp_cv5.bin > $O/exp_cv5.txt 2>&1
-timeout 200 ./scripts/exp_membw.bin > $O/exp_membw.txt 2>&1
+for b in 8 1; do PYTHONPATH=. timeout 300 python scripts/exp_blk_ab.py $b 2>&1 | grep -v amdgpu.ids >> $O/exp_blk_ab.txt; done
+for b in 8 1; do PYTHONPATH=. timeout 300 python scripts/exp_sk_ab.py $b 2>&1 | grep -v amdgpu.ids >> $O/exp_sk_ab.txt; done
+for b in 8 2 1; do timeout 300 python scripts/exp_ab_model.py small_conv $b 2>&1 | grep -v amdgpu.ids >> $O/exp_ab_small_conv.txt; done
 timeout 600 python scripts/exp_ab_model.py f16x2 8 2>&1 | grep -v amdgpu.ids > $O/exp_ab_f16x2.txt
 timeout 600 python scripts/exp_ab_model.py f16x2_stream_k 8 2>&1 | grep -v amdgpu.ids > $O/exp_ab_stream_k.txt
-timeout 300 python bench.py --streams 1 --no-cpu-baseline --no-op-leg --batch 1 --steps 200 2>/dev/null | tail -1 > $O/bench_b1_streams1.json
 cd /tmp && export TMPDIR=/tmp
 C="python $R/bench.py --steps 10 --warmup 3 --streams 1 --no-cpu-baseline --no-op-leg"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- $C > $O/prof_stdout.log 2>&1
 python $R/scripts/kernel_stats_table.py $O/prof 44 > $O/kernel_stats.txt 2>&1
+python $R/scripts/kernel_trace_forward.py $O/prof > $O/forward_trace_b8.txt 2>&1
+for b in 1 2; do
+  rm -rf /tmp/kt$b
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt$b -o kt -- python $R/bench.py --batch $b --steps 4 --warmup 3 --streams 1 --no-cpu-baseline --no-op-timing --no-op-leg --no-fp32-leg > /dev/null 2>&1
+  python $R/scripts/kernel_trace_forward.py /tmp/kt$b > $O/forward_trace_b$b.txt 2>&1
+done
+rm -rf /tmp/opleg
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/opleg -o op -- python $R/bench.py --op-leg-only > /dev/null 2>&1
+python $R/scripts/kernel_stats_table.py /tmp/opleg 12 > $O/kernel_stats_op_leg.txt 2>&1
 C2="python $R/bench.py --steps 3 --warmup 2 --streams 1 --no-cpu-baseline --no-op-timing --no-op-leg"
 mkdir -p $O/pmc_req $O/pmc_mfma
 timeout 600 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d $O/pmc_req -o RD --output-format csv -- $C2 > /dev/null 2>&1

@@ -52,10 +52,10 @@ def test_effective_streams_rule():
     from pwcnet_amd.model import PWCDCNet
     rule = PWCDCNet.effective_streams
     auto = types.SimpleNamespace(streams=None)
-    assert rule(auto, (8, 448, 1024, 3)) == 2 and rule(auto, (4, 64, 128, 3)) == 2
-    assert rule(auto, (2, 448, 1024, 3)) == 1 and rule(auto, (2, 128, 192, 3)) == 1       # 2 pairs: one stream (measured)
+    assert rule(auto, (8, 448, 1024, 3)) == 1 and rule(auto, (4, 64, 128, 3)) == 1       # round 5: one stream (measured)
+    assert rule(auto, (2, 448, 1024, 3)) == 1 and rule(auto, (2, 128, 192, 3)) == 1
     dc = types.SimpleNamespace(streams=None, use_dc=True)
-    assert rule(dc, (8, 448, 1024, 3)) == 1                                               # the DC network: one stream (measured)
+    assert rule(dc, (8, 448, 1024, 3)) == 1
     assert rule(auto, (1, 448, 1024, 3)) == 1 and rule(auto, (3, 448, 1024, 3)) == 1 and rule(auto, (7, 448, 1024, 3)) == 1
     two, one, four = (types.SimpleNamespace(streams=k) for k in (2, 1, 4))
     assert rule(two, (6, 64, 64, 3)) == 2 and rule(two, (5, 64, 64, 3)) == 1 and rule(one, (8, 448, 1024, 3)) == 1
