@@ -422,10 +422,11 @@ def main():
                                   "fp16((x - h) 2^11)), products uh vh + 2^-11 (uh vm' + um' vh) on v_mfma_f32_32x32x16_f16: "
                                   "error 0.1x that of the fp32 F(4x4) kernel it replaces (profiles/r04_exp_h2.txt)")
             roof["sustained_matrix_rate"] = {
-                "frac_of_peak": 0.65,
-                "why": "a loop of nothing but v_mfma_f32_32x32x16_f16 on random operands, two waves per SIMD on all 256 CUs, runs "
-                       "at 493 ns per 24 instructions = 1.6 PFLOP/s (350 ns on all-zero operands): the clock drops under the "
-                       "matrix pipe's load (profiles/r04_exp_h2_micro.txt); frac_executed against THAT rate = frac_executed / 0.65"}
+                "frac_of_peak": 0.69,
+                "why": "a loop of nothing but F16 matrix instructions on all 256 CUs runs at 2398 MHz / 848 W on all-zero operands "
+                       "(2.46 PFLOP/s) and at ~1700 MHz under the ~1300 W cap on N(0,1) or split operands = 1.74 PFLOP/s "
+                       "(sclk / power log: profiles/r05_exp_h2_micro_clock_power.txt; round 4's 493 ns per 24 instructions, "
+                       "profiles/r04_exp_h2_micro.txt); frac_executed against THAT rate = frac_executed / 0.69"}
         caps = {"conv3x3_wino_kernel": 0.83, "conv3x3_wino4_kernel": 0.62}
         if dominant in caps:
             roof["instruction_mix_cap"] = {

@@ -25,11 +25,10 @@ for b in 8 2 1; do timeout 300 python scripts/exp_ab_model.py small_conv $b 2>&1
 timeout 600 python scripts/exp_ab_model.py f16x2 8 2>&1 | grep -v amdgpu.ids > $O/exp_ab_f16x2.txt
 timeout 600 python scripts/exp_ab_model.py f16x2_stream_k 8 2>&1 | grep -v amdgpu.ids > $O/exp_ab_stream_k.txt
 cd /tmp && export TMPDIR=/tmp
-C="python $R/bench.py --steps 10 --warmup 3 --streams 1 --no-cpu-baseline --no-op-leg"
+C="python $R/bench.py --steps 10 --warmup 3 --streams 1 --no-cpu-baseline --no-op-leg --no-fp32-leg"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- $C > $O/prof_stdout.log 2>&1
 python $R/scripts/kernel_stats_table.py $O/prof 44 > $O/kernel_stats.txt 2>&1
-python $R/scripts/kernel_trace_forward.py $O/prof > $O/forward_trace_b8.txt 2>&1
-for b in 1 2; do
+for b in 8 1 2; do
   rm -rf /tmp/kt$b
   timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt$b -o kt -- python $R/bench.py --batch $b --steps 4 --warmup 3 --streams 1 --no-cpu-baseline --no-op-timing --no-op-leg --no-fp32-leg > /dev/null 2>&1
   python $R/scripts/kernel_trace_forward.py /tmp/kt$b > $O/forward_trace_b$b.txt 2>&1

@@ -331,7 +331,7 @@ def test_side_stream_probe_with_busy_dummy_streams(pa):
         torch.cuda.synchronize()
         return 1e3 * (time.perf_counter() - t0) / steps
 
-    clean = pa.PWCDCNet()
+    clean = pa.PWCDCNet(streams=2)                       # (one stream is the default since round 5: the probe only runs on request)
     clean.load_weights(w)
     base = ms_per_forward(clean)
     single = pa.PWCDCNet(streams=1)
@@ -346,7 +346,7 @@ def test_side_stream_probe_with_busy_dummy_streams(pa):
             with torch.cuda.stream(d):
                 junk.add_(1)
         torch.cuda.synchronize()
-        net = pa.PWCDCNet()
+        net = pa.PWCDCNet(streams=2)
         net.load_weights(w)
         t = ms_per_forward(net)
         rep = net.side_stream_report
