@@ -359,6 +359,24 @@ int pwc_conv3x3_sk_f32(const float* x, int x_cs, const float* packed_w, const fl
                        float slope, pwc_stream_t stream);
 int pwc_conv3x3_sk_supported(int N, int H, int W, int Cin_phys, int Cout, int stride, int dilation);
 int pwc_debug_conv3x3_sk_tile(int tile);
+
+/* Round 5: the same convolution for THIN inputs to 32 output channels (csrc/conv3x3_t32.hip) -- Cin_phys 16 (stride 1 | 2) or
+ * 32 (stride 1), Cout 32, no dilation: the feature extractor's full-resolution layers (reference modules.py:58-71,
+ * fp_extractor/conv2d_3 ... conv2d_5).  Weights STATIONARY: a wave keeps the split halves of the whole weight tensor in
+ * registers (9 or 18 K steps of a 32 x 32 x 16 matrix instruction whose row operand is all 32 output channels) and only pixel
+ * fragments move: a workgroup walks over tiles of 8 rows x 32 pixels, the next tile's input patch arrives by LDS-DMA while the
+ * four waves compute the current one; one barrier per tile.  Arithmetic, RANGE and alignment requirements of
+ * pwc_conv3x3_sk_f32.  packed_w: pwc_conv3x3_t32_pack_f32 (pwc_conv3x3_t32_packed_floats floats; cin_map as in
+ * pwc_conv3x3_pack_f32).  pwc_conv3x3_t32_supported: 1 where it is the fastest kernel of this library for the shape (a
+ * supported shape with at least 256 tiles), else 0. */
+size_t pwc_conv3x3_t32_packed_floats(int Cin_phys);
+int pwc_conv3x3_t32_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin, int Cin_phys, float* packed_w,
+                             pwc_stream_t stream);
+int pwc_conv3x3_t32_f32(const float* x, int x_cs, const float* packed_w, const float* bias, float* y, int y_cs,
+                        int N, int H, int W, int Cin_phys, int Cout, int stride, int apply_act, float slope,
+                        pwc_stream_t stream);
+int pwc_conv3x3_t32_supported(int N, int H, int W, int Cin_phys, int Cout, int stride);
+int pwc_debug_conv3x3_t32(int bits);   /* experiment knob (scripts/exp_t32_ab.py): 1 no fetches, 2 no matrix work, 4 no stores; 0 = production */
 /* Tile variants of the kernel above (workgroup = couts x rows x 32 columns): 1 = 128 x 8, 2 = 64 x 16, 3 = 96 x 8,
  * 4 = 32 x 16, 5 = 64 x 8.  pwc_conv3x3_h2_plan: the one pwc_conv3x3_h2_f32 launches for a shape (fewest estimated
  * rounds of 256 workgroups x matrix instructions per tap; 0 = the shape is not accepted).  pwc_conv3x3_h2_variant_f32:

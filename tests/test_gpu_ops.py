@@ -413,6 +413,75 @@ def test_conv_small_launch_kernel_vs_oracle(pa, N, H, W, cin, cout, stride, dil,
         L.pwc_debug_conv3x3_sk_tile(0)
 
 
+@pytest.mark.parametrize("N,H,W,cin,stride", [
+    (2, 112, 256, 32, 1), (16, 112, 256, 32, 1), (2, 224, 512, 16, 2), (16, 224, 512, 16, 2), (1, 40, 70, 32, 1), (3, 33, 45, 16, 2),
+    (1, 30, 64, 16, 1), (2, 9, 13, 16, 2), (1, 8, 32, 32, 1), (1, 3, 5, 32, 1), (1, 1, 1, 16, 2), (2, 61, 100, 16, 2)])
+def test_conv_thin_input_kernel_vs_oracle(pa, N, H, W, cin, stride):
+    """pwc_conv3x3_t32_f32 (round 5, conv3x3_t32.hip: weights stationary, patches by LDS-DMA): fp_extractor/conv2d_3 (16 -> 32,
+    stride 2) and conv2d_4 (32 -> 32) of BASELINE configs[1] at full size, ragged tiles (H % 8, W % 32 != 0), odd sizes under stride
+    2, images smaller than a tile, fewer tiles than workgroups; strided output with untouched neighbours; padded / permuted input
+    channels; launches repeat bitwise."""
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    cout = 32
+    x = rnd((N, H, W, cin), 571)
+    k = rnd((3, 3, cin, cout), 572) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 573) * 0.1
+    xg, kg, bg = gpu(x), gpu(k), gpu(b)
+    packed = torch.empty(L.pwc_conv3x3_t32_packed_floats(cin), device="cuda")
+    _lib.check(L.pwc_conv3x3_t32_pack_f32(_p(kg), None, cin, cin, _p(packed), None))
+    big = N * H * W > 200000
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    ys = []
+    for _ in range(2):
+        y = torch.full((N, Ho, Wo, cout + 8), -7.0, device="cuda")
+        _lib.check(L.pwc_conv3x3_t32_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout + 8, N, H, W, cin, cout, stride, 1, 0.1, None))
+        torch.cuda.synchronize()
+        ys.append(y)
+    assert torch.equal(ys[0], ys[1])
+    assert float(ys[0][..., cout:].min()) == -7.0 and float(ys[0][..., cout:].max()) == -7.0
+    if big:
+        for i in (0, N - 1):
+            close(ys[0][i:i + 1, ..., :cout], orc.conv3x3(x[i:i + 1], k, b, stride, 1, 0.1))
+        assert bool(torch.isfinite(ys[0]).all())
+        return
+    close(ys[0][..., :cout], orc.conv3x3(x, k, b, stride, 1, 0.1))
+    y = torch.empty((N, Ho, Wo, cout), device="cuda")
+    _lib.check(L.pwc_conv3x3_t32_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout, N, H, W, cin, cout, stride, 0, 0.0, None))
+    close(y, orc.conv3x3(x, k, b, stride, 1, None))
+    # physical layout: 12 / 20 logical channels scattered over the 16 / 32 physical ones, channel stride beyond them
+    cl = cin - 4 if cin == 16 else cin - 12
+    rs = np.random.RandomState(7)
+    pos = np.sort(rs.choice(cin, cl, replace=False))
+    cmap = np.full((cin,), -1, np.int32)
+    cmap[pos] = np.arange(cl, dtype=np.int32)
+    xl = rnd((N, H, W, cl), 574)
+    xp = rnd((N, H, W, cin + 4), 575)
+    xp[..., pos] = xl
+    kl = rnd((3, 3, cl, cout), 576) * float(1.0 / np.sqrt(9 * cl))
+    cm = torch.from_numpy(cmap).cuda()
+    packed2 = torch.empty(L.pwc_conv3x3_t32_packed_floats(cin), device="cuda")
+    _lib.check(L.pwc_conv3x3_t32_pack_f32(_p(gpu(kl)), _p(cm), cl, cin, _p(packed2), None))
+    xpg = gpu(xp)
+    _lib.check(L.pwc_conv3x3_t32_f32(_p(xpg), cin + 4, _p(packed2), _p(bg), _p(y), cout, N, H, W, cin, cout, stride, 1, 0.1, None))
+    close(y, orc.conv3x3(xl, kl, b, stride, 1, 0.1))
+
+
+def test_conv_thin_input_kernel_rejections(pa):
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    x = torch.zeros((1, 8, 32, 32), device="cuda")
+    y = torch.zeros((1, 8, 32, 32), device="cuda")
+    w = torch.zeros((L.pwc_conv3x3_t32_packed_floats(32),), device="cuda")
+    b = torch.zeros((32,), device="cuda")
+    assert L.pwc_conv3x3_t32_f32(_p(x), 32, _p(w), _p(b), _p(y), 32, 1, 8, 32, 32, 32, 2, 1, 0.1, None) == -4      # 32 channels, stride 2
+    assert L.pwc_conv3x3_t32_f32(_p(x), 32, _p(w), _p(b), _p(y), 32, 1, 8, 32, 32, 64, 1, 1, 0.1, None) == -4      # C_out
+    assert L.pwc_conv3x3_t32_f32(_p(x), 32, _p(w), _p(b), _p(y), 32, 1, 8, 32, 48, 32, 1, 1, 0.1, None) == -4      # C_in
+    assert L.pwc_conv3x3_t32_supported(16, 112, 256, 32, 32, 1) == 0 and L.pwc_conv3x3_t32_supported(16, 224, 512, 16, 32, 2) == 1
+    assert L.pwc_conv3x3_t32_supported(1, 112, 256, 32, 32, 1) == 0 and L.pwc_conv3x3_t32_supported(16, 112, 256, 32, 64, 2) == 0
+    assert L.pwc_conv3x3_t32_packed_floats(48) == 0
+
+
 def test_conv_small_launch_kernel_error_range_and_rejections(pa):
     """The small-launch kernel against a float64 convolution: not further from it than the fp32 matrix-pipe kernel; an input
     beyond fp16's range gives NaN in the outputs that read it; unsupported shapes / alignments are refused."""
