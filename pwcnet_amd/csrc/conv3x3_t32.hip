@@ -42,7 +42,7 @@ struct T32Args {
 
 template <int CIN, int S>
 struct T32Geom {
-    static constexpr int RPW = S == 1 ? 2 : 1;                     // output rows per wave
+    static constexpr int RPW = 1;                                  // output rows per wave (two: 64 more registers, one workgroup per CU: slower)
     static constexpr int TR = 4 * RPW, TW = 32;                    // output rows x columns of a tile
     static constexpr int PR = (TR - 1) * S + 3;                    // patch rows
     static constexpr int PC = (TW - 1) * S + 3;                    // patch columns
@@ -58,7 +58,7 @@ struct T32Geom {
     static constexpr int NP8 = (CIN / 8) * NPAR;                   // (8-channel group, parity) planes of the operand image
     static constexpr int OPI = NP8 * 2 * PLANE;                    // h plane + m' plane each
     static constexpr int OPX = 144;                                // bytes of an output pixel record in the LDS (128 + 16: conflict-free)
-    static constexpr bool OUTLDS = S == 1;                         // stride 2: results wait in registers instead, two workgroups per CU
+    static constexpr bool OUTLDS = false;                          // (true: finished rows through the LDS as 1 KB stores -- costs the second workgroup per CU)
     static constexpr int OUT = OUTLDS ? 4 * RPW * 32 * OPX : 0;   // finished rows, one region per wave
     static constexpr int NOW = RPW * 4;                            // 1 KB store instructions per wave and tile
     static constexpr int LDS = RAW + OPI + OUT;
@@ -295,12 +295,15 @@ extern "C" int pwc_conv3x3_t32_pack_f32(const float* w_hwio, const int32_t* cin_
 extern "C" int pwc_conv3x3_t32_supported(int N, int H, int W, int Cin_phys, int Cout, int stride) {
     if (N <= 0 || H <= 0 || W <= 0 || (Cin_phys != 16 && Cin_phys != 32) || Cout != 32 || stride < 1 || stride > 2) return 0;
     if (Cin_phys == 32 && stride == 2) return 0;                 // (two parity planes of 32 channels do not fit the LDS twice)
+    // 32 input channels: the entry point takes them, but 144 weight registers beside the fragments and accumulators leave one wave
+    // per SIMD (or spill) and the launch loses to conv3x3_h2_kernel (52 - 77 us against 48 at 16 x 112 x 256; in the forward
+    // 2.599 against 2.582 ms)
+    if (Cin_phys == 32) return 0;
     // 32 input channels: the entry point takes them, but 144 weight registers beside the fragments and accumulators spill into
     // the accumulation registers and the launch loses to conv3x3_h2_kernel (52 - 73 us against 48 at 16 x 112 x 256)
-    if (Cin_phys == 32) return 0;
     if ((long)N * H * W * Cin_phys * 4 >= (1L << 31)) return 0;
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
-    const int tr = stride == 1 ? 8 : 4;
+    const int tr = 4;
     return (long)N * ((Ho + tr - 1) / tr) * ((Wo + 31) / 32) >= 256 ? 1 : 0;
 }
 
@@ -344,7 +347,7 @@ extern "C" int pwc_conv3x3_t32_f32(const float* x, int x_cs, const float* packed
     pwc_same_pad(H, stride, 1, &a.Ho, &a.pad_t);
     pwc_same_pad(W, stride, 1, &a.Wo, &a.pad_l);
     a.apply_act = apply_act; a.slope = slope;
-    const int tr = stride == 1 ? 8 : 4;          // T32Geom::TR
+    const int tr = 4;          // T32Geom::TR
     a.tiles_x = (a.Wo + 31) / 32; a.tiles_y = (a.Ho + tr - 1) / tr;
     const long nt = (long)N * a.tiles_x * a.tiles_y;
     if (nt >= (1L << 30)) return PWC_ERANGE;

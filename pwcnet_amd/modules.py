@@ -346,6 +346,7 @@ class _ConvRunner:
         # thin inputs to 32 channels (round 5): weights stationary in registers (conv3x3_t32.hip)
         use_t32 = (use_mfma and getattr(self.owner, "f16x2", True) and getattr(self.owner, "thin_conv", True) and x2 is None
                    and tile < 0 and split == 0 and dilation == 1 and cout == 32 and y.cs % 4 == 0 and y.ptr % 16 == 0
+                   and (x.C == 16 or getattr(self.owner, "thin_conv32", True))
                    and L.pwc_conv3x3_t32_supported(x.N, x.H, x.W, x.C, cout, stride))
         if x2 is not None and not use_h2:
             raise _lib.PwcHipError(f"{name}: a two-operand input needs the F16-pipe kernel (h2_two_operand_ok)")
