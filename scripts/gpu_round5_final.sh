@@ -7,6 +7,7 @@ O=$R/gpurun_out/final5
 rm -rf $O; mkdir -p $O
 cd $R
 timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/gpu_tests.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench_default.json
 timeout 600 python bench.py --steps 120 --warmup 10 --no-cpu-baseline --no-op-leg 2>/dev/null | tail -1 > $O/bench_default_120steps.json
 timeout 600 python bench.py --streams 2 --no-cpu-baseline --no-op-leg 2>/dev/null | tail -1 > $O/bench_streams2.json
@@ -21,6 +22,8 @@ timeout 300 python scripts/exp_timeline.py 8 > $O/timeline_batch8.txt 2>/dev/nul
 timeout 200 python scripts/exp_host.py 1 > $O/exp_host_issue_vs_graph_b1.txt 2>&1
 for b in 8 1; do PYTHONPATH=. timeout 300 python scripts/exp_blk_ab.py $b 2>&1 | grep -v amdgpu.ids >> $O/exp_blk_ab.txt; done
 for b in 8 1; do PYTHONPATH=. timeout 300 python scripts/exp_sk_ab.py $b 2>&1 | grep -v amdgpu.ids >> $O/exp_sk_ab.txt; done
+PYTHONPATH=. timeout 300 python scripts/exp_t32_ab.py 8 2>&1 | grep -v amdgpu.ids > $O/exp_t32_ab.txt
+timeout 300 python scripts/exp_ab_model.py thin_conv 8 2>&1 | grep -v amdgpu.ids > $O/exp_ab_thin_conv.txt
 for b in 8 2 1; do timeout 300 python scripts/exp_ab_model.py small_conv $b 2>&1 | grep -v amdgpu.ids >> $O/exp_ab_small_conv.txt; done
 timeout 600 python scripts/exp_ab_model.py f16x2 8 2>&1 | grep -v amdgpu.ids > $O/exp_ab_f16x2.txt
 timeout 600 python scripts/exp_ab_model.py f16x2_stream_k 8 2>&1 | grep -v amdgpu.ids > $O/exp_ab_stream_k.txt
