@@ -44,6 +44,37 @@ def test_library_exports_every_declared_symbol():
     assert L.pwc_conv3x3_f32(None, 16, None, None, None, 16, 1, 4, 4, 16, 16, 1, 1, 1, 0.1, -1, 0, None, 0, None) == -1
 
 
+def test_round5_routing_rules_are_host_logic():
+    """Which kernel takes which launch is decided by pure host functions of the library (no GPU needed): the small-launch conv
+    (up to 1e8 multiply-adds and 4096 output pixels; stride-2 / thin layers beyond), the weights-stationary thin-input conv
+    (16 input channels, 32 output channels, at least 256 tiles), the block correlation (alignment only: the pixel limit is the
+    caller's), packed sizes, and argument validation before any launch."""
+    L = _lib.lib()
+    sk = L.pwc_conv3x3_sk_supported
+    # BASELINE configs[1], batch 8: estimator levels 0-1, the extractor's last levels (both frames stacked: N = 16)
+    assert sk(8, 7, 16, 288, 128, 1, 1) == 1 and sk(8, 14, 32, 128, 128, 1, 1) == 1 and sk(16, 14, 32, 128, 192, 2, 1) == 1
+    assert sk(8, 14, 32, 256, 128, 1, 1) == 0            # 1.17e8 multiply-adds: the tiled kernel + reduce is faster (measured)
+    assert sk(16, 14, 32, 128, 128, 1, 1) == 0           # 7168 output pixels, not thin
+    assert sk(16, 28, 64, 96, 128, 2, 1) == 1            # stride 2 beyond 4096 pixels
+    assert sk(8, 28, 64, 64, 32, 1, 1) == 1              # thin layer beyond 4096 pixels
+    assert sk(8, 112, 256, 128, 128, 1, 1) == 0 and sk(8, 7, 16, 48, 128, 1, 1) == 0 and sk(8, 7, 16, 64, 24, 1, 1) == 0
+    assert sk(1, 112, 256, 32, 32, 1, 1) == 1            # a single pair: 28672 pixels but 2.9e7 multiply-adds
+    assert L.pwc_conv3x3_sk_packed_floats(288, 128) == 9 * 288 * 128 and L.pwc_conv3x3_sk_packed_floats(48, 128) == 0
+    t32 = L.pwc_conv3x3_t32_supported
+    assert t32(16, 224, 512, 16, 32, 2) == 1 and t32(16, 112, 256, 32, 32, 1) == 0 and t32(16, 224, 512, 16, 16, 2) == 0
+    assert t32(1, 64, 128, 16, 32, 2) == 0               # 16 tiles: not worth a persistent launch
+    assert L.pwc_conv3x3_t32_packed_floats(16) == 9 * 512 and L.pwc_conv3x3_t32_packed_floats(32) == 18 * 512
+    blk = L.pwc_warp_cost_volume_concat_blk_supported
+    assert blk(7, 16, 192, 4, 192, 192, 0, 288, 288) == 1 and blk(14, 32, 128, 4, 128, 128, 2, 256, 256) == 1
+    assert blk(14, 32, 32, 4, 32, 32, 2, 128, 0) == 0 and blk(14, 32, 128, 3, 128, 128, 2, 256, 256) == 0
+    assert blk(14, 32, 128, 4, 130, 128, 2, 256, 256) == 0      # channel stride % 4
+    assert L.pwc_conv3x3_h2_stride2_supported(16, 224, 512, 16, 32) in (0, 1)
+    # validation before any launch
+    assert L.pwc_conv3x3_sk_f32(None, 32, None, None, None, 32, 1, 4, 4, 32, 32, 1, 1, 1, 0.1, None) == -1
+    assert L.pwc_conv3x3_t32_f32(None, 16, None, None, None, 32, 1, 4, 4, 16, 32, 1, 1, 0.1, None) == -1
+    assert L.pwc_warp_cost_volume_concat_blk_f32(None, 128, None, 128, None, 0, 1.0, None, 84, 1, None, 0, 1, 4, 4, 128, 4, 0.1, None) == -1
+
+
 def test_effective_streams_rule():
     """PWCDCNet.effective_streams: the one place that decides into how many sub-batches a batch is cut (bench.py asks the model
     instead of restating the rule).  Constructing the model needs the library, not a GPU... but its VariableStore allocates
