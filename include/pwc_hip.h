@@ -239,7 +239,10 @@ int pwc_conv3x3_wino4_supported(int N, int H, int W, int Cin_phys, int Cout, int
  * layer shape (profiles/r04_exp_h2.txt), 0.4x that of a v_mfma_f32_16x16x4_f32 chain (profiles/
  * r04_exp_f16x2_numerics.txt).  RANGE: inputs and weights must be below 65504 in magnitude (fp16's largest finite
  * value); a larger input makes the outputs that depend on it NaN (inf - inf in the split), never a silently wrong
- * number.  packed_w comes from pwc_conv3x3_h2_pack_f32 (split weights, pwc_conv3x3_h2_packed_floats floats; same
+ * number.  LOWER END: the split is exact to 22 bits for |x| >= 2^-14 (6e-5); below that h and m' reach fp16's subnormals and
+ * the operand carries an ABSOLUTE error of up to 1.5e-11 (3e-4 relative at |x| = 1e-7) -- harmless for activations and
+ * weights that are summed with terms of ordinary size, not for a tensor that is small as a whole: the training path keeps its
+ * data gradients on the fp32 kernels for that reason (pwcnet_amd/train.py, Trainer(f16x2_dgrad=False)).  packed_w comes from pwc_conv3x3_h2_pack_f32 (split weights, pwc_conv3x3_h2_packed_floats floats; same
  * cin_map semantics as pwc_conv3x3_pack_f32).  Needs Cout % 32 == 0, Cout <= 512, Cin_phys % 16 == 0, x and y 16-byte aligned with
  * x_cs % 4 == 0 and y_cs % 4 == 0.  pwc_conv3x3_h2_supported: 1 where it is the fastest kernel of this library for the
  * shape (Cin_phys >= 32, sub-lattices of at least 7 x 24 pixels -- narrower ones of an even dilation are taken two at a time
