@@ -167,6 +167,156 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sk_kernel(const SkArgs a) {
     }
 }
 
+// ---- the same with the input PATCH of the workgroup staged in the LDS (stride 1, dilation 1): the workgroup's 6 x (4 MT + 2)
+// input pixels are fetched once, 16 bytes per lane in pixel order (whole lines), and the waves read their tap-shifted fragments
+// from the LDS.  The direct form asks the texture addressers for every fragment of every tap in operand order (lane = pixel:
+// no two neighbouring lanes in one line) -- nine times the bytes at a quarter of the rate; that is what bounds it from a few
+// thousand pixels on.  Pixel records are padded by 16 bytes so that the 16 pixels of a fragment read fall into different banks.
+template <int MT, int NT, int PB>
+__global__ __launch_bounds__(512, 2) void conv3x3_skp_kernel(const SkArgs a) {
+    constexpr int PCW = 4 * MT + 2, NPX = 6 * PCW;
+    extern __shared__ __attribute__((aligned(16))) char skp_smem[];
+    float* const part = reinterpret_cast<float*>(skp_smem);                 // 8 MT NT partial tiles
+    char* const patch = skp_smem + 8 * MT * NT * 1024;
+    const int ps = a.Cin_phys * 4 + 16;                                     // bytes of a pixel record
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    int b = blockIdx.x;
+    const int ct = b % a.nct;
+    b /= a.nct;
+    const int tx = b % a.ntx;
+    b /= a.ntx;
+    const int by = b % a.nby;
+    const int n = b / a.nby;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((size_t)a.N * a.H * a.W * a.x_cs * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.wp, 0, (int)((size_t)a.Cout * a.nsteps * 128), 0x00020000);
+    const int m = lane & 15, kq = lane >> 4;
+
+    // ---- this wave's weight fragments: all requests first (they land under the patch fetch)
+    constexpr int NB = (88 + 8 * PB - 1) / (8 * PB);                        // batches that cover 88 K steps (C_in <= 288)
+    sk_u32x4 bv[PB][NT][2];
+    auto fetch_b = [&](int s0) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int s = s0 + 8 * i;
+            const bool live = s < a.nsteps;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const unsigned vo = live ? (unsigned)(((ct * NT + nt) * a.nsteps + s) * 2048 + lane * 16) : SK_OOB;
+                bv[i][nt][0] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)vo, 0, 0);
+                bv[i][nt][1] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)vo, 1024, 0);
+            }
+        }
+    };
+    fetch_b(wave);
+    // ---- the patch: 16-byte unit u = (pixel u / cq, chunk u % cq), neighbouring lanes ask for neighbouring bytes
+    {
+        const int cq = a.Cin_phys >> 2;
+        const int nu = NPX * cq;
+        const int gy0 = 4 * by - a.pad_t, gx0 = 4 * tx * MT - a.pad_l;
+        constexpr int UMAX = (NPX * 72 + 511) / 512;                         // units per thread at C_in = 288
+        f32x4 v[UMAX];
+        int dst[UMAX];
+#pragma unroll
+        for (int k = 0; k < UMAX; ++k) {
+            const int u = t + 512 * k;
+            const int px = u / cq, c = u - px * cq;
+            const int pr = px / PCW, pc = px - pr * PCW;
+            const int gy = gy0 + pr, gx = gx0 + pc;
+            const bool ok = u < nu && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const unsigned vo = ok ? (unsigned)(((n * a.H + gy) * a.W + gx) * a.x_cs + c * 4) * 4u : SK_OOB;
+            v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, 0, 0));
+            dst[k] = u < nu ? px * ps + c * 16 : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < UMAX; ++k)
+            if (dst[k] >= 0) *reinterpret_cast<f32x4*>(patch + dst[k]) = v[k];
+    }
+    __syncthreads();
+
+    f32x4 hh[MT][NT], xx[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            hh[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            xx[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    // this lane's pixel of block mt in the patch (tap (0, 0)), as a byte offset incl. its channel group
+    int pbase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) pbase[mt] = ((m >> 2) * PCW + 4 * mt + (m & 3)) * ps + kq * 32;
+
+#pragma unroll 1
+    for (int bi = 0; bi < NB; ++bi) {
+        const int s0 = wave + 8 * PB * bi;
+        if (s0 >= a.nsteps) break;
+        if (bi > 0) fetch_b(s0);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int s = s0 + 8 * i;                               // wave-uniform
+            if (s < a.nsteps) {
+                const int tap = s / a.cg, c32 = s - tap * a.cg;
+                const int dy = tap / 3, dx = tap - 3 * dy;
+                const int toff = (dy * PCW + dx) * ps + c32 * 128;
+                pwc_f16x8 ah[MT], am[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(patch + pbase[mt] + toff);
+                    const f32x4 r1 = *reinterpret_cast<const f32x4*>(patch + pbase[mt] + toff + 16);
+                    pwc_f16x4 h0, m0, h1, m1;
+                    pwc_split4(r0, h0, m0);
+                    pwc_split4(r1, h1, m1);
+                    ah[mt] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    am[mt] = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const pwc_f16x8 bh = __builtin_bit_cast(pwc_f16x8, bv[i][nt][0]);
+                    const pwc_f16x8 bm = __builtin_bit_cast(pwc_f16x8, bv[i][nt][1]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        xx[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bm, xx[mt][nt], 0, 0, 0);
+                        hh[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh, hh[mt][nt], 0, 0, 0);
+                        xx[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am[mt], bh, xx[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- the eight partial tiles meet in the LDS: D fragment = (pixel 4 kq + r, output channel m)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 s = __builtin_elementwise_fma(xx[mt][nt], f32x4{1.f / 2048.f, 1.f / 2048.f, 1.f / 2048.f, 1.f / 2048.f},
+                                                      hh[mt][nt]);
+            float* p = part + ((wave * MT + mt) * NT + nt) * 256;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[(4 * kq + r) * 16 + m] = s[r];
+        }
+    __syncthreads();
+    for (int it = t; it < MT * NT * 64; it += 512) {
+        const int tile = it >> 6, px = (it >> 2) & 15, q = it & 3;
+        const int mt = tile / NT, nt = tile - mt * NT;
+        const int co = (ct * NT + nt) * 16 + q * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += *reinterpret_cast<const f32x4*>(part + ((w * MT + mt) * NT + nt) * 256 + px * 16 + q * 4);
+        if (a.apply_act) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = pwc_lrelu(v[k], a.slope);
+        }
+        const int oy = 4 * by + (px >> 2), ox = 4 * (tx * MT + mt) + (px & 3);
+        if (oy < a.Ho && ox < a.Wo)
+            *reinterpret_cast<f32x4*>(a.y + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.y_cs + co) = v;
+    }
+}
+
 // packed[cb][s][hm][lane][e] (fp16): weight of output channel 16 cb + (lane & 15), tap s / cg, physical input channel
 // 32 (s % cg) + 8 (lane >> 4) + e -- the B fragment of K step s, h halves then m' halves
 __global__ void conv3x3_sk_pack_kernel(const float* __restrict__ w, const int32_t* __restrict__ cin_map, int Cin, int Cin_phys,
@@ -218,14 +368,18 @@ extern "C" int pwc_conv3x3_sk_pack_f32(const float* w_hwio, const int32_t* cin_m
 
 // 1 where this is the fastest kernel of the library for the shape, 0 otherwise; the entry point accepts every shape that meets
 // the requirements.  Measured (scripts/exp_sk_ab.py and the kernel traces of forwards with / without this kernel,
-// profiles/r05_exp_sk_ab.txt, r05_forward_trace_b8*.txt): it wins up to about 1e8 multiply-adds per launch (output pixels x C_in
-// x C_out) at up to 4096 output pixels -- 14 x 32 x 128 -> 128 of a batch of 8: 15.7 us against 13.0 + 5.3 -- and loses beyond
-// (14 x 32 x 256 -> 128: 28.1 against 25.0; 14 x 32 x 128 -> 128 of 16 images: 30.8 against 20.2; 28 x 64 x 224 -> 128: 64 against
-// 33): every workgroup fetches its tile's weights and pixels on its own, and that traffic grows with the pixel count while
-// the tiled kernels' does not.  Past 4096 pixels it still takes the stride-2 layers (the tiled stride-2 path is the fp32 one:
-// 25.5 against 29.7 at 28 x 64 x 96 -> 128 / 2) and thin layers (28 x 64 x 64 -> 32: 8.2 against 11.4).
+// profiles/r05_exp_sk_ab.txt, r05_forward_trace_b8*.txt).  With the patch in the LDS (stride 1, no dilation, up to 288 input
+// channels) it wins up to about 2.4e8 multiply-adds (output pixels x C_in x C_out) and 8 K output pixels: 14 x 32 x 256 -> 128 of
+// a batch of 8: 16.1 us against 20.8 + 5.0 for the tiled kernel and its reduce dispatch (19.6 in the forward); at 28 x 64 (14 K
+// pixels) it is level with the Winograd kernels in the forward (33.8 / 28.2 / 17.6 against 31.8 / 29.9 / 17.1 us) and loses on
+// the widest layer (28 x 64 x 224 -> 128: 48.9 against 33.4 on conv3x3_h2_kernel): every workgroup fetches its tile's weights on
+// its own, and that traffic grows with the pixel count while the tiled kernels' does not.  With fragments straight from global
+// memory (stride 2, dilation): up to 1e8 multiply-adds and 4096 output pixels, beyond that pixel count the stride-2 layers
+// (the tiled stride-2 path is the fp32 one: 25.5 against 29.7 at 28 x 64 x 96 -> 128 / 2) and thin layers.
 #define PWC_SK_MAX_MACS 100000000L
 #define PWC_SK_THIN_MACS 32000000L
+#define PWC_SK_LP_MAX_MACS 240000000L
+#define PWC_SK_LP_MAX_PIXELS 8192L
 extern "C" int pwc_conv3x3_sk_supported(int N, int H, int W, int Cin_phys, int Cout, int stride, int dilation) {
     if (!sk_shape_ok(N, H, W, Cin_phys, Cout, stride, dilation)) return 0;
     int Ho, Wo, pt, pl;
@@ -233,6 +387,8 @@ extern "C" int pwc_conv3x3_sk_supported(int N, int H, int W, int Cin_phys, int C
     pwc_same_pad(W, stride, dilation, &Wo, &pl);
     if ((long)N * H * W * Cin_phys * 4 >= (1L << 31)) return 0;
     const long M = (long)N * Ho * Wo, macs = M * Cin_phys * Cout;
+    if (stride == 1 && dilation == 1 && Cin_phys >= 96 && Cin_phys <= 288 && M <= PWC_SK_LP_MAX_PIXELS && macs <= PWC_SK_LP_MAX_MACS)
+        return 1;
     if (macs > PWC_SK_MAX_MACS) return 0;
     return (M <= 4096 || stride == 2 || macs <= PWC_SK_THIN_MACS) ? 1 : 0;
 }
@@ -247,7 +403,23 @@ static int sk_launch(SkArgs a, hipStream_t s) {
     return pwc_launch_status();
 }
 
-static int sk_tile_override = 0;   // experiment knob (pwc_debug_conv3x3_sk_tile): 11, 21, 22
+template <int MT, int NT, int PB>
+static int skp_launch(SkArgs a, hipStream_t s) {
+    a.ntx = (a.nbx + MT - 1) / MT;
+    a.nct = a.Cout / (16 * NT);
+    const long wgs = (long)a.N * a.nby * a.ntx * a.nct;
+    if (wgs >= (1L << 31)) return PWC_ERANGE;
+    const size_t lds = (size_t)8 * MT * NT * 1024 + (size_t)6 * (4 * MT + 2) * (a.Cin_phys * 4 + 16);
+    static PwcDevOnce attr_once;
+    if (pwc_first_on_device(&attr_once)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_skp_kernel<MT, NT, PB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 8 * MT * NT * 1024 + 6 * (4 * MT + 2) * (288 * 4 + 16));
+    }
+    hipLaunchKernelGGL((conv3x3_skp_kernel<MT, NT, PB>), dim3((unsigned)wgs), dim3(512), lds, s, a);
+    return pwc_launch_status();
+}
+
+static int sk_tile_override = 0;   // experiment knob (pwc_debug_conv3x3_sk_tile): 11, 21, 22 (fragments from global memory), 31, 41, 42 (patch in the LDS)
 
 extern "C" int pwc_debug_conv3x3_sk_tile(int tile) { sk_tile_override = tile; return 0; }
 
@@ -271,16 +443,24 @@ extern "C" int pwc_conv3x3_sk_f32(const float* x, int x_cs, const float* packed_
     a.nbx = (a.Wo + 3) / 4; a.nby = (a.Ho + 3) / 4;
     a.cg = Cin_phys / 32; a.nsteps = 9 * a.cg;
     a.ntx = a.nct = 0;
-    // tiles: 16 pixels x 16 channels while that makes at most two workgroups per CU (nothing to share yet: the smallest tile is
-    // the most parallel), else 32 x 32 (each weight and pixel fragment feeds two tiles: half the fetches per output; 7 x 16 x 192
-    // -> 192 of 16 images: 17.8 us against 27.8, 14 x 32 x 128 -> 128 of 8: 13.7 against 24.6)
+    // Form and tile (measured per layer shape, scripts/exp_sk_ab.py, profiles/r05_exp_sk_ab.txt).  Fragments straight from
+    // global memory: 16 pixels x 16 channels up to one workgroup per CU, 32 x 16 up to four, else 32 x 32.  Patch in the LDS
+    // (stride 1, no dilation, up to 288 input channels): from 192 input channels on always, from 96 on where the launch has more
+    // than one workgroup per CU -- 7 x 16 x 288 -> 128 of a batch of 8: 8.5 us against 12.8; 14 x 32 x 128 -> 128: 9.8 against 13.6;
+    // 7 x 16 x 192 -> 192 of 16 images: 11.5 against 17.9; thin layers (7 x 16 x 96 -> 64: 4.6 against 5.0) stay on the direct form.
     const long wgs11 = (long)N * a.nbx * a.nby * (Cout / 16);
-    int tile = wgs11 <= 512 ? 11 : (Cout % 32) ? 21 : 22;
-    if (sk_tile_override && !(sk_tile_override == 22 && Cout % 32)) tile = sk_tile_override;
+    int tile = wgs11 <= 256 ? 11 : (wgs11 <= 1024 || (Cout % 32)) ? 21 : 22;
+    const bool lp_ok = stride == 1 && dilation == 1 && Cin_phys <= 288;
+    if (lp_ok && (Cin_phys >= 192 || (Cin_phys >= 96 && wgs11 > 256)))
+        tile = wgs11 <= 256 ? 31 : (wgs11 <= 640 || (Cout % 32)) ? 41 : 42;
+    if (sk_tile_override && !((sk_tile_override % 10) == 2 && Cout % 32) && !(sk_tile_override > 30 && !lp_ok)) tile = sk_tile_override;
     hipStream_t s = (hipStream_t)stream;
     switch (tile) {
         case 11: return sk_launch<1, 1, 5>(a, s);
         case 21: return sk_launch<2, 1, 3>(a, s);
-        default: return sk_launch<2, 2, 2>(a, s);
+        case 22: return sk_launch<2, 2, 2>(a, s);
+        case 31: return skp_launch<1, 1, 11>(a, s);
+        case 41: return skp_launch<2, 1, 7>(a, s);
+        default: return skp_launch<2, 2, 3>(a, s);
     }
 }

@@ -21,8 +21,10 @@ for name, N, H, W, cin, cout, stride in SHAPES:
     xs = [torch.randn((N, H, W, cin), device="cuda") for _ in range(4)]
     ys = [torch.empty((N, Ho, Wo, cout), device="cuda") for _ in range(4)]
     line = f"{name:24s} M={N * Ho * Wo:6d}"
-    for tile in (11, 21, 22):
-        if tile == 22 and cout % 32:
+    for tile in (11, 21, 22, 31, 41, 42):
+        if tile % 10 == 2 and cout % 32:
+            continue
+        if tile > 30 and stride != 1:
             continue
         L.pwc_debug_conv3x3_sk_tile(tile)
         s = torch.cuda.current_stream().cuda_stream

@@ -360,7 +360,7 @@ def test_conv_f16x2_direct_stream_k(pa, N, H, W, cin, cout, dil):
     (8, 7, 16, 64, 32, 1, 1), (8, 14, 32, 256, 128, 1, 1), (16, 14, 32, 128, 192, 2, 1), (16, 7, 16, 192, 192, 1, 1),
     (1, 5, 3, 32, 16, 1, 1), (2, 9, 21, 64, 48, 1, 2), (1, 13, 30, 96, 32, 2, 1), (2, 11, 7, 32, 32, 1, 4),
     (1, 1, 1, 64, 16, 1, 1), (1, 56, 128, 128, 96, 1, 1), (3, 8, 8, 352, 32, 1, 1)])
-@pytest.mark.parametrize("tile", [0, 11, 21, 22])
+@pytest.mark.parametrize("tile", [0, 11, 21, 22, 31, 41, 42])
 def test_conv_small_launch_kernel_vs_oracle(pa, N, H, W, cin, cout, stride, dil, tile):
     """pwc_conv3x3_sk_f32 (round 5, conv3x3_sk.hip: the K dimension of a tile over the eight waves of one workgroup): the
     estimator / extractor layers of BASELINE configs[1]'s two coarsest levels as they are, stride 2 (even and odd sizes),
@@ -369,8 +369,10 @@ def test_conv_small_launch_kernel_vs_oracle(pa, N, H, W, cin, cout, stride, dil,
     bitwise."""
     from pwcnet_amd import _lib
     L = _lib.lib()
-    if tile == 22 and cout % 32:
+    if tile % 10 == 2 and cout % 32:
         pytest.skip("the 2 x 2 tile needs C_out % 32 == 0")
+    if tile > 30 and (stride != 1 or dil != 1 or cin > 288):
+        pytest.skip("the LDS-patch form takes stride 1, dilation 1, up to 288 input channels")
     x = rnd((N, H, W, cin), 471)
     k = rnd((3, 3, cin, cout), 472) * float(1.0 / np.sqrt(9 * cin))
     b = rnd((cout,), 473) * 0.1
@@ -518,7 +520,8 @@ def test_conv_small_launch_kernel_error_range_and_rejections(pa):
     assert L.pwc_conv3x3_sk_supported(8, 7, 16, 288, 128, 1, 1) == 1
     assert L.pwc_conv3x3_sk_supported(8, 28, 64, 64, 32, 1, 1) == 1
     assert L.pwc_conv3x3_sk_supported(8, 28, 64, 224, 128, 1, 1) == 0
-    assert L.pwc_conv3x3_sk_supported(16, 14, 32, 128, 128, 1, 1) == 0
+    assert L.pwc_conv3x3_sk_supported(16, 14, 32, 128, 128, 1, 1) == 1      # round 5, patch in the LDS: up to 2.4e8 multiply-adds
+    assert L.pwc_conv3x3_sk_supported(8, 56, 128, 64, 32, 1, 1) == 0
     assert L.pwc_conv3x3_sk_supported(16, 28, 64, 96, 128, 2, 1) == 1
     assert L.pwc_conv3x3_sk_supported(8, 112, 256, 128, 128, 1, 1) == 0
     assert L.pwc_conv3x3_sk_supported(8, 7, 16, 48, 128, 1, 1) == 0

@@ -53,8 +53,11 @@ def test_round5_routing_rules_are_host_logic():
     sk = L.pwc_conv3x3_sk_supported
     # BASELINE configs[1], batch 8: estimator levels 0-1, the extractor's last levels (both frames stacked: N = 16)
     assert sk(8, 7, 16, 288, 128, 1, 1) == 1 and sk(8, 14, 32, 128, 128, 1, 1) == 1 and sk(16, 14, 32, 128, 192, 2, 1) == 1
-    assert sk(8, 14, 32, 256, 128, 1, 1) == 0            # 1.17e8 multiply-adds: the tiled kernel + reduce is faster (measured)
-    assert sk(16, 14, 32, 128, 128, 1, 1) == 0           # 7168 output pixels, not thin
+    assert sk(8, 14, 32, 256, 128, 1, 1) == 1            # patch in the LDS (stride 1, 96 ... 288 channels): up to 2.4e8 multiply-adds
+    assert sk(16, 14, 32, 128, 128, 1, 1) == 1 and sk(8, 28, 64, 128, 128, 1, 1) == 0     # up to 8 K output pixels
+    assert sk(8, 28, 64, 224, 128, 1, 1) == 0            # 4.1e8: conv3x3_h2_kernel is faster (measured)
+    assert sk(8, 56, 128, 128, 96, 1, 1) == 0            # 57344 output pixels
+    assert sk(16, 14, 32, 128, 128, 1, 2) == 0           # dilated: fragments from global memory, 7168 pixels, not thin
     assert sk(16, 28, 64, 96, 128, 2, 1) == 1            # stride 2 beyond 4096 pixels
     assert sk(8, 28, 64, 64, 32, 1, 1) == 1              # thin layer beyond 4096 pixels
     assert sk(8, 112, 256, 128, 128, 1, 1) == 0 and sk(8, 7, 16, 48, 128, 1, 1) == 0 and sk(8, 7, 16, 64, 24, 1, 1) == 0
