@@ -176,8 +176,8 @@ template <int MT, int NT, int PB>
 __global__ __launch_bounds__(512, 2) void conv3x3_skp_kernel(const SkArgs a) {
     constexpr int PCW = 4 * MT + 2, NPX = 6 * PCW;
     extern __shared__ __attribute__((aligned(16))) char skp_smem[];
-    float* const part = reinterpret_cast<float*>(skp_smem);                 // 8 MT NT partial tiles
-    char* const patch = skp_smem + 8 * MT * NT * 1024;
+    float* const part = reinterpret_cast<float*>(skp_smem);                 // 8 MT NT partial tiles: they take the patch's place
+    char* const patch = skp_smem;                                           // when every wave is done with it
     const int ps = a.Cin_phys * 4 + 16;                                     // bytes of a pixel record
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -288,6 +288,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_skp_kernel(const SkArgs a) {
         }
     }
 
+    __syncthreads();          // (the last fragment reads of every wave are behind this)
     // ---- the eight partial tiles meet in the LDS: D fragment = (pixel 4 kq + r, output channel m)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -409,11 +410,12 @@ static int skp_launch(SkArgs a, hipStream_t s) {
     a.nct = a.Cout / (16 * NT);
     const long wgs = (long)a.N * a.nby * a.ntx * a.nct;
     if (wgs >= (1L << 31)) return PWC_ERANGE;
-    const size_t lds = (size_t)8 * MT * NT * 1024 + (size_t)6 * (4 * MT + 2) * (a.Cin_phys * 4 + 16);
+    size_t lds = (size_t)6 * (4 * MT + 2) * (a.Cin_phys * 4 + 16);         // the patch; the partial tiles reuse its space
+    if (lds < (size_t)8 * MT * NT * 1024) lds = (size_t)8 * MT * NT * 1024;
     static PwcDevOnce attr_once;
     if (pwc_first_on_device(&attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_skp_kernel<MT, NT, PB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 8 * MT * NT * 1024 + 6 * (4 * MT + 2) * (288 * 4 + 16));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 6 * (4 * MT + 2) * (288 * 4 + 16));
     }
     hipLaunchKernelGGL((conv3x3_skp_kernel<MT, NT, PB>), dim3((unsigned)wgs), dim3(512), lds, s, a);
     return pwc_launch_status();
