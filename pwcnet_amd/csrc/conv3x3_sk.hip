@@ -172,9 +172,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sk_kernel(const SkArgs a) {
 // from the LDS.  The direct form asks the texture addressers for every fragment of every tap in operand order (lane = pixel:
 // no two neighbouring lanes in one line) -- nine times the bytes at a quarter of the rate; that is what bounds it from a few
 // thousand pixels on.  Pixel records are padded by 16 bytes so that the 16 pixels of a fragment read fall into different banks.
-template <int MT, int NT, int PB>
+template <int MT, int NT, int PB, int S>
 __global__ __launch_bounds__(512, 2) void conv3x3_skp_kernel(const SkArgs a) {
-    constexpr int PCW = 4 * MT + 2, NPX = 6 * PCW;
+    // (stride S: the patch is 3 S + 3 rows x (4 MT - 1) S + 3 columns; up to 288 input channels at stride 1, 128 at stride 2)
+    constexpr int PCW = (4 * MT - 1) * S + 3, NPX = (3 * S + 3) * PCW;
     extern __shared__ __attribute__((aligned(16))) char skp_smem[];
     float* const part = reinterpret_cast<float*>(skp_smem);                 // 8 MT NT partial tiles: they take the patch's place
     char* const patch = skp_smem;                                           // when every wave is done with it
@@ -216,8 +217,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_skp_kernel(const SkArgs a) {
     {
         const int cq = a.Cin_phys >> 2;
         const int nu = NPX * cq;
-        const int gy0 = 4 * by - a.pad_t, gx0 = 4 * tx * MT - a.pad_l;
-        constexpr int UMAX = (NPX * 72 + 511) / 512;                         // units per thread at C_in = 288
+        const int gy0 = 4 * by * S - a.pad_t, gx0 = 4 * tx * MT * S - a.pad_l;
+        constexpr int UMAX = (NPX * (S == 1 ? 72 : 32) + 511) / 512;         // units per thread at the widest input
         f32x4 v[UMAX];
         int dst[UMAX];
 #pragma unroll
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_skp_kernel(const SkArgs a) {
     // this lane's pixel of block mt in the patch (tap (0, 0)), as a byte offset incl. its channel group
     int pbase[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) pbase[mt] = ((m >> 2) * PCW + 4 * mt + (m & 3)) * ps + kq * 32;
+    for (int mt = 0; mt < MT; ++mt) pbase[mt] = ((m >> 2) * S * PCW + (4 * mt + (m & 3)) * S) * ps + kq * 32;
 
 #pragma unroll 1
     for (int bi = 0; bi < NB; ++bi) {
@@ -381,6 +382,7 @@ extern "C" int pwc_conv3x3_sk_pack_f32(const float* w_hwio, const int32_t* cin_m
 #define PWC_SK_THIN_MACS 32000000L
 #define PWC_SK_LP_MAX_MACS 240000000L
 #define PWC_SK_LP_MAX_PIXELS 8192L
+#define PWC_SK_S2_MAX_MACS 200000000L
 extern "C" int pwc_conv3x3_sk_supported(int N, int H, int W, int Cin_phys, int Cout, int stride, int dilation) {
     if (!sk_shape_ok(N, H, W, Cin_phys, Cout, stride, dilation)) return 0;
     int Ho, Wo, pt, pl;
@@ -390,6 +392,8 @@ extern "C" int pwc_conv3x3_sk_supported(int N, int H, int W, int Cin_phys, int C
     const long M = (long)N * Ho * Wo, macs = M * Cin_phys * Cout;
     if (stride == 1 && dilation == 1 && Cin_phys >= 96 && Cin_phys <= 288 && M <= PWC_SK_LP_MAX_PIXELS && macs <= PWC_SK_LP_MAX_MACS)
         return 1;
+    // stride 2: the tiled alternative is the fp32-pipe kernel (56 x 128 x 64 -> 96 / 2 of 16 images: 34 us against 43 - 46)
+    if (stride == 2 && dilation == 1 && Cin_phys >= 64 && Cin_phys <= 128 && macs <= PWC_SK_S2_MAX_MACS) return 1;
     if (macs > PWC_SK_MAX_MACS) return 0;
     return (M <= 4096 || stride == 2 || macs <= PWC_SK_THIN_MACS) ? 1 : 0;
 }
@@ -404,20 +408,21 @@ static int sk_launch(SkArgs a, hipStream_t s) {
     return pwc_launch_status();
 }
 
-template <int MT, int NT, int PB>
+template <int MT, int NT, int PB, int S>
 static int skp_launch(SkArgs a, hipStream_t s) {
     a.ntx = (a.nbx + MT - 1) / MT;
     a.nct = a.Cout / (16 * NT);
     const long wgs = (long)a.N * a.nby * a.ntx * a.nct;
     if (wgs >= (1L << 31)) return PWC_ERANGE;
-    size_t lds = (size_t)6 * (4 * MT + 2) * (a.Cin_phys * 4 + 16);         // the patch; the partial tiles reuse its space
+    constexpr int NPX = (3 * S + 3) * ((4 * MT - 1) * S + 3);
+    size_t lds = (size_t)NPX * (a.Cin_phys * 4 + 16);                      // the patch; the partial tiles reuse its space
     if (lds < (size_t)8 * MT * NT * 1024) lds = (size_t)8 * MT * NT * 1024;
     static PwcDevOnce attr_once;
     if (pwc_first_on_device(&attr_once)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_skp_kernel<MT, NT, PB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 6 * (4 * MT + 2) * (288 * 4 + 16));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_skp_kernel<MT, NT, PB, S>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, NPX * ((S == 1 ? 288 : 128) * 4 + 16));
     }
-    hipLaunchKernelGGL((conv3x3_skp_kernel<MT, NT, PB>), dim3((unsigned)wgs), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_skp_kernel<MT, NT, PB, S>), dim3((unsigned)wgs), dim3(512), lds, s, a);
     return pwc_launch_status();
 }
 
@@ -452,17 +457,20 @@ extern "C" int pwc_conv3x3_sk_f32(const float* x, int x_cs, const float* packed_
     // 7 x 16 x 192 -> 192 of 16 images: 11.5 against 17.9; thin layers (7 x 16 x 96 -> 64: 4.6 against 5.0) stay on the direct form.
     const long wgs11 = (long)N * a.nbx * a.nby * (Cout / 16);
     int tile = wgs11 <= 256 ? 11 : (wgs11 <= 1024 || (Cout % 32)) ? 21 : 22;
-    const bool lp_ok = stride == 1 && dilation == 1 && Cin_phys <= 288;
-    if (lp_ok && (Cin_phys >= 192 || (Cin_phys >= 96 && wgs11 > 256)))
+    const bool lp_ok = dilation == 1 && ((stride == 1 && Cin_phys <= 288) || (stride == 2 && Cin_phys <= 128));
+    if (lp_ok && stride == 1 && (Cin_phys >= 192 || (Cin_phys >= 96 && wgs11 > 256)))
         tile = wgs11 <= 256 ? 31 : (wgs11 <= 640 || (Cout % 32)) ? 41 : 42;
+    // stride 2 (a 9 x 17-pixel patch for 4 x 8 outputs): 28 x 64 x 96 -> 128 / 2 of 16 images 16.8 us against 22.3 direct,
+    // 14 x 32 x 128 -> 192 / 2: 11.3 against 13.8; launches of up to one workgroup per CU stay direct (5.0 against 5.2)
+    if (lp_ok && stride == 2 && Cin_phys >= 64 && wgs11 > 256) tile = (wgs11 <= 640 || (Cout % 32)) ? 41 : 42;
     if (sk_tile_override && !((sk_tile_override % 10) == 2 && Cout % 32) && !(sk_tile_override > 30 && !lp_ok)) tile = sk_tile_override;
     hipStream_t s = (hipStream_t)stream;
     switch (tile) {
         case 11: return sk_launch<1, 1, 5>(a, s);
         case 21: return sk_launch<2, 1, 3>(a, s);
         case 22: return sk_launch<2, 2, 2>(a, s);
-        case 31: return skp_launch<1, 1, 11>(a, s);
-        case 41: return skp_launch<2, 1, 7>(a, s);
-        default: return skp_launch<2, 2, 3>(a, s);
+        case 31: return stride == 1 ? skp_launch<1, 1, 11, 1>(a, s) : skp_launch<1, 1, 11, 2>(a, s);
+        case 41: return stride == 1 ? skp_launch<2, 1, 7, 1>(a, s) : skp_launch<2, 1, 7, 2>(a, s);
+        default: return stride == 1 ? skp_launch<2, 2, 3, 1>(a, s) : skp_launch<2, 2, 3, 2>(a, s);
     }
 }

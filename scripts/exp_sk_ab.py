@@ -6,7 +6,7 @@ from pwcnet_amd import _lib
 L = _lib.lib()
 _p = lambda t: t.data_ptr()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-SHAPES = [("ext 14x32 128->192 s2", 2 * B, 14, 32, 128, 192, 2), ("ext 7x16 192->192", 2 * B, 7, 16, 192, 192, 1),
+SHAPES = [("ext 56x128 64->96 s2", 2 * B, 56, 128, 64, 96, 2), ("ext 28x64 96->128 s2", 2 * B, 28, 64, 96, 128, 2), ("ext 14x32 128->192 s2", 2 * B, 14, 32, 128, 192, 2), ("ext 7x16 192->192", 2 * B, 7, 16, 192, 192, 1),
           ("L0 288->128", B, 7, 16, 288, 128, 1), ("L0 128->128", B, 7, 16, 128, 128, 1), ("L0 128->96", B, 7, 16, 128, 96, 1),
           ("L0 96->64", B, 7, 16, 96, 64, 1), ("L0 64->32", B, 7, 16, 64, 32, 1),
           ("L1 256->128", B, 14, 32, 256, 128, 1), ("L1 128->128", B, 14, 32, 128, 128, 1), ("L1 128->96", B, 14, 32, 128, 96, 1),
@@ -24,7 +24,7 @@ for name, N, H, W, cin, cout, stride in SHAPES:
     for tile in (11, 21, 22, 31, 41, 42):
         if tile % 10 == 2 and cout % 32:
             continue
-        if tile > 30 and stride != 1:
+        if tile > 30 and stride != 1 and cin > 128:
             continue
         L.pwc_debug_conv3x3_sk_tile(tile)
         s = torch.cuda.current_stream().cuda_stream

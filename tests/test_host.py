@@ -59,6 +59,8 @@ def test_round5_routing_rules_are_host_logic():
     assert sk(8, 56, 128, 128, 96, 1, 1) == 0            # 57344 output pixels
     assert sk(16, 14, 32, 128, 128, 1, 2) == 0           # dilated: fragments from global memory, 7168 pixels, not thin
     assert sk(16, 28, 64, 96, 128, 2, 1) == 1            # stride 2 beyond 4096 pixels
+    assert sk(16, 56, 128, 64, 96, 2, 1) == 1            # 1.76e8 multiply-adds at stride 2: against the fp32-pipe kernel (measured)
+    assert sk(16, 112, 256, 32, 64, 2, 1) == 0
     assert sk(8, 28, 64, 64, 32, 1, 1) == 1              # thin layer beyond 4096 pixels
     assert sk(8, 112, 256, 128, 128, 1, 1) == 0 and sk(8, 7, 16, 48, 128, 1, 1) == 0 and sk(8, 7, 16, 64, 24, 1, 1) == 0
     assert sk(1, 112, 256, 32, 32, 1, 1) == 1            # a single pair: 28672 pixels but 2.9e7 multiply-adds
