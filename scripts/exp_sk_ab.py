@@ -6,7 +6,7 @@ from pwcnet_amd import _lib
 L = _lib.lib()
 _p = lambda t: t.data_ptr()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-SHAPES = [("ext 56x128 64->96 s2", 2 * B, 56, 128, 64, 96, 2), ("ext 28x64 96->128 s2", 2 * B, 28, 64, 96, 128, 2), ("ext 14x32 128->192 s2", 2 * B, 14, 32, 128, 192, 2), ("ext 7x16 192->192", 2 * B, 7, 16, 192, 192, 1),
+SHAPES = [("ext 112x256 32->64 s2", 2 * B, 112, 256, 32, 64, 2), ("ext 56x128 64->64", 2 * B, 56, 128, 64, 64, 1), ("ext 28x64 96->96", 2 * B, 28, 64, 96, 96, 1), ("ext 56x128 64->96 s2", 2 * B, 56, 128, 64, 96, 2), ("ext 28x64 96->128 s2", 2 * B, 28, 64, 96, 128, 2), ("ext 14x32 128->192 s2", 2 * B, 14, 32, 128, 192, 2), ("ext 7x16 192->192", 2 * B, 7, 16, 192, 192, 1),
           ("L0 288->128", B, 7, 16, 288, 128, 1), ("L0 128->128", B, 7, 16, 128, 128, 1), ("L0 128->96", B, 7, 16, 128, 96, 1),
           ("L0 96->64", B, 7, 16, 96, 64, 1), ("L0 64->32", B, 7, 16, 64, 32, 1),
           ("L1 256->128", B, 14, 32, 256, 128, 1), ("L1 128->128", B, 14, 32, 128, 128, 1), ("L1 128->96", B, 14, 32, 128, 96, 1),
