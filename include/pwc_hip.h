@@ -351,10 +351,10 @@ int pwc_conv3x3_h2_stride2_supported(int N, int H, int W, int Cin_phys, int Cout
  * plus a reduce launch to fill the device.  Needs Cin_phys % 32 == 0, Cout % 16 == 0, x / y / packed_w / bias 16-byte
  * aligned, x_cs % 4 == 0, y_cs % 4 == 0, N*H*W*x_cs*4 < 2^31.  packed_w: pwc_conv3x3_sk_pack_f32 (the split halves in
  * fragment order, pwc_conv3x3_sk_packed_floats floats; cin_map as in pwc_conv3x3_pack_f32).  pwc_conv3x3_sk_supported: 1
- * where it is the fastest kernel of this library for the shape (stride 1, no dilation, 96 ... 288 input channels -- the
- * form that stages the workgroup's input patch in the LDS --: up to 2.4e8 multiply-adds, output pixels x Cin_phys x Cout, and 8 K
- * output pixels; otherwise up to 1e8 multiply-adds and 4096 output pixels, beyond that pixel count stride-2 and thin layers only),
- * else 0.
+ * where it is the fastest kernel of this library for the shape (the form that stages the workgroup's input patch in the
+ * LDS: stride 1, no dilation, 96 ... 288 input channels, up to 2.4e8 multiply-adds -- output pixels x Cin_phys x Cout -- and 8 K
+ * output pixels; stride 2, 64 ... 128 input channels, up to 2e8 multiply-adds; otherwise up to 1e8 multiply-adds and 4096
+ * output pixels, beyond that pixel count stride-2 and thin layers only), else 0.
  * pwc_debug_conv3x3_sk_tile(11 | 21 | 22 | 31 | 41 | 42) pins the workgroup tile and form (3x / 4x: patch in the LDS; 0: default choice) -- an experiment knob, process-wide. */
 size_t pwc_conv3x3_sk_packed_floats(int Cin_phys, int Cout);
 int pwc_conv3x3_sk_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin, int Cin_phys, int Cout,
