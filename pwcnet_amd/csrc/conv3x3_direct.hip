@@ -428,6 +428,102 @@ __global__ __launch_bounds__(256) void conv3x3_head2_mfma_kernel(const DirectArg
 }
 
 
+// ---------------------------------------------------------------- the same for WIDE inputs (round 5): the dense-connection heads
+// modules.py:274 with use_dc=True reads the whole estimator buffer (736 ... 3200 physical channels: every level's buffer holds the
+// up-sampled buffer of the level below).  The 1x1-GEMM form above with the channels in chunks of 32: a wave keeps the Z
+// accumulators of its (up to six) 16-pixel groups of the 10 x 34 patch in registers and walks the chunks -- weights of a chunk into
+// registers once, 8 channels of every group pixel per lane, 16 matrix instructions per group and chunk.  These launches are
+// bandwidth: 2.9 GB of input at the 112 x 256 level of configs[3] -- 1094 us = 2.7 TB/s here, 1455 us on the LDS-tiled FMA kernel it
+// replaces (conv3x3_head2_wide_kernel; 115 / 199 / 284 / 490 us at the levels below, 51 / 103 / 156 / 244 here).  (A group-major
+// walk with the weights in the LDS -- whole pixel records front to back -- was slower: 1900 us, one workgroup per CU.)
+__global__ __launch_bounds__(256) void conv3x3_head2_widemfma_kernel(const DirectArgs a, int tiles_x, int tiles_y, int N) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int GPW = (HM_NG + 3) / 4;                     // groups per wave
+    __shared__ __attribute__((aligned(16))) float zs[HM_NG * 16 * HM_ZS];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fr = lane & 15, kq = lane >> 4;
+    const int tile = blockIdx.x;
+    const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int y0 = by * HM_R, x0 = bx * HM_C;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + (size_t)n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 9 * a.Cin * 2 * 4, 0x00020000);
+    // this lane's pixel of each of its groups: byte offset of channel 8 kq (out-of-image / beyond the patch: out of range)
+    int pvo[GPW];
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+        const int j = (wave + 4 * gi) * 16 + fr;
+        const int py = j / HM_PW, px = j - py * HM_PW;
+        const int yy = y0 - 1 + py, xx = x0 - 1 + px;
+        const bool ok = wave + 4 * gi < HM_NG && j < HM_NP && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        pvo[gi] = ok ? ((yy * a.W + xx) * a.x_cs + 8 * kq) * 4 : -1;
+    }
+    f32x4 z0[GPW], z1[GPW];
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) { z0[gi] = f32x4{0.f, 0.f, 0.f, 0.f}; z1[gi] = z0[gi]; }
+    for (int c0 = 0; c0 < a.Cin; c0 += 32) {
+        const bool cok = c0 + 8 * kq < a.Cin;                 // (a last chunk of 16 channels: lanes kq >= 2 carry zeros)
+        // weights of the chunk: row m = 2 tap + co of M tile T, channels c0 + 8 kq + i -- HWIO (tap, channel, co): the 8 channels
+        // of one tap are 16 consecutive floats (both co)
+        float wa[2][8];
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            const int m = T * 16 + fr;
+            const bool wok = m < 18 && cok;
+            const unsigned wo = wok ? (unsigned)((((m >> 1) * a.Cin + c0 + 8 * kq) * 2) * 4) : 0x80000000u;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 w4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wo, q4 * 16, 0));
+                wa[T][2 * q4] = (m & 1) ? w4[1] : w4[0];
+                wa[T][2 * q4 + 1] = (m & 1) ? w4[3] : w4[2];
+            }
+        }
+        f32x4 lo[GPW], hi[GPW];
+#pragma unroll
+        for (int gi = 0; gi < GPW; ++gi) {
+            const int vo = (pvo[gi] >= 0 && cok) ? pvo[gi] + c0 * 4 : (int)C3M_OOB;
+            lo[gi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, vo, 0, 0));
+            hi[gi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, vo, 16, 0));
+        }
+#pragma unroll
+        for (int gi = 0; gi < GPW; ++gi) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xv = i < 4 ? lo[gi][i & 3] : hi[gi][i & 3];
+                z0[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0][i], xv, z0[gi], 0, 0, 0);
+                z1[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][i], xv, z1[gi], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+        const int g = wave + 4 * gi;
+        if (g < HM_NG) {
+            const int j = g * 16 + fr;
+            *reinterpret_cast<f32x4*>(zs + j * HM_ZS + 4 * kq) = z0[gi];
+            if (kq == 0) *reinterpret_cast<f32x2*>(zs + j * HM_ZS + 16) = f32x2{z1[gi][0], z1[gi][1]};
+        }
+    }
+    __syncthreads();
+    const int r = t >> 5, c = t & 31;
+    f32x2 acc = {a.bias[0], a.bias[1]};
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx)
+            acc += *reinterpret_cast<const f32x2*>(zs + ((r + ty) * HM_PW + c + tx) * HM_ZS + (ty * 3 + tx) * 2);
+    const int oy = y0 + r, ox = x0 + c;
+    if (oy < a.H && ox < a.W) {
+        const size_t m = ((size_t)n * a.H + oy) * a.W + ox;
+        float v0 = acc[0], v1 = acc[1];
+        if (a.apply_act) { v0 = pwc_lrelu(v0, a.slope); v1 = pwc_lrelu(v1, a.slope); }
+        if (a.res) { v0 += a.res[m * a.res_cs]; v1 += a.res[m * a.res_cs + 1]; }
+        a.y[m * a.y_cs] = v0;
+        a.y[m * a.y_cs + 1] = v1;
+    }
+}
+
 extern "C" int pwc_conv3x3_direct_f32(const float* x, int x_cs, const float* w_hwio, const float* bias,
                                       float* y, int y_cs, const float* residual, int res_cs, int N, int H,
                                       int W, int Cin, int Cout, int stride, int dilation, int apply_act,
@@ -474,6 +570,16 @@ extern "C" int pwc_conv3x3_direct_f32(const float* x, int x_cs, const float* w_h
         const long nblk = (long)N * tiles_x * tiles_y;
         if (nblk < (1L << 31)) {
             hipLaunchKernelGGL(conv3x3_head2_mfma_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a, tiles_x, tiles_y, N);
+            return pwc_launch_status();
+        }
+    }
+    if (Cout == 2 && Cin >= 64 && Cin % 16 == 0 && vec4 && stride == 1 && dilation == 1 && pwc_aligned16(w_hwio) &&
+        (long)H * W * x_cs * 4 < (long)C3M_OOB) {
+        // wide heads (use_dc=True): the 1x1-GEMM form on the matrix pipe
+        const int tiles_x = (W + HM_C - 1) / HM_C, tiles_y = (H + HM_R - 1) / HM_R;
+        const long nblk = (long)N * tiles_x * tiles_y;
+        if (nblk < (1L << 31)) {
+            hipLaunchKernelGGL(conv3x3_head2_widemfma_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a, tiles_x, tiles_y, N);
             return pwc_launch_status();
         }
     }

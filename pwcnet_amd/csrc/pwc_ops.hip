@@ -299,6 +299,49 @@ __global__ __launch_bounds__(256) void resize_pair_kernel(const ResizePairArgs a
     }
 }
 
+// The same for an exact x2 up-sampling of WIDE feature maps (the dense-connection estimators hand 736 ... 2632 channels to the
+// next level: 2.4 GB written at the 112 x 256 level of configs[3]): one thread per (source pixel, unit) writes the 2 x 2 output
+// pixels of its cell -- every source value is requested once per neighbour instead of once per output pixel.  Same formulas,
+// same values: in = out / 2 exactly, weights 0 or 1/2.
+__global__ __launch_bounds__(256) void resize_pair2x_kernel(const ResizePairArgs a, long total) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const unsigned upp = 1u + (unsigned)a.CB / 4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long pix = e / upp;
+        const unsigned un = (unsigned)(e - pix * upp);
+        const int x = (int)(pix % a.W);
+        const long r = pix / a.W;
+        const int y = (int)(r % a.H), n = (int)(r / a.H);
+        const int x1 = min(x + 1, a.W - 1), y1 = min(y + 1, a.H - 1);
+        const size_t p00 = ((size_t)n * a.H + y) * a.W, p10 = ((size_t)n * a.H + y1) * a.W;
+        const size_t o00 = ((size_t)n * a.OH + 2 * y) * a.OW + 2 * x, o10 = o00 + a.OW;
+        if (un == 0) {
+            const f32x2 tl = *reinterpret_cast<const f32x2*>(a.xa + (p00 + x) * a.xa_cs);
+            const f32x2 tr = *reinterpret_cast<const f32x2*>(a.xa + (p00 + x1) * a.xa_cs);
+            const f32x2 bl = *reinterpret_cast<const f32x2*>(a.xa + (p10 + x) * a.xa_cs);
+            const f32x2 br = *reinterpret_cast<const f32x2*>(a.xa + (p10 + x1) * a.xa_cs);
+            const f32x2 top0 = tl + (tr - tl) * 0.f, bot0 = bl + (br - bl) * 0.f;
+            const f32x2 top1 = tl + (tr - tl) * 0.5f, bot1 = bl + (br - bl) * 0.5f;
+            *reinterpret_cast<f32x2*>(a.ya + o00 * a.ya_cs) = top0 + (bot0 - top0) * 0.f;
+            *reinterpret_cast<f32x2*>(a.ya + (o00 + 1) * a.ya_cs) = top1 + (bot1 - top1) * 0.f;
+            *reinterpret_cast<f32x2*>(a.ya + o10 * a.ya_cs) = top0 + (bot0 - top0) * 0.5f;
+            *reinterpret_cast<f32x2*>(a.ya + (o10 + 1) * a.ya_cs) = top1 + (bot1 - top1) * 0.5f;
+        } else {
+            const int c = (int)(un - 1) * 4;
+            const f32x4 tl = *reinterpret_cast<const f32x4*>(a.xb + (p00 + x) * a.xb_cs + c);
+            const f32x4 tr = *reinterpret_cast<const f32x4*>(a.xb + (p00 + x1) * a.xb_cs + c);
+            const f32x4 bl = *reinterpret_cast<const f32x4*>(a.xb + (p10 + x) * a.xb_cs + c);
+            const f32x4 br = *reinterpret_cast<const f32x4*>(a.xb + (p10 + x1) * a.xb_cs + c);
+            const f32x4 top0 = tl + (tr - tl) * 0.f, bot0 = bl + (br - bl) * 0.f;
+            const f32x4 top1 = tl + (tr - tl) * 0.5f, bot1 = bl + (br - bl) * 0.5f;
+            *reinterpret_cast<f32x4*>(a.yb + o00 * a.yb_cs + c) = top0 + (bot0 - top0) * 0.f;
+            *reinterpret_cast<f32x4*>(a.yb + (o00 + 1) * a.yb_cs + c) = top1 + (bot1 - top1) * 0.f;
+            *reinterpret_cast<f32x4*>(a.yb + o10 * a.yb_cs + c) = top0 + (bot0 - top0) * 0.5f;
+            *reinterpret_cast<f32x4*>(a.yb + (o10 + 1) * a.yb_cs + c) = top1 + (bot1 - top1) * 0.5f;
+        }
+    }
+}
+
 extern "C" int pwc_resize_bilinear_pair_f32(const float* xa, int xa_cs, float* ya, int ya_cs, const float* xb,
                                             int xb_cs, float* yb, int yb_cs, int N, int H, int W, int CB, int OH,
                                             int OW, pwc_stream_t stream) {
@@ -314,6 +357,13 @@ extern "C" int pwc_resize_bilinear_pair_f32(const float* xa, int xa_cs, float* y
     a.H = H; a.W = W; a.CB = CB; a.OH = OH; a.OW = OW;
     a.sy = (float)H / (float)OH; a.sx = (float)W / (float)OW;
     a.rows = N * OH;
+    if (OH == 2 * H && OW == 2 * W && CB >= 64) {
+        const long total = (long)N * H * W * (1 + CB / 4);
+        long blocks = (total + 255) / 256;
+        if (blocks > 256 * 64) blocks = 256 * 64;
+        hipLaunchKernelGGL(resize_pair2x_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, total);
+        return pwc_launch_status();
+    }
     const dim3 grid((unsigned)(((long)OW * (1 + CB / 4) + 255) / 256), (unsigned)(a.rows < 65535 ? a.rows : 65535));
     hipLaunchKernelGGL(resize_pair_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     return pwc_launch_status();

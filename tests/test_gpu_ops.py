@@ -979,7 +979,11 @@ def test_conv_flow_head_gemm_kernel(pa, N, H, W, res):
 
 
 @pytest.mark.parametrize("N,H,W,cin,res", [(2, 7, 16, 724, False), (1, 30, 45, 100, True), (1, 64, 96, 1384, True),
-                                           (2, 9, 70, 64, False), (1, 17, 33, 92, True)])
+                                           (2, 9, 70, 64, False), (1, 17, 33, 92, True),
+                                           # Cin % 16 == 0 (the physical layouts of the model): the matrix-pipe form of round 5, incl. a
+                                           # last chunk of 16 channels, ragged tiles, an image smaller than a tile, BASELINE configs[3]'s level 4
+                                           (2, 7, 16, 720, True), (1, 30, 45, 112, True), (1, 64, 96, 1392, False), (1, 3, 5, 80, True),
+                                           (1, 112, 256, 576, True)])
 def test_conv_flow_head_wide_kernel(pa, N, H, W, cin, res):
     """Cin >= 64 -> 2 heads (the dense-connection estimators' flow heads: Cin = 725 ... 3169 logical channels): tiles with
     a loop over 32-channel chunks, ragged tiles and a last chunk of fewer than 32 channels."""
@@ -1467,7 +1471,8 @@ def test_resize_vs_oracle(pa, N, H, W, C, OH, OW, mul):
     close(pa.resize_bilinear(gpu(x), (OH, OW), mul), orc.resize_bilinear(x, (OH, OW), mul), rel=1e-6, floor=1e-6)
 
 
-@pytest.mark.parametrize("N,H,W,C", [(2, 7, 16, 32), (1, 14, 32, 32), (1, 5, 9, 8), (2, 6, 10, 288)])
+@pytest.mark.parametrize("N,H,W,C", [(2, 7, 16, 32), (1, 14, 32, 32), (1, 5, 9, 8), (2, 6, 10, 288), (1, 1, 1, 64), (2, 9, 13, 736),
+                                     (1, 56, 128, 128)])
 def test_resize_pair_vs_oracle(pa, N, H, W, C):
     """flows (2 ch) + features (C ch) of one level resized x2 in ONE launch into channel slices of
     the next level's buffer (modules.py:283-284)."""
