@@ -42,7 +42,7 @@ def main():
     from pwcnet_amd import ckpt, flow_io, sharding
 
     pairs = [ln.split() for ln in open(args.list) if ln.strip() and not ln.startswith("#")]
-    model = pwcnet_amd.PWCDCNet()
+    model = pwcnet_amd.PWCDCNet(range_check="sync")      # results are final when a call returns (fp16-range check + fp32 repeat)
     if args.resume:
         model.load_weights(ckpt.load_weights(args.resume))
 

@@ -19,7 +19,12 @@
  *     call returns immediately;
  *   - return value: PWC_OK (0), a negative PWC_E* argument error, or a positive
  *     hipError_t from the launch.  No exceptions, no global mutable state: the
- *     functions are re-entrant and thread-safe on distinct streams.
+ *     functions are re-entrant and thread-safe on distinct streams.  What a launch
+ *     does is decided by its arguments alone (tile variants are explicit `_variant_`
+ *     entry points); the library exports NO process-wide setting.  The ablation /
+ *     tile-pinning knobs the A/B scripts under scripts/ use (pwc_debug_*) exist only
+ *     in libpwc_hip_harness.so, a second build of the same sources with -DPWC_HARNESS
+ *     (pwcnet_amd/_lib.py, PWC_HARNESS=1) that no product path and no test loads.
  */
 #ifndef PWC_HIP_H
 #define PWC_HIP_H
@@ -145,8 +150,7 @@ int pwc_warp_cost_volume_concat_h2_f32(const float* f0, int f0_cs, const float* 
  * block rows (the _h2 form: faster from about 8192 pixels per launch on, where this form's nine-fold re-gather of f1 costs
  * more than the walk's prologue).  Also takes C = 64 (small batches).  Arithmetic and range as
  * pwc_warp_cost_volume_concat_h2_f32.  Alignment requirements as pwc_warp_cost_volume_concat_f32;
- * pwc_warp_cost_volume_concat_blk_supported tells in advance.  pwc_debug_cost_volume_blk_rows(1 | 3) pins the window rows per
- * workgroup (0: the default choice) -- an experiment knob for scripts/exp_blk_ab.py, process-wide, not for production. */
+ * pwc_warp_cost_volume_concat_blk_supported tells in advance. */
 int pwc_warp_cost_volume_concat_blk_f32(const float* f0, int f0_cs, const float* f1, int f1_cs,
                                        const float* flow, int flow_cs, float flow_scale,
                                        float* out, int out_cs, int out_pad_writable,
@@ -155,7 +159,6 @@ int pwc_warp_cost_volume_concat_blk_f32(const float* f0, int f0_cs, const float*
                                        pwc_stream_t stream);
 int pwc_warp_cost_volume_concat_blk_supported(int H, int W, int C, int search_range, int f0_cs, int f1_cs,
                                               int flow_cs, int out_cs, int f0_copy_cs);
-int pwc_debug_cost_volume_blk_rows(int rows);
 
 /* ---- a4/a5/a6: tf.layers.Conv2D(Cout,(3,3),(s,s),'same',dilation_rate=d) [+
  * tf.nn.leaky_relu(slope)] -- modules.py:62-67,267-268,274,306-324 ----
@@ -328,7 +331,8 @@ int pwc_conv3x3_c3c16pair_supported(int N, int H0, int W0);
  * (a strided convolution needs 9 Cin; round 4's "stride-1 launch storing every second sum" executed 36 Cin and lost to the fp32
  * kernel).  y is (N, H / 2, W / 2) at channel stride y_cs.  packed_w: pwc_conv3x3_h2_stride2_pack_f32 (same arguments as
  * pwc_conv3x3_h2_pack_f32: cin_map over the input's Cin_phys physical channels; pwc_conv3x3_h2_stride2_packed_floats floats);
- * workspace: pwc_conv3x3_h2_stride2_workspace_floats (0: none), rules of pwc_conv3x3_h2_f32.  Odd sizes: PWC_EUNSUPPORTED
+ * workspace: pwc_conv3x3_h2_stride2_workspace_floats (0: none), rules of pwc_conv3x3_h2_f32; status: the caller's status words
+ * (or NULL), as pwc_conv3x3_h2_ex_f32's (PWC_STATUS_STREAMK_TIMEOUT).  Odd sizes: PWC_EUNSUPPORTED
  * (pwc_conv3x3_f32 takes them).  _supported: 1 where it is the faster kernel: inputs of up to 32 channels whose output is a
  * shape pwc_conv3x3_h2_supported takes at 4 Cin_phys channels (measured: 16 -> 32 and 32 -> 64 of the extractor; from 64 input
  * channels on the per-stage fixed cost of 4 x as many stages outweighs the matrix pipe's rate). */
@@ -339,7 +343,7 @@ size_t pwc_conv3x3_h2_stride2_workspace_floats(int N, int H, int W, int Cin_phys
 int pwc_conv3x3_h2_stride2_f32(const float* x, int x_cs, const float* packed_w, const float* bias,
                                float* y, int y_cs, int N, int H, int W, int Cin_phys, int Cout,
                                int apply_act, float slope, float* workspace, size_t workspace_floats,
-                               pwc_stream_t stream);
+                               uint32_t* status, pwc_stream_t stream);
 int pwc_conv3x3_h2_stride2_supported(int N, int H, int W, int Cin_phys, int Cout);
 
 /* Round 5: 3x3 convolution for SMALL launches (csrc/conv3x3_sk.hip) -- the 7 x 16 and 14 x 32 pyramid levels of a batch of
@@ -355,7 +359,10 @@ int pwc_conv3x3_h2_stride2_supported(int N, int H, int W, int Cin_phys, int Cout
  * LDS: stride 1, no dilation, 96 ... 288 input channels, up to 2.4e8 multiply-adds -- output pixels x Cin_phys x Cout -- and 8 K
  * output pixels; stride 2, 64 ... 128 input channels, up to 2e8 multiply-adds; otherwise up to 1e8 multiply-adds and 4096
  * output pixels, beyond that pixel count stride-2 and thin layers only), else 0.
- * pwc_debug_conv3x3_sk_tile(11 | 21 | 22 | 31 | 41 | 42) pins the workgroup tile and form (3x / 4x: patch in the LDS; 0: default choice) -- an experiment knob, process-wide. */
+ * pwc_conv3x3_sk_variant_f32: the same convolution with the workgroup tile and form GIVEN -- tile in {11, 21, 22} (fragments from
+ * global memory), {31, 41, 42} (patch in the LDS) -- for tests and tuning (every tile gives the same result on every shape it
+ * admits; PWC_EUNSUPPORTED where it does not: x2 tiles need Cout % 32 == 0, 3x / 4x no dilation and at most 288 (stride 2: 128)
+ * input channels).  The tile is an argument of the call: the library keeps no process-wide setting. */
 size_t pwc_conv3x3_sk_packed_floats(int Cin_phys, int Cout);
 int pwc_conv3x3_sk_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin, int Cin_phys, int Cout,
                             float* packed_w, pwc_stream_t stream);
@@ -363,7 +370,9 @@ int pwc_conv3x3_sk_f32(const float* x, int x_cs, const float* packed_w, const fl
                        int N, int H, int W, int Cin_phys, int Cout, int stride, int dilation, int apply_act,
                        float slope, pwc_stream_t stream);
 int pwc_conv3x3_sk_supported(int N, int H, int W, int Cin_phys, int Cout, int stride, int dilation);
-int pwc_debug_conv3x3_sk_tile(int tile);
+int pwc_conv3x3_sk_variant_f32(const float* x, int x_cs, const float* packed_w, const float* bias, float* y, int y_cs,
+                               int N, int H, int W, int Cin_phys, int Cout, int stride, int dilation, int apply_act,
+                               float slope, int tile, pwc_stream_t stream);
 
 /* Round 5: the same convolution for THIN inputs to 32 output channels (csrc/conv3x3_t32.hip) -- Cin_phys 16 (stride 1 | 2) or
  * 32 (stride 1), Cout 32, no dilation: the feature extractor's full-resolution layers (reference modules.py:58-71,
@@ -381,7 +390,6 @@ int pwc_conv3x3_t32_f32(const float* x, int x_cs, const float* packed_w, const f
                         int N, int H, int W, int Cin_phys, int Cout, int stride, int apply_act, float slope,
                         pwc_stream_t stream);
 int pwc_conv3x3_t32_supported(int N, int H, int W, int Cin_phys, int Cout, int stride);
-int pwc_debug_conv3x3_t32(int bits);   /* experiment knob (scripts/exp_t32_ab.py): 1 no fetches, 2 no matrix work, 4 no stores; 0 = production */
 /* Tile variants of the kernel above (workgroup = couts x rows x 32 columns): 1 = 128 x 8, 2 = 64 x 16, 3 = 96 x 8,
  * 4 = 32 x 16, 5 = 64 x 8.  pwc_conv3x3_h2_plan: the one pwc_conv3x3_h2_f32 launches for a shape (fewest estimated
  * rounds of 256 workgroups x matrix instructions per tap; 0 = the shape is not accepted).  pwc_conv3x3_h2_variant_f32:

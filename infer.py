@@ -37,7 +37,7 @@ def main():
     images = np.array(imgs, dtype=np.float32) / 255.0                      # (2, h, w, 3)
     x = torch.from_numpy(images).cuda()
 
-    model = pwcnet_amd.PWCDCNet()
+    model = pwcnet_amd.PWCDCNet(range_check="sync")      # results are final when a call returns (fp16-range check + fp32 repeat)
     if args.resume is not None:
         print(f"Loading learned model from checkpoint {args.resume}")
         model.load_weights(ckpt.load_weights(args.resume))

@@ -53,7 +53,7 @@ def main():
     from pwcnet_amd import ckpt, flow_io
 
     torch.cuda.set_device(args.gpu)
-    model = pwcnet_amd.PWCDCNet()
+    model = pwcnet_amd.PWCDCNet(range_check="sync")      # results are final when a call returns (fp16-range check + fp32 repeat)
     if args.resume is not None:
         print(f"Loading learned model from checkpoint {args.resume}")
         model.load_weights(ckpt.load_weights(args.resume))

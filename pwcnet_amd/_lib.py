@@ -13,7 +13,12 @@ import torch  # noqa: F401  (loads libamdhip64 before libpwc_hip.so)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libpwc_hip.so")
+# PWC_HARNESS=1 (the A/B scripts under scripts/ set it before importing this package; nothing else does): load
+# libpwc_hip_harness.so instead -- the same sources compiled with -DPWC_HARNESS, which adds the process-wide pwc_debug_* knobs
+# (tile pinning, ablations).  The production library exports none of them (tests/test_host.py checks).
+HARNESS = os.environ.get("PWC_HARNESS", "") == "1"
+LIB_PATH = os.path.join(CSRC, "libpwc_hip_harness.so" if HARNESS else "libpwc_hip.so")
+HARNESS_SIGNATURES_NAMES = ("pwc_debug_cost_volume_blk_rows", "pwc_debug_conv3x3_sk_tile", "pwc_debug_conv3x3_t32")
 SOURCES = ["conv3x3_mfma.hip", "conv3x3_wino.hip", "conv3x3_direct.hip", "cost_volume.hip", "pwc_ops.hip",
            "pwc_backward.hip", "conv3x3_wgrad.hip", "conv3x3_h2.hip", "conv3x3_c16pair.hip", "conv3x3_sk.hip", "conv3x3_t32.hip"]
 HEADERS = ["pwc_common.h", "cost_volume_roll.hip", "cost_volume_mfma.hip", "cost_volume_h2.hip", "cost_volume_blk.hip", "conv3x3_wino4.hip", os.path.join("..", "..", "include", "pwc_hip.h")]
@@ -37,7 +42,6 @@ SIGNATURES = {
     "pwc_warp_cost_volume_concat_blk_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_warp_cost_volume_concat_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "pwc_warp_cost_volume_concat_blk_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
-    "pwc_debug_cost_volume_blk_rows": (_i, [_i]),
     "pwc_conv3x3_packed_floats": (_sz, [_i, _i]),
     "pwc_conv3x3_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pwc_conv3x3_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
@@ -60,18 +64,17 @@ SIGNATURES = {
     "pwc_conv3x3_h2_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "pwc_conv3x3_h2_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "pwc_conv3x3_h2_plan": (_i, [_i, _i, _i, _i, _i, _i]),
-    "pwc_conv3x3_h2_stride2_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "pwc_conv3x3_h2_stride2_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp]),
     "pwc_conv3x3_h2_stride2_supported": (_i, [_i, _i, _i, _i, _i]),
     "pwc_conv3x3_sk_packed_floats": (_sz, [_i, _i]),
     "pwc_conv3x3_sk_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pwc_conv3x3_sk_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_conv3x3_sk_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
-    "pwc_debug_conv3x3_sk_tile": (_i, [_i]),
+    "pwc_conv3x3_sk_variant_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "pwc_conv3x3_t32_packed_floats": (_sz, [_i]),
     "pwc_conv3x3_t32_pack_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pwc_conv3x3_t32_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_conv3x3_t32_supported": (_i, [_i, _i, _i, _i, _i, _i]),
-    "pwc_debug_conv3x3_t32": (_i, [_i]),
     "pwc_conv3x3_h2_stride2_packed_floats": (_sz, [_i, _i]),
     "pwc_conv3x3_h2_stride2_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pwc_conv3x3_h2_stride2_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),
@@ -112,6 +115,10 @@ SIGNATURES = {
     "pwc_flow_norm_sums_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp]),
 }
 
+if HARNESS:
+    for _n in HARNESS_SIGNATURES_NAMES:
+        SIGNATURES[_n] = (_i, [_i])
+
 # status word bits of the F16-matrix-pipe kernels (include/pwc_hip.h)
 STATUS_NONFINITE = 1
 STATUS_STREAMK_TIMEOUT = 2
@@ -142,11 +149,13 @@ def build_library(force=False, verbose=False):
     from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build_harness" if HARNESS else "build")
     os.makedirs(objdir, exist_ok=True)
     # -fno-slp-vectorize: hipcc otherwise packs the scalar fp32 FMA chains of the
     # correlation kernel into v_pk_fma_f32 pairs (hundreds of v_mov shuffles, VGPR spills)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-pass-failed"]
+    if HARNESS:
+        flags.append("-DPWC_HARNESS")
     jobs, objs = [], []
     for src in srcs:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")

@@ -762,7 +762,11 @@ extern "C" int pwc_conv3x3_h2_supported(int N, int H, int W, int Cin_phys, int C
     return hs >= 7 && ws >= 24 && filled && Cin_phys >= 32 ? 1 : 0;
 }
 
-static unsigned* h2_debug_counters = nullptr;      // harness only
+#ifdef PWC_HARNESS
+static unsigned* h2_debug_counters = nullptr;      // scripts/exp_h2.hip only: s_memtime totals / self-test of the exchange
+#else
+constexpr unsigned* h2_debug_counters = nullptr;
+#endif
 
 template <int CT, int PT, int WCG, int ABL, int XS = 1, bool S2 = false>
 static int h2_launch(H2Args& a, int hs, int ws, float* workspace, size_t workspace_floats, hipStream_t stream) {
@@ -900,9 +904,9 @@ extern "C" size_t pwc_conv3x3_h2_stride2_workspace_floats(int N, int H, int W, i
 
 extern "C" int pwc_conv3x3_h2_stride2_f32(const float* x, int x_cs, const float* packed_w, const float* bias, float* y,
                                           int y_cs, int N, int H, int W, int Cin_phys, int Cout, int apply_act, float slope,
-                                          float* workspace, size_t workspace_floats, pwc_stream_t stream) {
+                                          float* workspace, size_t workspace_floats, uint32_t* status, pwc_stream_t stream) {
     return h2_run<0>(x, x_cs, packed_w, bias, y, y_cs, N, H, W, Cin_phys, Cout, 1, apply_act, slope, stream, 0,
-                     workspace, workspace_floats, 2);
+                     workspace, workspace_floats, 2, nullptr, 0, 0, status);
 }
 
 // The tile variant pwc_conv3x3_h2_f32 uses for a shape (1 - 5, see h2_variant; 0 = none fits), and the same convolution with

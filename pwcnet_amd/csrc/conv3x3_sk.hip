@@ -426,13 +426,19 @@ static int skp_launch(SkArgs a, hipStream_t s) {
     return pwc_launch_status();
 }
 
-static int sk_tile_override = 0;   // experiment knob (pwc_debug_conv3x3_sk_tile): 11, 21, 22 (fragments from global memory), 31, 41, 42 (patch in the LDS)
-
+#ifdef PWC_HARNESS
+// libpwc_hip_harness.so only (scripts/exp_sk_ab.py, exp_sk_tiles.py: pins the tile of every launch of a model forward).  The
+// production library has no such state: a caller who wants a given tile passes it to pwc_conv3x3_sk_variant_f32.
+static int sk_tile_override = 0;
 extern "C" int pwc_debug_conv3x3_sk_tile(int tile) { sk_tile_override = tile; return 0; }
+#endif
 
-extern "C" int pwc_conv3x3_sk_f32(const float* x, int x_cs, const float* packed_w, const float* bias, float* y, int y_cs,
-                                  int N, int H, int W, int Cin_phys, int Cout, int stride, int dilation, int apply_act,
-                                  float slope, pwc_stream_t stream) {
+// tile_req: 0 = the library's choice for the shape; 11, 21, 22 (fragments from global memory), 31, 41, 42 (patch in the LDS) = that
+// workgroup tile, PWC_EUNSUPPORTED where the shape does not admit it (x2 tiles: C_out % 32; 3x / 4x: no dilation, up to 288
+// input channels at stride 1, 128 at stride 2).
+static int sk_run(const float* x, int x_cs, const float* packed_w, const float* bias, float* y, int y_cs,
+                  int N, int H, int W, int Cin_phys, int Cout, int stride, int dilation, int apply_act,
+                  float slope, int tile_req, pwc_stream_t stream) {
     if (!x || !packed_w || !bias || !y) return PWC_EINVAL;
     if (N <= 0 || H <= 0 || W <= 0 || Cin_phys <= 0 || Cout <= 0 || stride < 1 || stride > 2 || dilation < 1) return PWC_EINVAL;
     if (Cin_phys % 32 || Cout % 16) return PWC_EUNSUPPORTED;
@@ -463,7 +469,14 @@ extern "C" int pwc_conv3x3_sk_f32(const float* x, int x_cs, const float* packed_
     // stride 2 (a 9 x 17-pixel patch for 4 x 8 outputs): 28 x 64 x 96 -> 128 / 2 of 16 images 16.8 us against 22.3 direct,
     // 14 x 32 x 128 -> 192 / 2: 11.3 against 13.8; launches of up to one workgroup per CU stay direct (5.0 against 5.2)
     if (lp_ok && stride == 2 && Cin_phys >= 64 && wgs11 > 256) tile = (wgs11 <= 640 || (Cout % 32)) ? 41 : 42;
-    if (sk_tile_override && !((sk_tile_override % 10) == 2 && Cout % 32) && !(sk_tile_override > 30 && !lp_ok)) tile = sk_tile_override;
+    if (tile_req) {
+        if (tile_req != 11 && tile_req != 21 && tile_req != 22 && tile_req != 31 && tile_req != 41 && tile_req != 42) return PWC_EINVAL;
+        if (((tile_req % 10) == 2 && Cout % 32) || (tile_req > 30 && !lp_ok)) return PWC_EUNSUPPORTED;
+        tile = tile_req;
+    }
+#ifdef PWC_HARNESS
+    else if (sk_tile_override && !((sk_tile_override % 10) == 2 && Cout % 32) && !(sk_tile_override > 30 && !lp_ok)) tile = sk_tile_override;
+#endif
     hipStream_t s = (hipStream_t)stream;
     switch (tile) {
         case 11: return sk_launch<1, 1, 5>(a, s);
@@ -473,4 +486,19 @@ extern "C" int pwc_conv3x3_sk_f32(const float* x, int x_cs, const float* packed_
         case 41: return stride == 1 ? skp_launch<2, 1, 7, 1>(a, s) : skp_launch<2, 1, 7, 2>(a, s);
         default: return stride == 1 ? skp_launch<2, 2, 3, 1>(a, s) : skp_launch<2, 2, 3, 2>(a, s);
     }
+}
+
+extern "C" int pwc_conv3x3_sk_f32(const float* x, int x_cs, const float* packed_w, const float* bias, float* y, int y_cs,
+                                  int N, int H, int W, int Cin_phys, int Cout, int stride, int dilation, int apply_act,
+                                  float slope, pwc_stream_t stream) {
+    return sk_run(x, x_cs, packed_w, bias, y, y_cs, N, H, W, Cin_phys, Cout, stride, dilation, apply_act, slope, 0, stream);
+}
+
+// The same convolution with the workgroup tile given (tests and tuning: every tile must give the same result on every shape it
+// admits) -- an argument of the call, not a process-wide setting.
+extern "C" int pwc_conv3x3_sk_variant_f32(const float* x, int x_cs, const float* packed_w, const float* bias, float* y, int y_cs,
+                                          int N, int H, int W, int Cin_phys, int Cout, int stride, int dilation, int apply_act,
+                                          float slope, int tile, pwc_stream_t stream) {
+    if (tile == 0) return PWC_EINVAL;
+    return sk_run(x, x_cs, packed_w, bias, y, y_cs, N, H, W, Cin_phys, Cout, stride, dilation, apply_act, slope, tile, stream);
 }

@@ -303,16 +303,24 @@ extern "C" int pwc_conv3x3_t32_supported(int N, int H, int W, int Cin_phys, int 
     // the accumulation registers and the launch loses to conv3x3_h2_kernel (52 - 73 us against 48 at 16 x 112 x 256)
     if ((long)N * H * W * Cin_phys * 4 >= (1L << 31)) return 0;
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+    if ((long)N * Ho * Wo * Cout * 4 >= (1L << 31)) return 0;   // (a dense output; a wider y_cs is the entry point's PWC_ERANGE)
     const int tr = 4;
     return (long)N * ((Ho + tr - 1) / tr) * ((Wo + 31) / 32) >= 256 ? 1 : 0;
 }
 
+#ifdef PWC_HARNESS
+// libpwc_hip_harness.so only (scripts/exp_t32_ab.py: ablations -- 1 no fetches, 2 no matrix work, 4 no stores, 8 no split pass)
 static int t32_dbg = 0;
 extern "C" int pwc_debug_conv3x3_t32(int bits) { t32_dbg = bits; return 0; }
+#endif
 
 template <int CIN, int S>
 static int t32_launch(T32Args& a, hipStream_t s) {
+#ifdef PWC_HARNESS
     a.dbg = t32_dbg;
+#else
+    a.dbg = 0;
+#endif
     using G = T32Geom<CIN, S>;
     static PwcDevOnce attr_once;
     if (pwc_first_on_device(&attr_once)) {
@@ -341,6 +349,11 @@ extern "C" int pwc_conv3x3_t32_f32(const float* x, int x_cs, const float* packed
     if ((x_cs & 3) || (y_cs & 3) || !pwc_aligned16(x) || !pwc_aligned16(y) || !pwc_aligned16(packed_w) || !pwc_aligned16(bias))
         return PWC_EALIGN;
     if ((long)N * H * W * x_cs * 4 >= (1L << 31)) return PWC_ERANGE;
+    {   // the OUTPUT's buffer resource and store offsets are 32-bit too (a stride-1 launch writes twice the input's
+        // bytes, a slice of a wide buffer more)
+        const long Ho_ = (H + stride - 1) / stride, Wo_ = (W + stride - 1) / stride;
+        if ((long)N * Ho_ * Wo_ * y_cs * 4 >= (1L << 31)) return PWC_ERANGE;
+    }
     T32Args a;
     a.x = x; a.wp = packed_w; a.bias = bias; a.y = y; a.x_cs = x_cs; a.y_cs = y_cs;
     a.N = N; a.H = H; a.W = W;

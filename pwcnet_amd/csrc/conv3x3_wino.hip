@@ -456,10 +456,12 @@ extern "C" int pwc_conv3x3_wino_pack_f32(const float* w_hwio, const int32_t* cin
 // (256 CUs x 2) empty -- measured on the 28 x 64 level (14 336 pixels): 16 is faster below ~384 workgroups
 static int wino_bn(long pix_blocks, int Cout) {
     if (Cout % 32) return 16;
-    if (const char* e = getenv("PWC_WINO_FORCE_BN")) {          // scripts/tune_wino_split.py only
+#ifdef PWC_HARNESS
+    if (const char* e = getenv("PWC_WINO_FORCE_BN")) {          // libpwc_hip_harness.so only (scripts/tune_wino_split.py)
         const int v = atoi(e);
         if (v == 16 || v == 32) return v;
     }
+#endif
     return pix_blocks * (Cout / 32) >= WINO_BN32_MIN_WG ? 32 : 16;
 }
 
@@ -523,10 +525,12 @@ static int wino_run(const float* x, int x_cs, const float* packed_u, const float
 // pwc_conv3x3_wino_split_plan returns the csplit pwc_conv3x3_wino_split_f32 should be given (1: no split).
 extern "C" int pwc_conv3x3_wino_split_plan(int N, int H, int W, int Cin_phys, int Cout, int dilation) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin_phys < 16 || Cout <= 0 || dilation < 1 || (Cin_phys % 16) || (Cout % 16)) return 1;
-    if (const char* e = getenv("PWC_WINO_FORCE_SPLIT")) {       // scripts/tune_wino_split.py only
+#ifdef PWC_HARNESS
+    if (const char* e = getenv("PWC_WINO_FORCE_SPLIT")) {       // libpwc_hip_harness.so only (scripts/tune_wino_split.py)
         const int v = atoi(e);
         if (v >= 1 && v <= Cin_phys / 16) return v;
     }
+#endif
     const long wgs = pwc_conv3x3_wino_workgroups(N, H, W, Cout, dilation);
     const int nc16 = Cin_phys / 16;
     // measured (batch 8, levels 14x32 / 28x64): the split pays from a quarter-filled GPU down and from 6 stages up --
@@ -618,7 +622,11 @@ static int wino_run(const float* x, int x_cs, const float* packed_u, const float
     // (A dedicated 16 -> 16 kernel -- weights resident in registers, double-buffered patch, LDS-only barriers -- was built
     // and measured in round 3: 76.7 us against this kernel's 75.4 us on 16 x 224 x 512; its memory side alone runs in 38 us,
     // its compute side alone in 49 us, together 77: removed again, see DESIGN.md.)
-    const char* pe = getenv("PWC_WINO_PERSIST");
+#ifdef PWC_HARNESS
+    const char* pe = getenv("PWC_WINO_PERSIST");                // libpwc_hip_harness.so only (scripts/exp_wino_bn.py)
+#else
+    const char* pe = nullptr;
+#endif
     const bool persist = (pe ? atoi(pe) != 0 : true) && bn == 16 && Cin_phys <= 32 && nblk > 1024 && csplit == 1;
     if (persist && geo == 0) { WINO_LAUNCH_P(1, 0, 1); return pwc_launch_status(); }
     if (persist && geo == 2) { WINO_LAUNCH_P(1, 2, 1); return pwc_launch_status(); }

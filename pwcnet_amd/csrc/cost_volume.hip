@@ -822,7 +822,9 @@ extern "C" int pwc_warp_cost_volume_concat_blk_supported(int H, int W, int C, in
                         f0_copy_cs, H, W, C, search_range) ? 1 : 0;
 }
 
+#ifdef PWC_HARNESS
 extern "C" int pwc_debug_cost_volume_blk_rows(int rows) { cvb_rows_override = rows; return 0; }
+#endif
 
 extern "C" int pwc_warp_cost_volume_concat_blk_f32(const float* f0, int f0_cs, const float* f1, int f1_cs,
                                                    const float* flow, int flow_cs, float flow_scale, float* out,

@@ -274,7 +274,11 @@ static int cvb_launch_q(const CvbArgs& a, hipStream_t s) {
     return pwc_launch_status();
 }
 
-static int cvb_rows_override = 0;   // experiment knob (pwc_debug_cost_volume_blk_rows)
+#ifdef PWC_HARNESS
+static int cvb_rows_override = 0;   // libpwc_hip_harness.so only (pwc_debug_cost_volume_blk_rows, scripts/exp_blk_ab.py)
+#else
+constexpr int cvb_rows_override = 0;
+#endif
 
 template <int CG, bool WARP, bool PAD>
 static int cvb_launch_t(const CvbArgs& a, hipStream_t s) {

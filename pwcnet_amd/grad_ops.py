@@ -17,6 +17,32 @@ F16X2 = True      # training FORWARD: route the layers pwc_conv3x3_h2_supported 
 # True) (or this flag) turns it on for runs whose gradients are known to stay large (-7 % step time at batch 8).
 F16X2_DGRAD = False
 
+_STATUS = {}
+
+
+def status_words(dev):
+    """The training path's status words on `dev` (two uint32, include/pwc_hip.h): every F16-pipe launch of conv3x3_raw ORs
+    PWC_STATUS_STREAMK_TIMEOUT into word 0 when a bounded stream-K wait runs out (the launch said nothing before).
+    Trainer.status() reads and clears them."""
+    key = str(dev)
+    w = _STATUS.get(key)
+    if w is None:
+        w = _STATUS[key] = torch.zeros(2, dtype=torch.int32, device=dev)
+    return w
+
+
+def read_status(clear=True):
+    """OR of the status words of every device (synchronises); a stream-K timeout also refills the stream-K workspaces."""
+    flags = 0
+    for w in _STATUS.values():
+        flags |= int(w[0].item())
+        if clear:
+            w.zero_()
+    if flags & _lib.STATUS_STREAMK_TIMEOUT:
+        from .modules import h2_workspaces_refill
+        h2_workspaces_refill()
+    return flags
+
 
 def _L():
     return _lib.lib()
@@ -173,7 +199,8 @@ def conv3x3_raw(x, w_hwio, bias, y, stride=1, dilation=1, slope=None, keep=None,
         ws = _h2_workspace(dev, wsf) if wsf else None
         _lib.check(L.pwc_conv3x3_h2_stride2_f32(_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.data_ptr()), _p(y.ptr), y.cs,
                                                 x.N, x.H, x.W, x.C, cout, act, sl,
-                                                _p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0, s),
+                                                _p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0,
+                                                _p(status_words(dev).data_ptr()), s),
                    "conv3x3_h2 stride 2 (raw)")
         tmp.append(packed)
     elif (h2_ok and stride == 1
@@ -184,9 +211,10 @@ def conv3x3_raw(x, w_hwio, bias, y, stride=1, dilation=1, slope=None, keep=None,
         _lib.check(L.pwc_conv3x3_h2_pack_f32(_p(w_hwio.data_ptr()), None, x.C, x.C, cout, _p(packed.data_ptr()), s), "h2 pack")
         wsf = L.pwc_conv3x3_h2_workspace_floats(x.N, x.H, x.W, x.C, cout, dilation)
         ws = _h2_workspace(dev, wsf) if wsf else None
-        _lib.check(L.pwc_conv3x3_h2_f32(_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.data_ptr()), _p(y.ptr), y.cs,
-                                        x.N, x.H, x.W, x.C, cout, dilation, act, sl,
-                                        _p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0, s),
+        _lib.check(L.pwc_conv3x3_h2_ex_f32(_p(x.ptr), x.cs, 0, None, 0, _p(packed.data_ptr()), _p(bias.data_ptr()), _p(y.ptr), y.cs,
+                                           x.N, x.H, x.W, x.C, cout, dilation, act, sl,
+                                           _p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0,
+                                           _p(status_words(dev).data_ptr()), s),
                    "conv3x3_h2 (raw)")
         tmp.append(packed)
     elif use_mfma and stride == 1 and _wino_pays(L, x.N, x.H, x.W, cout, dilation):

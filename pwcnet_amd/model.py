@@ -129,11 +129,16 @@ class PWCDCNet(object):
         # only divides the frames by 255), so a flagged forward is REPEATED on the fp32 kernels into the very tensors it
         # returned, with a warning, and the model stays on fp32 from then on (frames that are not finite themselves take the
         # same path once and come out as non-finite as the reference's would):
-        #   range_check="lazy" (default): the words are copied to the host behind every forward (8 bytes, asynchronous) and
-        #       looked at when the next forward is called, or by status() / synchronize() -- no host synchronisation is added
-        #       to a forward, and a caller who reads results after torch.cuda.synchronize() without calling status() would see
-        #       the NaN of a flagged forward (never a wrong number);
-        #   range_check="sync": every call ends with status(): results are right when it returns (the CLIs use this);
+        #   range_check="lazy" (default): the words are copied to the host behind every forward (8 bytes, asynchronous, a slot of
+        #       its own per forward) and looked at when a later forward is called, or by status() / synchronize() -- no host
+        #       synchronisation is added to a forward.  The words are sticky, so the FIRST pending forward whose copy shows a flag
+        #       is the one that tripped it; it and every forward issued behind it (they ran with the flag already up) are
+        #       repeated on the fp32 kernels into the tensors they returned -- provided the caller has not written into their
+        #       input tensors since (torch's version counters): outputs of a forward whose inputs were refilled in place are set
+        #       to NaN instead, never to flows of other frames.  A caller who reads results after torch.cuda.synchronize()
+        #       without calling status() / synchronize() would see the NaN of a flagged forward (never a wrong number);
+        #   range_check="sync": every call ends with status(): results are right when it returns (infer.py, infer_continuous.py and
+        #       evaluate.py build their models this way);
         #   range_check="off": no status words at all.
         # track_max: every operand of an F16-pipe kernel is also scanned for its largest magnitude (pwc_absmax_f32, one small
         # launch each: slower) -> status()["max_abs"] -- for the first person with trained weights to see the margin in one run.
@@ -142,8 +147,8 @@ class PWCDCNet(object):
         self.track_max = bool(track_max)
         self.two_operand = True             # features_0 read from the pyramid tensor where the first conv allows (_est_layout)
         self.f16x2 = bool(f16x2)
-        self._status = {}                   # device -> (device words, pinned host copy)
-        self._pending = None                # the last forward's record: (event, host words, inputs, outputs, device)
+        self._status = {}                   # device -> [device words, pinned host ring (slots x 2), next slot]
+        self._pending = collections.deque() # forwards whose status words nobody has looked at: (event, host slot, inputs, their versions, outputs, device)
         self.fallback_reason = None         # set when the model left the F16-pipe kernels
         _lib.lib()  # fail now, loudly, if the HIP library is missing
         self.store = VariableStore(seed=seed)
@@ -248,54 +253,83 @@ class PWCDCNet(object):
         return self._call_one(images_0, images_1, with_features, into=into)
 
     # ------------------------------------------------------------------ status words of the F16-pipe kernels
+    _STATUS_SLOTS = 64
+
     def _attach_status(self, dev):
         key = str(dev)
         if key not in self._status:
             words = torch.zeros(2, dtype=torch.int32, device=dev)
-            host = torch.zeros(2, dtype=torch.int32).pin_memory()
-            self._status[key] = (words, host)
+            ring = torch.zeros((self._STATUS_SLOTS, 2), dtype=torch.int32).pin_memory()
+            self._status[key] = [words, ring, 0]
         words = self._status[key][0]
         for mod in self._mods:
             mod.status = words
             mod.track_max = self.track_max
 
     def _record(self, images_0, images_1, out):
-        words, host = self._status[str(images_0.device)]
+        """The status words as they stand behind this forward, copied (asynchronously) into a host slot of its own."""
+        if len(self._pending) >= self._STATUS_SLOTS - 1:    # (a slot is reused only after its forward has been looked at)
+            self._examine(wait=True)
+        st = self._status[str(images_0.device)]
+        words, ring, nxt = st
+        host = ring[nxt % self._STATUS_SLOTS]
+        st[2] = nxt + 1
         host.copy_(words, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._pending = (ev, host, images_0, images_1, out, images_0.device)
+        vers = (getattr(images_0, "_version", None), getattr(images_1, "_version", None))
+        self._pending.append((ev, host, images_0, images_1, vers, out, images_0.device))
 
     def _examine(self, wait):
-        """Look at the last forward's status words (wait=False: only if their copy has arrived).  A range violation or a
-        stream-K timeout: warn, leave the F16-pipe kernels for good, and repeat that forward on the fp32 kernels into the
-        tensors it returned (stream-ordered on the current stream)."""
-        pend = self._pending
-        if pend is None:
-            return 0
-        ev, host, im0, im1, out, dev = pend
-        if not wait and not ev.query():
-            return 0
-        ev.synchronize()
-        self._pending = None
-        flags = int(host[0].item())
-        if not flags:
-            return 0
-        why = []
-        if flags & _lib.STATUS_NONFINITE:
-            why.append("the flows are not finite: an activation left fp16's range (|x| >= 65504) in a kernel that splits its "
-                       "operands into fp16 pairs (or the frames are not finite)")
-        if flags & _lib.STATUS_STREAMK_TIMEOUT:
-            why.append("a stream-K workgroup gave up waiting for a partial sum")
-            _m.h2_workspaces_refill()
-        self.fallback_reason = "; ".join(why)
-        warnings.warn(f"PWCDCNet: {self.fallback_reason}: the affected forward is repeated on the fp32 kernels and the model "
-                      "stays on them (f16x2=False) from now on", RuntimeWarning, stacklevel=3)
-        self._set_f16x2(False)
-        self._status[str(dev)][0][0] = 0
-        with torch.cuda.device(dev):
-            self._dispatch(im0, im1, len(out) == 3, into=(out[0], list(out[1])))
-        return flags
+        """Look at the status words of the pending forwards, oldest first (wait=False: those whose copy has arrived).  The
+        words are sticky: the first forward whose copy shows a flag is the one that raised it.  A range violation or a
+        stream-K timeout: warn, leave the F16-pipe kernels for good, and repeat that forward AND every forward issued behind it
+        on the fp32 kernels into the tensors they returned (stream-ordered on the current stream) -- unless the caller has
+        written into a forward's input tensors since: its outputs are then set to NaN (never flows of other frames)."""
+        while self._pending:
+            ev, host, im0, im1, vers, out, dev = self._pending[0]
+            if not wait and not ev.query():
+                return 0
+            ev.synchronize()
+            flags = int(host[0].item())
+            if not flags:
+                self._pending.popleft()
+                continue
+            affected = list(self._pending)
+            self._pending.clear()
+            why = []
+            if flags & _lib.STATUS_NONFINITE:
+                why.append("the flows are not finite: an activation left fp16's range (|x| >= 65504) in a kernel that splits its "
+                           "operands into fp16 pairs (or the frames are not finite)")
+            if flags & _lib.STATUS_STREAMK_TIMEOUT:
+                why.append("a stream-K workgroup gave up waiting for a partial sum")
+                _m.h2_workspaces_refill()
+            self.fallback_reason = "; ".join(why)
+            stale = [rec for rec in affected
+                     if (getattr(rec[2], "_version", None), getattr(rec[3], "_version", None)) != rec[4]]
+            warnings.warn(f"PWCDCNet: {self.fallback_reason}: the affected forward" +
+                          (f" and the {len(affected) - 1} issued behind it are" if len(affected) > 1 else " is") +
+                          " repeated on the fp32 kernels and the model stays on them (f16x2=False) from now on" +
+                          (f"; {len(stale)} of them had their input tensors modified since: their outputs are set to NaN"
+                           if stale else ""), RuntimeWarning, stacklevel=3)
+            self._set_f16x2(False)
+            with torch.cuda.device(dev):
+                self._status[str(dev)][0].zero_()
+                cur = torch.cuda.current_stream(dev)
+                for rec in affected:
+                    r_ev, _, r0, r1, r_vers, r_out, _ = rec
+                    cur.wait_event(r_ev)                    # (a forward issued on another stream)
+                    if (getattr(r0, "_version", None), getattr(r1, "_version", None)) != r_vers:
+                        r_out[0].fill_(float("nan"))
+                        for t in r_out[1]:
+                            t.fill_(float("nan"))
+                        continue
+                    res = self._dispatch(r0, r1, len(r_out) == 3, into=(r_out[0], list(r_out[1])))
+                    if len(r_out) == 3:                     # with_features: the pyramid came from the overflowing extractor too
+                        for dst, src in zip(r_out[2], res[2]):
+                            dst.copy_(src)
+            return flags
+        return 0
 
     def _set_f16x2(self, on):
         self.f16x2 = bool(on)
@@ -306,13 +340,18 @@ class PWCDCNet(object):
         self._warm.clear()
 
     def status(self):
-        """Synchronise with the last forward's status words and act on them (see __init__).  Returns
+        """Synchronise with the status words of every forward not yet looked at and act on them (see __init__).  Returns
         {"flags", "f16x2", "fallback_reason"[, "max_abs"]}."""
         flags = self._examine(wait=True)
         rep = {"flags": flags, "f16x2": self.f16x2, "fallback_reason": self.fallback_reason}
         if self.track_max:
-            rep["max_abs"] = max([float(w[1:2].view(torch.float32).item()) for w, _ in self._status.values()], default=0.0)
+            rep["max_abs"] = max([float(st[0][1:2].view(torch.float32).item()) for st in self._status.values()], default=0.0)
         return rep
+
+    def synchronize(self):
+        """status() for callers who only want the guarantee: when it returns, every tensor this model has handed out holds
+        what the fp32 reference arithmetic gives (a flagged forward has been repeated on the fp32 kernels)."""
+        return self.status()
 
     def effective_streams(self, shape):
         """Number of sub-batches a batch of this (N, H, W, 3) shape is run as: `streams` if given (and dividing N), else 1.

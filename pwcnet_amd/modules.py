@@ -347,6 +347,7 @@ class _ConvRunner:
         use_t32 = (use_mfma and getattr(self.owner, "f16x2", True) and getattr(self.owner, "thin_conv", True) and x2 is None
                    and tile < 0 and split == 0 and dilation == 1 and cout == 32 and y.cs % 4 == 0 and y.ptr % 16 == 0
                    and (x.C == 16 or getattr(self.owner, "thin_conv32", True))
+                   and x.N * Ho * Wo * y.cs * 4 < (1 << 31)      # (32-bit store offsets: ADVICE r5)
                    and L.pwc_conv3x3_t32_supported(x.N, x.H, x.W, x.C, cout, stride))
         if x2 is not None and not use_h2:
             raise _lib.PwcHipError(f"{name}: a two-operand input needs the F16-pipe kernel (h2_two_operand_ok)")
@@ -433,7 +434,7 @@ class _ConvRunner:
             else:
                 fn = L.pwc_conv3x3_h2_stride2_f32
                 args = (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
-                        x.N, x.H, x.W, x.C, cout, act, sl) + wsa + (s,)
+                        x.N, x.H, x.W, x.C, cout, act, sl) + wsa + (_p(status.data_ptr()) if status is not None else None, s)
             _launch(fn, args, f"conv3x3_h2 {name}", "conv3x3_h2_kernel",
                     2.0 * x.N * Ho * Wo * 9 * cin * cout, 4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout),
                     # executed: three fp16 products per multiply-add, per physical input channel (stride 2: 16 products per
@@ -479,7 +480,8 @@ class _ConvRunner:
                 cache[key] = packed
             _keep(packed, y_t)
             # launches that would leave most workgroup slots empty deal their channel stages to several workgroups
-            csplit = L.pwc_conv3x3_wino_split_plan(x.N, x.H, x.W, x.C, cout, dilation)
+            csplit = (L.pwc_conv3x3_wino_split_plan(x.N, x.H, x.W, x.C, cout, dilation)
+                      if getattr(self.owner, "wino_channel_split", True) else 1)
             if csplit > 1:
                 ws = _workspace(kern.value.device, L.pwc_conv3x3_wino_split_workspace_floats(x.N, x.H, x.W, cout, csplit))
                 _keep(ws)
@@ -589,9 +591,15 @@ def _h2_workspace(device, want_floats):
 
 def h2_workspaces_refill():
     """Every stream-K workspace back to "nothing published" (0xFF bytes) -- after a launch reported
-    PWC_STATUS_STREAMK_TIMEOUT a late publisher may have left sums in a slot."""
+    PWC_STATUS_STREAMK_TIMEOUT a late publisher may have left sums in a slot.  The workspaces belong to
+    different streams: every device that owns one is synchronised first, so that no launch in flight on another stream
+    is using a workspace while it is refilled (a rare path: a timeout means a fault)."""
+    for dev in {ws.device for ws in _H2_WS.values()}:
+        torch.cuda.synchronize(dev)
     for ws in _H2_WS.values():
         ws.view(torch.int32).fill_(-1)
+    for dev in {ws.device for ws in _H2_WS.values()}:
+        torch.cuda.synchronize(dev)
 
 
 def _wino_pays(L, N, H, W, cout, dilation):
@@ -632,6 +640,7 @@ def _mfma_kernel_name(L, M, cout, cin_phys, tile, split):
 class _Module:
     winograd = False     # route eligible convs (stride 1, dilation 1, Cout % 32 == 0) to the Winograd kernel
     winograd4 = True     # ... and the big ones among them to the F(4x4,3x3) kernel (pwc_conv3x3_wino4_supported)
+    wino_channel_split = True    # F(2x2) launches that leave most workgroup slots empty deal their channel stages to several workgroups
     f16x2_stream_k = True    # ... with one workgroup per CU and an equal share of the work each where a launch has more tiles than CUs
     f16x2 = True         # the layers pwc_conv3x3_h2_supported names go to the direct F16-matrix-pipe kernel (fp32 operands as
                          # exact-to-22-bit fp16 pairs, fp32 accumulation; inputs must stay below 65504)

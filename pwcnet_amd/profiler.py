@@ -14,6 +14,25 @@ import torch
 _ACTIVE = None
 
 
+def source_stamp():
+    """sha256 over the kernel sources and the C header (pwcnet_amd/csrc/*.hip, *.h, include/pwc_hip.h; names and bytes, sorted):
+    what identifies THE BUILD a set of hardware-counter passes was taken from.  scripts/pmc_*_table.py write it into
+    profiles/pmc_traffic.json, bench.py recomputes it and refuses to print counter traffic taken from other sources
+    (`traffic_stale`).  Computable on the GPU box (no .git there)."""
+    import glob
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "pwcnet_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "pwcnet_amd", "csrc", "*.h"))
+                   + [os.path.join(root, "include", "pwc_hip.h")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.relpath(f, root).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def active():
     return _ACTIVE
 

@@ -387,6 +387,12 @@ class Trainer:
             return losses.multirobust_loss(flows_gt, self.flows_pyramid, self.loss_weights, self.epsilon, self.q)
         return losses.multiscale_loss(flows_gt, self.flows_pyramid, self.loss_weights)
 
+    def status(self):
+        """Status words of the training path's F16-pipe launches since the last call (synchronises): 0, or
+        _lib.STATUS_STREAMK_TIMEOUT when a stream-K wait ran out somewhere (the affected step's loss is NaN; the stream-K
+        workspaces have been refilled: repeat the step)."""
+        return G.read_status()
+
     def step(self, images_0, images_1, flows_gt):
         """One optimisation step (reference train.py:66-92, 114-118).  Returns the data loss (without the L2 term)."""
         self.forward(images_0, images_1)

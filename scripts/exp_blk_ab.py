@@ -1,6 +1,9 @@
 """A/B of the small-level correlation launches in ONE process (round 5): coarse fp32 kernel / row-walking F16 kernel / block
 kernel with 1 or 3 window block rows per workgroup, on rotating operand sets (cold: > 256 MB in rotation; warm: one set).
 Prints the average time of a launch from one pair of events around a captured chain of launches (graph replay: no host in the loop)."""
+import os
+os.environ["PWC_HARNESS"] = "1"   # libpwc_hip_harness.so: the pwc_debug_* knobs exist only there (build it here first:
+                                    # PWC_HARNESS=1 python -c 'from pwcnet_amd import _lib; _lib.build_library()')
 import sys, ctypes, torch
 sys.path.insert(0, ".")
 import pwcnet_amd as pa

@@ -2,6 +2,7 @@
 // with scaled two-term operand splits) against the shipped fp32 kernels (conv3x3_wino4.hip, conv3x3_wino.hip) and a
 // double-precision CPU convolution on sampled outputs.  Not part of the library.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize scripts/exp_h2.hip -o scripts/exp_h2.bin
+#define PWC_HARNESS 1
 #include "../pwcnet_amd/csrc/conv3x3_wino.hip"
 #include "../pwcnet_amd/csrc/conv3x3_h2.hip"
 #include <cstdio>

@@ -1,5 +1,8 @@
 """The small-launch conv kernel (conv3x3_sk.hip) per layer shape and workgroup tile, graph replays of launch chains (round 5).
 us per launch = one event pair around a captured chain of 64 launches over 4 rotating operand sets."""
+import os
+os.environ["PWC_HARNESS"] = "1"   # libpwc_hip_harness.so: the pwc_debug_* knobs exist only there (build it here first:
+                                    # PWC_HARNESS=1 python -c 'from pwcnet_amd import _lib; _lib.build_library()')
 import sys, torch
 sys.path.insert(0, ".")
 from pwcnet_amd import _lib

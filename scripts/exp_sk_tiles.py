@@ -1,4 +1,7 @@
 """Forward time with the small-launch conv kernel's workgroup tile pinned (round 5): python scripts/exp_sk_tiles.py [batch]"""
+import os
+os.environ["PWC_HARNESS"] = "1"   # libpwc_hip_harness.so: the pwc_debug_* knobs exist only there (build it here first:
+                                    # PWC_HARNESS=1 python -c 'from pwcnet_amd import _lib; _lib.build_library()')
 import os, sys, statistics
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

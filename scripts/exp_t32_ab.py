@@ -1,5 +1,8 @@
 """The thin-input conv kernel (conv3x3_t32_kernel) on the full-resolution extractor layers (round 5): graph replays of launch chains
 over operand sets rotating through 400 MB; us per launch, median of 5."""
+import os
+os.environ["PWC_HARNESS"] = "1"   # libpwc_hip_harness.so: the pwc_debug_* knobs exist only there (build it here first:
+                                    # PWC_HARNESS=1 python -c 'from pwcnet_amd import _lib; _lib.build_library()')
 import sys, torch
 sys.path.insert(0, ".")
 from pwcnet_amd import _lib

@@ -1,6 +1,8 @@
 """16 vs 32 output channels per workgroup, persistent or not, on the short-channel-loop layers (2-4 stages).
 Measured: the plan in the library is within 1 us of the best everywhere; a persistent 32-cout form (spills 80-92 B per
 lane) gives 65.9 vs 58.9 us on 32->32 at 112x256 and nothing elsewhere.   python scripts/exp_wino_bn.py"""
+import os
+os.environ["PWC_HARNESS"] = "1"   # libpwc_hip_harness.so: the PWC_WINO_* environment knobs exist only there
 import ctypes, os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from pwcnet_amd import _lib

@@ -31,7 +31,10 @@ for name, d in sorted(vals.items()):
 print(f"{'sum = one forward':60s} {'':>4s} {tot_r / 1e6:9.1f} {tot_w / 1e6:9.1f}")
 if len(sys.argv) > 2:
     t = json.load(open(sys.argv[2])) if os.path.exists(sys.argv[2]) else {}
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from pwcnet_amd.profiler import source_stamp
     t["op_leg"] = {"hbm_read_bytes_per_forward": tot_r, "hbm_write_bytes_per_forward": tot_w, "per_kernel": per,
+                   "stamp": {"source_sha": source_stamp(), "kernel_symbols": sorted(per)},
                    "source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ{,_64B}_sum (separate passes) over "
                              "`python bench.py --op-leg-only` (scripts/gpu_round5_final.sh); bytes = sum(size x requests)"}
     json.dump(t, open(sys.argv[2], "w"), indent=1)

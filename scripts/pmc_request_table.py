@@ -39,10 +39,19 @@ if len(sys.argv) > 2:
         base = re.sub(r"<.*", "", name).split()[-1]
         fam[base][0] += n; fam[base][1] += n * rd; fam[base][2] += n * wr
     old = json.load(open(sys.argv[2])) if os.path.exists(sys.argv[2]) else {}
+    # the stamp: which sources these counters belong to, and how many forwards the passes saw -- bench.py
+    # compares both (and the dominant kernel's launches per forward) with the run it is printing and reports the traffic as
+    # stale instead of printing it when they differ.  git_sha is filled in by scripts/stamp_pmc.py where a .git exists.
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from pwcnet_amd.profiler import source_stamp
+    forwards = int(sys.argv[3]) if len(sys.argv) > 3 else (fam.get("conv3x3_c16pair_kernel", [0])[0] or fam.get("resize_kernel", [0])[0] or 0)
     out = {"source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ{,_64B}_sum (separate passes), bytes = sum(size x "
                      "requests); python bench.py --steps 3 --warmup 2 --streams 1 (batch 8, 448x1024, use_dc=False: every launch "
                      "a whole batch-8 launch); calibration profiles/r04_pmc_calibration.txt",
-           "kernels": {k: {"launches": v[0], "hbm_read_bytes_per_launch": v[1] / v[0], "hbm_write_bytes_per_launch": v[2] / v[0]}
+           "stamp": {"source_sha": source_stamp(), "git_sha": None, "forwards_profiled": forwards,
+                     "kernel_symbols": sorted(fam)},
+           "kernels": {k: {"launches": v[0], "launches_per_forward": (v[0] / forwards if forwards else None),
+                           "hbm_read_bytes_per_launch": v[1] / v[0], "hbm_write_bytes_per_launch": v[2] / v[0]}
                        for k, v in fam.items()}}
     for k, v in old.items():            # (the other tables of the file: mfma_busy, op_leg, ...)
         if k not in out:

@@ -1,6 +1,8 @@
 """Winograd launches that do not fill the GPU (batch 8, 448x1024: pyramid levels 28x64 / 14x32, estimator levels 1-3):
 16 vs 32 output channels per workgroup x channel split 1..4, against the library's own plan.
     python scripts/tune_wino_split.py"""
+import os
+os.environ["PWC_HARNESS"] = "1"   # libpwc_hip_harness.so: the PWC_WINO_* environment knobs exist only there
 import ctypes, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -391,7 +391,15 @@ def test_bench_json_contract(pa):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["value"] > 0
+    # the shared host makes the CPU figure swing -- repeat count, median, best and worst are in the line
+    assert c["repeats"] >= 3 and len(c["seconds_per_pair"]) == c["repeats"]
+    assert c["value_worst"] <= c["value_median"] <= c["value_best"] and c["value_worst"] <= c["value"] <= c["value_best"]
     assert d["parity"]["max_abs_flows_final"] <= d["parity"]["tolerance"]
+    pm = d["parity_real_motion"]
+    assert pm["f16x2_kept"] is True and pm["max_abs_flows_final"] <= pm["tolerance"]
+    # counter traffic is printed only when its stamp matches the build and launch pattern of THIS run (the
+    # committed passes are of the batch-8 448x1024 workload: this small configuration gets none and says nothing stale either)
+    assert r["traffic"] is None and "traffic_stale" not in r
 
 
 @pytest.mark.parametrize("gain,use_dc", [(1.35, False), (1.6, False), (1.25, True)])
@@ -572,11 +580,147 @@ def test_channel_split_launches_do_not_change_the_flows(pa, monkeypatch):
     net = pa.PWCDCNet()
     net.load_weights(w)
     final, pyr = net(gpu(im0), gpu(im1))
-    monkeypatch.setenv("PWC_WINO_FORCE_SPLIT", "1")                           # read by the library at plan time
     ref = pa.PWCDCNet()
     ref.load_weights(w)
+    for mod in ref._mods:                    # (a host-side routing attribute: the library reads no environment variable)
+        mod.wino_channel_split = False
     rfinal, rpyr = ref(gpu(im0), gpu(im1))
-    monkeypatch.delenv("PWC_WINO_FORCE_SPLIT")
     assert float((final - rfinal).abs().max()) <= 2e-5 * max(1.0, float(rfinal.abs().max()))
     for a, b in zip(pyr, rpyr):
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+# ------------------------------------------------------------------ real motion
+def motion_weights(use_dc, head_bias, gain=1.3):
+    """Glorot weights (kernel gain 1.3: flows that vary by tens of pixels over the frame) with the bias of the coarsest flow
+    head set to `head_bias` (px / 20): every level adds its residual to the upsampled flow of the level below
+    (reference modules.py:275-277, :283 -- no x2 on the values), so the whole pyramid carries that translation and flows_final
+    = 20 x it (model.py:127): Sintel-scale motion out of random weights, with warps of up to 20 / 2^(6-l) x it at level l."""
+    w = util.model_weights(use_dc, gain=gain)
+    w["pwcdcnet/optflow_0/conv2d_5/bias"] = np.asarray(head_bias, np.float32)
+    return w
+
+
+@pytest.mark.parametrize("head_bias,floor_px,use_dc", [((5.2, -3.1), 100.0, False), ((15.5, -9.0), 300.0, False),
+                                                        ((5.2, -3.1), 100.0, True), ((15.5, -9.0), 300.0, True)])
+def test_e2e_real_motion_vs_oracle(pa, head_bias, floor_px, use_dc):
+    """BASELINE configs[1] / configs[3] frame size, DEFAULT routing (F16-pipe kernels, the two F(4x4) layers, stream-K), flows of
+    >= 100 px and >= 300 px: the oracle's flows_final must peak above `floor_px` and the HIP forward must meet it within the
+    north_star's 1e-3 px.  The margin is printed (DESIGN.md section 4 quotes it); the same forward on the fp32 kernels is run
+    beside it so that the split arithmetic's share of the error is visible."""
+    w = motion_weights(use_dc, head_bias)
+    im0, im1 = util.smooth_images(1, 448, 1024, seed=95, shift=(-4, 3))
+    net = pa.PWCDCNet(use_dc=use_dc, range_check="sync")
+    net.load_weights(w)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                       # no fallback: the F16-pipe kernels must carry this
+        final, pyr = net(gpu(im0), gpu(im1))
+    assert net.status()["f16x2"] is True
+    net32 = pa.PWCDCNet(use_dc=use_dc, f16x2=False)
+    net32.load_weights(w)
+    final32, _ = net32(gpu(im0), gpu(im1))
+    e_final, e_pyr = orc.OraclePWCDCNet(w, use_dc=use_dc)(im0, im1)
+    mag = float(np.abs(e_final).max())
+    err = float(np.abs(final.cpu().numpy() - e_final).max())
+    err32 = float(np.abs(final32.cpu().numpy() - e_final).max())
+    print(f"real motion use_dc={use_dc}: oracle max |flow| {mag:.1f} px; max abs err {err:.3e} px = {err / 1e-3:.2f} of the 1e-3 budget "
+          f"(the same forward on the fp32 kernels: {err32:.3e})")
+    assert np.isfinite(mag) and mag >= floor_px, mag
+    assert err <= 1e-3, err
+    for g, e in zip(pyr, e_pyr):
+        assert float(np.abs(g.cpu().numpy() - e).max()) <= 1e-3 / 20.0
+
+
+def test_activations_near_the_fp16_range_stay_on_the_fast_kernels(pa):
+    """walk the range guard of the split arithmetic (|x| < 65504) without crossing it.  Frames scaled by 5e3:
+    the oracle's activations reach 1e3 ... 1e4 (the cost volume 1e3), the flows thousands of px/20 units.  The F16-pipe forward must (a) raise no
+    flag and stay on the fast kernels, (b) report a largest operand inside [1e3, 65504), (c) agree with the fp32-kernel forward
+    and the oracle to fp32 accuracy RELATIVE to the flow magnitude (an absolute 1e-3 px means nothing at 1e3 px)."""
+    import warnings
+    w = util.model_weights(False)
+    im0, im1 = util.smooth_images(1, 448, 1024, seed=95, shift=(-4, 3))
+    im0, im1 = im0 * 5e3, im1 * 5e3
+    net = pa.PWCDCNet(range_check="sync", track_max=True)
+    net.load_weights(w)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        final, _ = net(gpu(im0), gpu(im1))
+        rep = net.status()
+    assert rep["flags"] == 0 and rep["f16x2"] is True, rep
+    assert 1e3 <= rep["max_abs"] < 65504.0, rep
+    net32 = pa.PWCDCNet(f16x2=False)
+    net32.load_weights(w)
+    final32, _ = net32(gpu(im0), gpu(im1))
+    e_final, _ = orc.OraclePWCDCNet(w)(im0, im1)
+    mag = float(np.abs(e_final).max())
+    err = float(np.abs(final.cpu().numpy() - e_final).max())
+    err32 = float(np.abs(final32.cpu().numpy() - e_final).max())
+    print(f"near the fp16 range: largest F16-pipe operand {rep['max_abs']:.0f} ({rep['max_abs'] / 65504:.2f} of the range), "
+          f"max |flow| {mag:.0f} px, err {err:.3e} ({err / mag:.1e} relative; fp32 kernels: {err32:.3e})")
+    assert np.isfinite(mag) and bool(torch.isfinite(final).all())
+    assert err <= max(1e-3, 2e-5 * mag) and err <= 3.0 * err32 + 1e-6 * mag, (err, err32, mag)
+
+
+# ------------------------------------------------------------------ the range check in a pipelined loop (ADVICE r5)
+def test_lazy_range_check_maps_each_flag_to_its_forward(pa):
+    """range_check="lazy" in a pipelined loop: forwards 0-1 in range, forward 2 overflows, forwards 3-4 are issued behind it
+    before anybody looks.  Every forward has a status slot of its own; the words are sticky, so the first slot that shows the
+    flag names the culprit: forwards 2, 3, 4 are repeated on the fp32 kernels into the tensors they returned, forwards 0-1 are
+    left alone.  A forward whose INPUT tensors were refilled in place since (torch's version counter) is not repeated from
+    them: its outputs become NaN, never flows of other frames."""
+    w = util.model_weights(False)
+    im0, im1 = util.smooth_images(2, 192, 256, seed=31, shift=(2, -1))
+    ref = pa.PWCDCNet(f16x2=False)
+    ref.load_weights(w)
+    net = pa.PWCDCNet(range_check="lazy")
+    net.load_weights(w)
+    frames = [(gpu(im0 * s), gpu(im1 * s)) for s in (1.0, 0.5, 1e7, 2.0, 0.25)]
+    want = [ref(a, b)[0].clone() for a, b in frames]
+    torch.cuda.synchronize()
+    from pwcnet_amd import _lib
+    with pytest.warns(RuntimeWarning, match="issued behind it"):
+        outs = [net(a, b)[0] for a, b in frames[:2]]
+        # a device-side spin (~50 ms) in front of forward 2: none of the status copies behind it can arrive before status()
+        _lib.check(_lib.lib().pwc_device_spin(5_000_000, _lib.current_stream()))
+        outs.append(net(*frames[2])[0])
+        outs.append(net(*frames[3])[0])
+        # forward 4's frames are refilled in place before anybody has looked at the status words
+        a4, b4 = frames[4][0].clone(), frames[4][1].clone()
+        outs.append(net(a4, b4)[0])
+        a4.mul_(3.0)
+        rep = net.status()
+    assert rep["f16x2"] is False
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        assert float((outs[i] - want[i]).abs().max()) <= 1e-4          # (F16-pipe results, untouched)
+    for i in (2, 3):
+        assert torch.equal(outs[i], want[i]), i                        # repeated on the fp32 kernels
+    assert bool(torch.isnan(outs[4]).all())                            # inputs modified since: invalidated, not recomputed
+
+
+@pytest.mark.parametrize("streams", [1, 2])
+def test_fallback_refreshes_the_returned_pyramid_too(pa, streams):
+    """with_features=True hands out pyramid_0, which came from the overflowing F16-pipe extractor -- the fp32 repeat
+    must refresh it along with the flows; and the repeat must also work when the batch runs as sub-batches on side streams."""
+    w = util.model_weights(False)
+    im0, im1 = util.smooth_images(4, 192, 256, seed=33, shift=(1, 2))
+    big0, big1 = gpu(im0 * 1e7), gpu(im1 * 1e7)
+    ref = pa.PWCDCNet(f16x2=False, streams=streams)
+    ref.load_weights(w)
+    net = pa.PWCDCNet(range_check="sync", streams=streams)
+    net.load_weights(w)
+    if streams == 1:
+        want = ref(big0, big1, with_features=True)
+        with pytest.warns(RuntimeWarning, match="fp16's range"):
+            got = net(big0, big1, with_features=True)
+        torch.cuda.synchronize()
+        assert len(got) == 3 and torch.equal(got[0], want[0])
+        for g, e in zip(got[2], want[2]):
+            assert bool(torch.isfinite(g).all()) and torch.equal(g, e)
+    else:
+        want = ref(big0, big1)
+        with pytest.warns(RuntimeWarning, match="fp16's range"):
+            got = net(big0, big1)
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], want[0]) and all(torch.equal(g, e) for g, e in zip(got[1], want[1]))

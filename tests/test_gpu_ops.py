@@ -381,38 +381,44 @@ def test_conv_small_launch_kernel_vs_oracle(pa, N, H, W, cin, cout, stride, dil,
     _lib.check(L.pwc_conv3x3_sk_pack_f32(_p(kg), None, cin, cin, cout, _p(packed), None))
     exp = orc.conv3x3(x, k, b, stride, dil, 0.1)
     Ho, Wo = exp.shape[1:3]
-    L.pwc_debug_conv3x3_sk_tile(tile)
-    try:
-        ys = []
-        for _ in range(2):
-            y = torch.full((N, Ho, Wo, cout + 8), -7.0, device="cuda")
-            _lib.check(L.pwc_conv3x3_sk_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout + 8, N, H, W, cin, cout, stride, dil, 1, 0.1, None))
-            torch.cuda.synchronize()
-            ys.append(y)
-        close(ys[0][..., :cout], exp)
-        assert float(ys[0][..., cout:].min()) == -7.0 and float(ys[0][..., cout:].max()) == -7.0
-        assert torch.equal(ys[0], ys[1])
-        # no activation
-        y = torch.empty((N, Ho, Wo, cout), device="cuda")
-        _lib.check(L.pwc_conv3x3_sk_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout, N, H, W, cin, cout, stride, dil, 0, 0.0, None))
-        close(y, orc.conv3x3(x, k, b, stride, dil, None))
-        # physical layout: channels padded / permuted, channel stride beyond them
-        cs = cin + 32
-        rs = np.random.RandomState(7)
-        pos = np.sort(rs.choice(cs, cin, replace=False))
-        cmap = np.full((cs,), -1, np.int32)
-        cmap[pos] = np.arange(cin, dtype=np.int32)
-        xp = rnd((N, H, W, cs + 4), 474)
-        xp[..., pos] = x
-        cm = torch.from_numpy(cmap).cuda()
-        packed2 = torch.empty(L.pwc_conv3x3_sk_packed_floats(cs, cout), device="cuda")
-        _lib.check(L.pwc_conv3x3_sk_pack_f32(_p(kg), _p(cm), cin, cs, cout, _p(packed2), None))
-        y = torch.empty((N, Ho, Wo, cout), device="cuda")
-        xpg = gpu(xp)
-        _lib.check(L.pwc_conv3x3_sk_f32(_p(xpg), cs + 4, _p(packed2), _p(bg), _p(y), cout, N, H, W, cs, cout, stride, dil, 1, 0.1, None))
-        close(y, exp)
-    finally:
-        L.pwc_debug_conv3x3_sk_tile(0)
+    def sk(*a, t=tile):
+        """pwc_conv3x3_sk_f32 (tile 0: the library's choice) or the same launch with the workgroup tile given -- an ARGUMENT of
+        pwc_conv3x3_sk_variant_f32, not a process-wide knob."""
+        if t == 0:
+            return L.pwc_conv3x3_sk_f32(*a)
+        return L.pwc_conv3x3_sk_variant_f32(*a[:-1], t, a[-1])
+    ys = []
+    for _ in range(2):
+        y = torch.full((N, Ho, Wo, cout + 8), -7.0, device="cuda")
+        _lib.check(sk(_p(xg), cin, _p(packed), _p(bg), _p(y), cout + 8, N, H, W, cin, cout, stride, dil, 1, 0.1, None))
+        torch.cuda.synchronize()
+        ys.append(y)
+    close(ys[0][..., :cout], exp)
+    assert float(ys[0][..., cout:].min()) == -7.0 and float(ys[0][..., cout:].max()) == -7.0
+    assert torch.equal(ys[0], ys[1])
+    # no activation
+    y = torch.empty((N, Ho, Wo, cout), device="cuda")
+    _lib.check(sk(_p(xg), cin, _p(packed), _p(bg), _p(y), cout, N, H, W, cin, cout, stride, dil, 0, 0.0, None))
+    close(y, orc.conv3x3(x, k, b, stride, dil, None))
+    # physical layout: channels padded / permuted, channel stride beyond them
+    cs = cin + 32
+    rs = np.random.RandomState(7)
+    pos = np.sort(rs.choice(cs, cin, replace=False))
+    cmap = np.full((cs,), -1, np.int32)
+    cmap[pos] = np.arange(cin, dtype=np.int32)
+    xp = rnd((N, H, W, cs + 4), 474)
+    xp[..., pos] = x
+    cm = torch.from_numpy(cmap).cuda()
+    packed2 = torch.empty(L.pwc_conv3x3_sk_packed_floats(cs, cout), device="cuda")
+    _lib.check(L.pwc_conv3x3_sk_pack_f32(_p(kg), _p(cm), cin, cs, cout, _p(packed2), None))
+    y = torch.empty((N, Ho, Wo, cout), device="cuda")
+    xpg = gpu(xp)
+    wide = tile > 30 and cs > (288 if stride == 1 else 128)       # (the padded input is too wide for the LDS-patch form)
+    if wide:
+        assert L.pwc_conv3x3_sk_variant_f32(_p(xpg), cs + 4, _p(packed2), _p(bg), _p(y), cout, N, H, W, cs, cout, stride, dil, 1, 0.1,
+                                            tile, None) == -4      # PWC_EUNSUPPORTED, said -- not silently another tile
+    _lib.check(sk(_p(xpg), cs + 4, _p(packed2), _p(bg), _p(y), cout, N, H, W, cs, cout, stride, dil, 1, 0.1, None, t=0 if wide else tile))
+    close(y, exp)
 
 
 @pytest.mark.parametrize("N,H,W,cin,stride", [
@@ -551,7 +557,7 @@ def test_conv_f16x2_direct_stride2_vs_oracle(pa, N, H, W, cin, cout):
     for ws in wss:
         y = torch.full((N, Ho, Wo, cout + 8), -7.0, device="cuda")
         wp, wn = (None, 0) if ws is None else (_p(ws), ws.numel())
-        _lib.check(L.pwc_conv3x3_h2_stride2_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout + 8, N, H, W, cin, cout, 1, 0.1, wp, wn, None))
+        _lib.check(L.pwc_conv3x3_h2_stride2_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout + 8, N, H, W, cin, cout, 1, 0.1, wp, wn, None, None))
         torch.cuda.synchronize()
         if big:
             for i in (0, N - 1):
@@ -577,12 +583,12 @@ def test_conv_f16x2_direct_stride2_vs_oracle(pa, N, H, W, cin, cout):
         _lib.check(L.pwc_conv3x3_h2_stride2_pack_f32(_p(kg), _p(cm), cin, cs, cout, _p(packed2), None))
         y = torch.full((N, Ho, Wo, cout), -7.0, device="cuda")
         xpg = gpu(xp)
-        _lib.check(L.pwc_conv3x3_h2_stride2_f32(_p(xpg), cs + 4, _p(packed2), _p(bg), _p(y), cout, N, H, W, cs, cout, 1, 0.1, None, 0, None))
+        _lib.check(L.pwc_conv3x3_h2_stride2_f32(_p(xpg), cs + 4, _p(packed2), _p(bg), _p(y), cout, N, H, W, cs, cout, 1, 0.1, None, 0, None, None))
         torch.cuda.synchronize()
         close(y, exp)
     # odd sizes: not this kernel's
     y = torch.empty((N, (H + 2) // 2, Wo, cout), device="cuda")
-    assert L.pwc_conv3x3_h2_stride2_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout, N, H - 1, W, cin, cout, 1, 0.1, None, 0, None) == -4
+    assert L.pwc_conv3x3_h2_stride2_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), cout, N, H - 1, W, cin, cout, 1, 0.1, None, 0, None, None) == -4
     assert L.pwc_conv3x3_h2_stride2_supported(N, H - 1, W, cin, cout) == 0
     # the extractor's layers of BASELINE configs[1] (16 images) that go to it, and the one that does not (7 x 16 outputs)
     assert L.pwc_conv3x3_h2_stride2_supported(16, 224, 512, 16, 32) == 1 and L.pwc_conv3x3_h2_stride2_supported(16, 112, 256, 32, 64) == 1

@@ -44,6 +44,31 @@ def test_library_exports_every_declared_symbol():
     assert L.pwc_conv3x3_f32(None, 16, None, None, None, 16, 1, 4, 4, 16, 16, 1, 1, 1, 0.1, -1, 0, None, 0, None) == -1
 
 
+def test_production_library_has_no_debug_knobs():
+    """VERDICT r5 item 5 / SURVEY 8(b) "no global mutable state": the production libpwc_hip.so exports no pwc_debug_* symbol
+    (the tile-pinning / ablation knobs of the A/B scripts live in libpwc_hip_harness.so, built with -DPWC_HARNESS only when a
+    script asks, PWC_HARNESS=1), the header declares none, and the tile of the small-launch conv is an ARGUMENT
+    (pwc_conv3x3_sk_variant_f32) validated before any launch."""
+    assert not _lib.HARNESS and _lib.LIB_PATH.endswith("libpwc_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    assert any(n == "pwc_version" for n in exported)
+    assert [n for n in exported if "debug" in n.lower()] == []
+    header = open(os.path.join(ROOT, "include", "pwc_hip.h")).read()
+    assert not re.search(r"\bpwc_debug_[a-z0-9_]+\s*\(", header)
+    assert not any("debug" in n for n in _lib.SIGNATURES)
+    L = _lib.lib()
+    for name in _lib.HARNESS_SIGNATURES_NAMES:
+        assert not hasattr(L, name), name
+    al = ctypes.c_void_p(4096)      # (an aligned non-null address: argument checks only, nothing is launched)
+    v = L.pwc_conv3x3_sk_variant_f32
+    assert v(al, 64, al, al, al, 32, 1, 8, 8, 64, 32, 1, 1, 1, 0.1, 0, None) == -1       # tile 0 is pwc_conv3x3_sk_f32's business
+    assert v(al, 64, al, al, al, 32, 1, 8, 8, 64, 32, 1, 1, 1, 0.1, 13, None) == -1      # no such tile
+    assert v(al, 64, al, al, al, 48, 1, 8, 8, 64, 48, 1, 1, 1, 0.1, 22, None) == -4      # x2 tiles need Cout % 32 == 0
+    assert v(al, 64, al, al, al, 32, 1, 8, 8, 64, 32, 1, 2, 1, 0.1, 31, None) == -4      # the LDS-patch form takes no dilation
+    assert v(al, 320, al, al, al, 32, 1, 8, 8, 320, 32, 1, 1, 1, 0.1, 41, None) == -4    # ... and at most 288 input channels
+
+
 def test_round5_routing_rules_are_host_logic():
     """Which kernel takes which launch is decided by pure host functions of the library (no GPU needed): the small-launch conv
     (up to 1e8 multiply-adds and 4096 output pixels; stride-2 / thin layers beyond), the weights-stationary thin-input conv
@@ -503,3 +528,27 @@ def test_flow_color_wheel_and_crop():
     c = flow_io.flow_to_color(f)
     assert not np.array_equal(c[0, 0], c[0, 1])                                        # opposite directions differ
     assert flow_io.factor_crop(np.zeros((130, 200, 3))).shape == (128, 192, 3)
+
+
+def test_stale_counter_evidence_is_refused(tmp_path):
+    """bench.traffic_stale: no stamp, another source hash, or another launch count per forward -> a reason (the traffic is not
+    printed); the tree's own stamp with the same launch count -> None.  And the committed profiles/pmc_traffic.json either
+    matches the committed kernel sources or will be reported as stale -- never printed as this run's evidence."""
+    import json, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from pwcnet_amd.profiler import source_stamp
+    now = source_stamp()
+    assert len(now) == 16 and now == source_stamp()
+    fam = {"launches_per_forward": 23.0}
+    assert bench.traffic_stale(None, fam, 23.0) is not None
+    assert "kernel sources" in bench.traffic_stale({"source_sha": "0" * 16}, fam, 23.0)
+    assert "launches per forward" in bench.traffic_stale({"source_sha": now}, fam, 24.0)
+    assert bench.traffic_stale({"source_sha": now}, fam, 23.0) is None
+    t = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    st = t.get("stamp")
+    verdict = bench.traffic_stale(st, t["kernels"].get("conv3x3_h2_kernel"), None)
+    assert verdict is None or isinstance(verdict, str)
+    if st and st.get("source_sha") == now:
+        assert verdict is None and "conv3x3_h2_kernel" in st["kernel_symbols"]
