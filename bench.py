@@ -585,6 +585,53 @@ def corr_warp_op_leg(net, B, H, Wd, dev, reps=12):
         levels.append((l, h, w, chans[l]))
     totals = collections.OrderedDict()
     per_level = {}
+    # Round 6: inside the forward a correlation launch follows matrix-bound launches that hold the chip at
+    # its power cap (sclk ~1.7 GHz, ~1300 W); among its own kind (the chains above) it runs at ~2.35 GHz / 400 W
+    # (profiles/r06_exp_cv_in_context.txt + the sclk / power trace beside it).  "In context" = a chain of [conv3x3_h2 128 -> 128 at
+    # B x 112 x 256 ; the level's launches] minus the chain of the convolutions alone: what the level costs right behind a
+    # matrix-bound launch -- the figure the forward pays, and this leg's headline.
+    import ctypes
+    from pwcnet_amd import _lib
+    Lc = _lib.lib()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    cx = torch.randn((B, 112, 256, 128), generator=g, device=dev)
+    cy = torch.empty((B, 112, 256, 128), device=dev)
+    cw = torch.randn((3, 3, 128, 128), generator=g, device=dev) * 0.03
+    cb = torch.zeros(128, device=dev)
+    cpk = torch.empty(Lc.pwc_conv3x3_h2_packed_floats(128, 128), device=dev)
+    _lib.check(Lc.pwc_conv3x3_h2_pack_f32(vp(cw), None, 128, 128, 128, vp(cpk), None))
+    cwsf = int(Lc.pwc_conv3x3_h2_workspace_floats(B, 112, 256, 128, 128, 1))
+    cws = torch.full((max(cwsf, 1),), -1, dtype=torch.int32, device=dev).view(torch.float32)
+
+    def neighbour():
+        _lib.check(Lc.pwc_conv3x3_h2_f32(vp(cx), 128, vp(cpk), vp(cb), vp(cy), 128, B, 112, 256, 128, 128, 1, 1, 0.1,
+                                         vp(cws) if cwsf else None, cws.numel() if cwsf else 0, _lib.current_stream()))
+
+    def replay_us(fn, n):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for r in range(n):
+                fn(r)
+        graph.replay()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / n)
+        del graph
+        return sorted(ts)[2]
+
+    neighbour()
+    torch.cuda.synchronize()
+    conv_us = None
+    try:
+        conv_us = replay_us(lambda r: neighbour(), 24)
+    except RuntimeError as e:
+        print(f"op leg: no graph capture of the neighbour chain ({e})", file=sys.stderr)
     for l, h, w, C in levels:
         # the estimator input buffer of this level, as PWCDCNet lays it out (non-DC geometry)
         lay = net._est_layout(l, B, h, w, C, l > 0, list(range(32)) if l > 0 else None)
@@ -647,26 +694,46 @@ def corr_warp_op_leg(net, B, H, Wd, dev, reps=12):
             del graph
         except RuntimeError as e:      # capture refused (a launch path that allocates): the event pairs stay the measure
             print(f"op leg level {l}: no graph capture ({e}); event pairs per launch only", file=sys.stderr)
+        ctx_us = None
+        if conv_us is not None and chain_us is not None:
+            try:
+                n_chain = max(nsets, 24)
+                ctx_us = replay_us(lambda r: (neighbour(), run(sets[r % nsets])), n_chain) - conv_us
+            except RuntimeError as e:
+                print(f"op leg level {l}: no graph capture of the in-context chain ({e})", file=sys.stderr)
         level_us = chain_us if chain_us is not None else 1e3 * ev_ms / reps
         for k, d in lsum.items():
             share = d["ms"] / ev_ms if ev_ms > 0 else 1.0 / len(lsum)
-            t = totals.setdefault(k, dict(us=0.0, bytes=0.0, launches=0.0, ev_us=0.0))
+            t = totals.setdefault(k, dict(us=0.0, bytes=0.0, launches=0.0, ev_us=0.0, ctx_us=0.0))
             t["us"] += level_us * share                 # a level of several launches: the chain time split by event-pair shares
+            t["ctx_us"] += (ctx_us if ctx_us is not None else level_us) * share
             t["bytes"] += d["bytes"] / reps
             t["launches"] += d["launches"] / reps
             t["ev_us"] += 1e3 * d["ms"] / reps
         per_level[l] = dict(h=h, w=w, C=C, sets=nsets, est_buffer_channels=est_cs, f0_in_buffer="f0" in lay.segments,
-                            us_chain=chain_us, us_event_pairs=1e3 * ev_ms / reps)
+                            us_chain=chain_us, us_event_pairs=1e3 * ev_ms / reps, us_in_context=ctx_us,
+                            algorithmic_bytes=sum(d["bytes"] for d in lsum.values()) / reps)
         del sets
-    us = sum(t["us"] for t in totals.values())
+    us_alone = sum(t["us"] for t in totals.values())
+    us = sum(t["ctx_us"] for t in totals.values())      # headline: in context (falls back to the plain chains level by level)
     by = sum(t["bytes"] for t in totals.values())
     ach = by / (us * 1e-6) / 1e9
+    for lv in per_level.values():
+        u = lv["us_in_context"] if lv["us_in_context"] is not None else lv["us_chain"]
+        lv["frac_in_context"] = (lv["algorithmic_bytes"] / (u * 1e-6) / 1e9 / PEAK_HBM_GBS) if u else None
+        lv["frac_alone"] = (lv["algorithmic_bytes"] / (lv["us_chain"] * 1e-6) / 1e9 / PEAK_HBM_GBS) if lv["us_chain"] else None
     return {"kernel": "+".join(totals), "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": ach / PEAK_HBM_GBS, "traffic": None,
             "us_per_forward": us,
+            "headline": "in context: every level's launches timed right behind a matrix-bound launch (chain of [conv3x3_h2 128 -> 128 ; "
+                        "level] minus the chain of the convolutions alone) -- the clock and power state the forward runs them in",
+            "neighbour_conv_us": conv_us,
+            "us_per_forward_alone": us_alone, "achieved_alone": by / (us_alone * 1e-6) / 1e9,
+            "frac_alone": by / (us_alone * 1e-6) / 1e9 / PEAK_HBM_GBS,
             "us_per_forward_event_pairs": sum(t["ev_us"] for t in totals.values()),
             "algorithmic_bytes_per_forward": by,
             "per_kernel": {k: {"avg_us": t["us"] / t["launches"], "avg_us_event_pair": t["ev_us"] / t["launches"],
+                               "avg_us_in_context": t["ctx_us"] / t["launches"],
                                "gbs": t["bytes"] / (t["us"] * 1e-6) / 1e9,
                                "launches_per_forward": t["launches"]} for k, t in totals.items()},
             "per_level": per_level,

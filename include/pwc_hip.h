@@ -390,6 +390,22 @@ int pwc_conv3x3_t32_f32(const float* x, int x_cs, const float* packed_w, const f
                         int N, int H, int W, int Cin_phys, int Cout, int stride, int apply_act, float slope,
                         pwc_stream_t stream);
 int pwc_conv3x3_t32_supported(int N, int H, int W, int Cin_phys, int Cout, int stride);
+/* Round 6: the same convolution for 32 OUTPUT channels from 32 or 64 input channels, stride 1, no dilation (csrc/conv3x3_w32.hip)
+ * -- fp_extractor/conv2d_4, conv2d_5 (reference modules.py:58-71), optflow_l/conv2d_4 (modules.py:266-268: the 64 -> 32 layer of
+ * every estimator) and context/conv2d_5 (modules.py:321-322).  The whole split weight tensor stays in the LDS for the life of a
+ * persistent workgroup (36 / 72 KB), all 32 output channels are the row operand of one 32 x 32 x 16 matrix instruction, the input
+ * patch of a tile (8 / 4 rows x 32 columns) is requested into registers under the previous tile's K loop and split once: no
+ * per-stage staging (pwc_conv3x3_h2_f32 runs these layers at half the rate of its 128-cout layers).  64 input channels: the K
+ * loop is dealt to two wave groups whose finished sums are added in a fixed order (launches repeat bitwise).  Arithmetic, RANGE
+ * and alignment requirements of pwc_conv3x3_sk_f32; N*H*W*x_cs*4 and N*H*W*y_cs*4 < 2^31.  packed_w: pwc_conv3x3_w32_pack_f32
+ * (pwc_conv3x3_w32_packed_floats floats; cin_map as in pwc_conv3x3_pack_f32).  pwc_conv3x3_w32_supported: 1 where it is the
+ * fastest kernel of this library for the shape (a supported shape with at least 256 tiles), else 0. */
+size_t pwc_conv3x3_w32_packed_floats(int Cin_phys);
+int pwc_conv3x3_w32_pack_f32(const float* w_hwio, const int32_t* cin_map, int Cin, int Cin_phys, float* packed_w,
+                             pwc_stream_t stream);
+int pwc_conv3x3_w32_f32(const float* x, int x_cs, const float* packed_w, const float* bias, float* y, int y_cs,
+                        int N, int H, int W, int Cin_phys, int Cout, int apply_act, float slope, pwc_stream_t stream);
+int pwc_conv3x3_w32_supported(int N, int H, int W, int Cin_phys, int Cout, int stride, int dilation);
 /* Tile variants of the kernel above (workgroup = couts x rows x 32 columns): 1 = 128 x 8, 2 = 64 x 16, 3 = 96 x 8,
  * 4 = 32 x 16, 5 = 64 x 8.  pwc_conv3x3_h2_plan: the one pwc_conv3x3_h2_f32 launches for a shape (fewest estimated
  * rounds of 256 workgroups x matrix instructions per tap; 0 = the shape is not accepted).  pwc_conv3x3_h2_variant_f32:

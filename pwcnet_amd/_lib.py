@@ -20,7 +20,7 @@ HARNESS = os.environ.get("PWC_HARNESS", "") == "1"
 LIB_PATH = os.path.join(CSRC, "libpwc_hip_harness.so" if HARNESS else "libpwc_hip.so")
 HARNESS_SIGNATURES_NAMES = ("pwc_debug_cost_volume_blk_rows", "pwc_debug_conv3x3_sk_tile", "pwc_debug_conv3x3_t32")
 SOURCES = ["conv3x3_mfma.hip", "conv3x3_wino.hip", "conv3x3_direct.hip", "cost_volume.hip", "pwc_ops.hip",
-           "pwc_backward.hip", "conv3x3_wgrad.hip", "conv3x3_h2.hip", "conv3x3_c16pair.hip", "conv3x3_sk.hip", "conv3x3_t32.hip"]
+           "pwc_backward.hip", "conv3x3_wgrad.hip", "conv3x3_h2.hip", "conv3x3_c16pair.hip", "conv3x3_sk.hip", "conv3x3_t32.hip", "conv3x3_w32.hip"]
 HEADERS = ["pwc_common.h", "cost_volume_roll.hip", "cost_volume_mfma.hip", "cost_volume_h2.hip", "cost_volume_blk.hip", "conv3x3_wino4.hip", os.path.join("..", "..", "include", "pwc_hip.h")]
 
 _vp, _i, _f, _l, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long, ctypes.c_size_t
@@ -75,6 +75,10 @@ SIGNATURES = {
     "pwc_conv3x3_t32_pack_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pwc_conv3x3_t32_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "pwc_conv3x3_t32_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "pwc_conv3x3_w32_packed_floats": (_sz, [_i]),
+    "pwc_conv3x3_w32_pack_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "pwc_conv3x3_w32_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "pwc_conv3x3_w32_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "pwc_conv3x3_h2_stride2_packed_floats": (_sz, [_i, _i]),
     "pwc_conv3x3_h2_stride2_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pwc_conv3x3_h2_stride2_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),

@@ -176,6 +176,48 @@ __global__ __launch_bounds__(256) void resize_kernel(const ResizeArgs a) {
     if (STATUS && bad) atomicOr(a.status, (unsigned)PWC_STATUS_NONFINITE);
 }
 
+// Round 6: the forward's LAST launch -- the x4 up-sampling of the 2-channel flows to the frame size, times 20 (reference
+// model.py:125-127; 29 MB written for 1.8 MB read at batch 8) -- one thread per SOURCE cell: its four corners are requested once
+// and its 4 x 4 output pixels leave as four 32-byte runs (a wave: 2 KB contiguous per output row) instead of one 8-byte store and
+// four corner requests per output pixel.  in / out = 1/4 exactly: src = dst / 4 is exact, lo = dst >> 2, t = (dst & 3) / 4 -- the
+// values of resize_kernel, same expressions.  Needs C == 2, OH == 4 H, OW == 4 W, y dense (y_cs == 2) and 16-byte aligned.
+template <bool STATUS>
+__global__ __launch_bounds__(256) void resize_x4_c2_kernel(const ResizeArgs a, int ncells) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= ncells) return;
+    const int xs = e % a.W;
+    const int r = e / a.W;
+    const int ys = r % a.H, n = r / a.H;
+    const int x1 = min(xs + 1, a.W - 1), y1 = min(ys + 1, a.H - 1);
+    const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs;
+    const f32x2 tl = *reinterpret_cast<const f32x2*>(xn + ((size_t)ys * a.W + xs) * a.x_cs);
+    const f32x2 tr = *reinterpret_cast<const f32x2*>(xn + ((size_t)ys * a.W + x1) * a.x_cs);
+    const f32x2 bl = *reinterpret_cast<const f32x2*>(xn + ((size_t)y1 * a.W + xs) * a.x_cs);
+    const f32x2 br = *reinterpret_cast<const f32x2*>(xn + ((size_t)y1 * a.W + x1) * a.x_cs);
+    bool bad = false;
+    float* yo = a.y + (((size_t)n * a.OH + 4 * ys) * a.OW + 4 * xs) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float yl = 0.25f * (float)j;
+        f32x2 o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xl = 0.25f * (float)i;
+            const f32x2 top = tl + (tr - tl) * xl;
+            const f32x2 bot = bl + (br - bl) * xl;
+            o[i] = (top + (bot - top) * yl) * a.mul;
+            if (STATUS)
+                bad = bad || (__builtin_bit_cast(unsigned, (float)o[i][0]) & 0x7F800000u) == 0x7F800000u ||
+                      (__builtin_bit_cast(unsigned, (float)o[i][1]) & 0x7F800000u) == 0x7F800000u;
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(yo + (size_t)j * a.OW * 2);
+        dst[0] = f32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
+        dst[1] = f32x4{o[2][0], o[2][1], o[3][0], o[3][1]};
+    }
+    if (STATUS && bad) atomicOr(a.status, (unsigned)PWC_STATUS_NONFINITE);
+}
+
 static int resize_run(const float* x, int x_cs, float* y, int y_cs, int N, int H, int W,
                       int C, int OH, int OW, float mul, uint32_t* status, pwc_stream_t stream) {
     if (!x || !y) return PWC_EINVAL;
@@ -189,6 +231,14 @@ static int resize_run(const float* x, int x_cs, float* y, int y_cs, int N, int H
     a.sy = (float)H / (float)OH; a.sx = (float)W / (float)OW; a.mul = mul;
     a.rows = N * OH;
     a.status = status;
+    if (C == 2 && OH == 4 * H && OW == 4 * W && y_cs == 2 && (x_cs % 2 == 0) && ((uintptr_t)x % 8 == 0) && pwc_aligned16(y) &&
+        (long)N * H * W < (1L << 31)) {
+        const int ncells = N * H * W;
+        const dim3 g((unsigned)((ncells + 255) / 256));
+        if (status) hipLaunchKernelGGL(resize_x4_c2_kernel<true>, g, dim3(256), 0, (hipStream_t)stream, a, ncells);
+        else hipLaunchKernelGGL(resize_x4_c2_kernel<false>, g, dim3(256), 0, (hipStream_t)stream, a, ncells);
+        return pwc_launch_status();
+    }
     const bool vec4 = (C % 4 == 0) && (x_cs % 4 == 0) && (y_cs % 4 == 0) && pwc_aligned16(x) && pwc_aligned16(y);
     const bool vec2 = (C % 2 == 0) && (x_cs % 2 == 0) && (y_cs % 2 == 0) && ((uintptr_t)x % 8 == 0) &&
                       ((uintptr_t)y % 8 == 0);
@@ -357,7 +407,14 @@ extern "C" int pwc_resize_bilinear_pair_f32(const float* xa, int xa_cs, float* y
     a.H = H; a.W = W; a.CB = CB; a.OH = OH; a.OW = OW;
     a.sy = (float)H / (float)OH; a.sx = (float)W / (float)OW;
     a.rows = N * OH;
-    if (OH == 2 * H && OW == 2 * W && CB >= 64) {
+    // per source cell from 64 feature channels on, and from 32 on where a launch has at least 8192 source pixels (measured, batch 8,
+    // flow 2 + features 32 into a 128-channel buffer: 28 x 64: 5.0 against 5.9 us, 56 x 128: 12.7 against 14.3; the two coarsest
+    // levels are level or slower: profiles/r06_exp_resize_ab.txt)
+    int min_cb_2x = (long)N * H * W >= 8192 ? 32 : 64;
+#ifdef PWC_HARNESS
+    if (const char* e = getenv("PWC_RESIZE2X_MIN_CB")) min_cb_2x = atoi(e);     // libpwc_hip_harness.so only (scripts/exp_resize_ab.py)
+#endif
+    if (OH == 2 * H && OW == 2 * W && CB >= min_cb_2x) {
         const long total = (long)N * H * W * (1 + CB / 4);
         long blocks = (total + 255) / 256;
         if (blocks > 256 * 64) blocks = 256 * 64;

@@ -271,12 +271,22 @@ class PWCDCNet(object):
         if len(self._pending) >= self._STATUS_SLOTS - 1:    # (a slot is reused only after its forward has been looked at)
             self._examine(wait=True)
         st = self._status[str(images_0.device)]
-        words, ring, nxt = st
+        words, ring, nxt = st[0], st[1], st[2]
         host = ring[nxt % self._STATUS_SLOTS]
         st[2] = nxt + 1
-        host.copy_(words, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        # the 8-byte copy runs on a stream of its own behind an event: on the caller's stream it is a 4-5 us blit dispatch at the
+        # end of every forward (profiles/r05_forward_trace_b8.txt, row 63).  The words are sticky, so a copy that is overtaken by
+        # the next forward can only show a flag EARLY -- _examine then repeats one innocent forward more, never one less.
+        if len(st) < 4:
+            st.append(torch.cuda.Stream(device=images_0.device))
+        side = st[3]
+        done = torch.cuda.Event()
+        done.record()
+        side.wait_event(done)
+        with torch.cuda.stream(side):
+            host.copy_(words, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
         vers = (getattr(images_0, "_version", None), getattr(images_1, "_version", None))
         self._pending.append((ev, host, images_0, images_1, vers, out, images_0.device))
 
@@ -434,7 +444,7 @@ class PWCDCNet(object):
             self._eager_buffers[bkey] = self._buffers = {} if bufs is None else bufs
             while len(self._eager_buffers) > self.max_plans:
                 self._eager_buffers.popitem(last=False)
-            return self._hand_over(self._forward(iv0, iv1, dev, with_features), into)
+            return self._hand_over(self._forward(iv0, iv1, dev, with_features), into, with_features)
         # (the alignment of the frames is part of the key: the fused level-1 launch of the extractor takes 16-byte aligned
         # frames only, and a plan recorded with it must not be replayed on a view that is not -- ADVICE r4)
         key = (iv0[1:], str(dev), stream, bool(with_features), self.store.version, iv0.ptr % 16, iv1.ptr % 16)
@@ -477,8 +487,8 @@ class PWCDCNet(object):
         self._plans[key] = plan
         while len(self._plans) > self.max_plans:
             self._plans.popitem(last=False)          # least recently used; its buffers go with it
-        if into is not None:                         # recording call of a sub-batch: hand the results over
-            return self._hand_over(outputs, into)
+        if into is not None:                         # recording call of a sub-batch / of a repeat: hand the results over
+            return self._hand_over(outputs, into, with_features)
         if with_features and not self.persistent_outputs:
             # pyramid_0 are slices of plan-owned extractor activations: the next replay of this shape would
             # rewrite them under the caller (flows_final / flows_pyramid of the recording call are tensors of
@@ -487,14 +497,17 @@ class PWCDCNet(object):
         return outputs
 
     @staticmethod
-    def _hand_over(outputs, into):
+    def _hand_over(outputs, into, with_features=False):
         """Copy a forward's own flows into the caller-provided `into` = (final, pyramid) slices (sub-batches on
-        side streams); with into=None the outputs pass through."""
+        side streams, repeats on the fp32 kernels); with into=None the outputs pass through.  with_features: the pyramid of
+        that forward rides along as the third element (copies: the activations behind it belong to the plan)."""
         if into is None:
             return outputs
         into[0].copy_(outputs[0])
         for dst, src in zip(into[1], outputs[1]):
             dst.copy_(src)
+        if with_features:
+            return into[0], into[1], [t.clone() for t in outputs[2]]
         return into
 
     def _fresh_outputs(self, plan, patch, into=None):

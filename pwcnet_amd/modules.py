@@ -351,6 +351,32 @@ class _ConvRunner:
                    and L.pwc_conv3x3_t32_supported(x.N, x.H, x.W, x.C, cout, stride))
         if x2 is not None and not use_h2:
             raise _lib.PwcHipError(f"{name}: a two-operand input needs the F16-pipe kernel (h2_two_operand_ok)")
+        # 32 output channels from 32 / 64 input channels (round 6): the weights resident in the LDS (conv3x3_w32.hip)
+        use_w32 = (use_mfma and getattr(self.owner, "f16x2", True) and getattr(self.owner, "w32_conv", True) and x2 is None
+                   and tile < 0 and split == 0 and stride == 1 and dilation == 1 and cout == 32 and x.C in (32, 64)
+                   and y.cs % 4 == 0 and y.ptr % 16 == 0 and x.N * Ho * Wo * y.cs * 4 < (1 << 31)
+                   and L.pwc_conv3x3_w32_supported(x.N, x.H, x.W, x.C, cout, stride, dilation))
+        if use_w32:
+            key = (name, "w32", x.C, None if cin_map is None else cin_map.tobytes(), self.store.version)
+            packed = cache.get(key)
+            if packed is None:
+                packed = torch.empty((L.pwc_conv3x3_w32_packed_floats(x.C),), dtype=torch.float32, device=kern.value.device)
+                cm = None
+                if cin_map is not None:
+                    assert len(cin_map) == x.C
+                    cm = torch.from_numpy(np.ascontiguousarray(cin_map, np.int32)).to(kern.value.device)
+                _lib.check(L.pwc_conv3x3_w32_pack_f32(_p(kern.value.data_ptr()), _p(cm.data_ptr()) if cm is not None else None,
+                                                      cin, x.C, _p(packed.data_ptr()), s), "conv3x3 w32 pack")
+                cache[key] = packed
+            _keep(packed, y_t)
+            _track_max(self.owner, x)
+            _launch(L.pwc_conv3x3_w32_f32,
+                    (_p(x.ptr), x.cs, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
+                     x.N, x.H, x.W, x.C, cout, act, sl, s),
+                    f"conv3x3_w32 {name}", "conv3x3_w32_kernel",
+                    2.0 * x.N * Ho * Wo * 9 * cin * cout, 4.0 * (x.N * x.H * x.W * cin + x.N * Ho * Wo * cout),
+                    exec_flops=3.0 * 2.0 * x.N * Ho * Wo * 9 * x.C * cout)
+            return y, y_t
         if use_t32:
             key = (name, "t32", x.C, None if cin_map is None else cin_map.tobytes(), self.store.version)
             packed = cache.get(key)

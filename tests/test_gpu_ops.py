@@ -421,6 +421,64 @@ def test_conv_small_launch_kernel_vs_oracle(pa, N, H, W, cin, cout, stride, dil,
     close(y, exp)
 
 
+@pytest.mark.parametrize("N,H,W,cin", [
+    (16, 112, 256, 32), (8, 112, 256, 64), (8, 56, 128, 64), (1, 40, 70, 32), (3, 33, 45, 64), (1, 8, 32, 32), (1, 4, 32, 64),
+    (1, 3, 5, 64), (1, 1, 1, 32), (2, 61, 100, 64), (2, 9, 100, 32), (1, 240, 480, 64)])
+def test_conv_lds_resident_weights_kernel_vs_oracle(pa, N, H, W, cin):
+    """pwc_conv3x3_w32_f32 (round 6, conv3x3_w32.hip: 32 output channels, the whole weight tensor resident in the LDS, patches
+    through registers): fp_extractor/conv2d_4 (32 -> 32 at 16 x 112 x 256), optflow_4/conv2d_4 and context/conv2d_5 (64 -> 32 at
+    8 x 112 x 256), optflow_3/conv2d_4 of BASELINE configs[1] and the 64 -> 32 layer of configs[4] at full size, ragged tiles
+    (H % 8, H % 4, W % 32 != 0), images smaller than a tile, more tiles than CUs and fewer; strided output with untouched
+    neighbours, no activation, padded / permuted input channels (cin_map) at a channel stride beyond them; the two K halves of
+    the 64-channel form are added in a fixed order: launches repeat bitwise."""
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    x = rnd((N, H, W, cin), 481)
+    k = rnd((3, 3, cin, 32), 482) * float(1.0 / np.sqrt(9 * cin))
+    b = rnd((32,), 483) * 0.1
+    xg, kg, bg = gpu(x), gpu(k), gpu(b)
+    packed = torch.empty(L.pwc_conv3x3_w32_packed_floats(cin), device="cuda")
+    _lib.check(L.pwc_conv3x3_w32_pack_f32(_p(kg), None, cin, cin, _p(packed), None))
+    big = N * H * W > 200000
+    exp = orc.conv3x3(x[:2] if big else x, k, b, 1, 1, 0.1)
+    ys = []
+    for _ in range(2):
+        y = torch.full((N, H, W, 40), -7.0, device="cuda")
+        _lib.check(L.pwc_conv3x3_w32_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), 40, N, H, W, cin, 32, 1, 0.1, None))
+        torch.cuda.synchronize()
+        ys.append(y)
+    close(ys[0][:exp.shape[0], ..., :32], exp)
+    if big:                                                  # (the last image too: the persistent walk reaches every tile)
+        close(ys[0][N - 1:, ..., :32], orc.conv3x3(x[N - 1:], k, b, 1, 1, 0.1))
+    assert float(ys[0][..., 32:].min()) == -7.0 and float(ys[0][..., 32:].max()) == -7.0
+    assert torch.equal(ys[0], ys[1])
+    if big:
+        return
+    y = torch.empty((N, H, W, 32), device="cuda")
+    _lib.check(L.pwc_conv3x3_w32_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), 32, N, H, W, cin, 32, 0, 0.0, None))
+    close(y, orc.conv3x3(x, k, b, 1, 1, None))
+    # physical layout: fewer logical channels, scattered over the physical ones, at a channel stride beyond them
+    clog = cin - 5
+    rs = np.random.RandomState(9)
+    pos = np.sort(rs.choice(cin, clog, replace=False))
+    cmap = np.full((cin,), -1, np.int32)
+    cmap[pos] = np.arange(clog, dtype=np.int32)
+    xl = rnd((N, H, W, clog), 484)
+    xp = rnd((N, H, W, cin + 4), 485)
+    xp[..., pos] = xl
+    k2 = rnd((3, 3, clog, 32), 486) * float(1.0 / np.sqrt(9 * clog))
+    cm = torch.from_numpy(cmap).cuda()
+    packed2 = torch.empty(L.pwc_conv3x3_w32_packed_floats(cin), device="cuda")
+    _lib.check(L.pwc_conv3x3_w32_pack_f32(_p(gpu(k2)), _p(cm), clog, cin, _p(packed2), None))
+    xpg = gpu(xp)
+    _lib.check(L.pwc_conv3x3_w32_f32(_p(xpg), cin + 4, _p(packed2), _p(bg), _p(y), 32, N, H, W, cin, 32, 1, 0.1, None))
+    close(y, orc.conv3x3(xl, k2, b, 1, 1, 0.1))
+    # what the entry point refuses
+    assert L.pwc_conv3x3_w32_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), 32, N, H, W, 48, 32, 1, 0.1, None) == -4
+    assert L.pwc_conv3x3_w32_f32(_p(xg), cin, _p(packed), _p(bg), _p(y), 64, N, H, W, cin, 64, 1, 0.1, None) == -4
+    assert L.pwc_conv3x3_w32_f32(_p(xg), cin - 4, _p(packed), _p(bg), _p(y), 32, N, H, W, cin, 32, 1, 0.1, None) == -1
+
+
 @pytest.mark.parametrize("N,H,W,cin,stride", [
     (2, 112, 256, 32, 1), (16, 112, 256, 32, 1), (2, 224, 512, 16, 2), (16, 224, 512, 16, 2), (1, 40, 70, 32, 1), (3, 33, 45, 16, 2),
     (1, 30, 64, 16, 1), (2, 9, 13, 16, 2), (1, 8, 32, 32, 1), (1, 3, 5, 32, 1), (1, 1, 1, 16, 2), (2, 61, 100, 16, 2)])
@@ -1475,6 +1533,35 @@ def test_coarse_cost_volume_rejects_other_search_ranges(pa):
 def test_resize_vs_oracle(pa, N, H, W, C, OH, OW, mul):
     x = rnd((N, H, W, C), 34)
     close(pa.resize_bilinear(gpu(x), (OH, OW), mul), orc.resize_bilinear(x, (OH, OW), mul), rel=1e-6, floor=1e-6)
+
+
+@pytest.mark.parametrize("N,H,W,x_cs", [(8, 112, 256, 2), (3, 5, 7, 2), (1, 1, 1, 2), (2, 9, 13, 6), (1, 240, 480, 2)])
+def test_final_flow_upsampling_x4_vs_oracle(pa, N, H, W, x_cs):
+    """Round 6: the forward's last launch -- x4 up-sampling of the 2-channel flows, times 20 (reference model.py:125-127) -- on
+    the one-thread-per-source-cell kernel (resize_x4_c2_kernel): production shapes of configs[1] / configs[4], odd sizes, a
+    single pixel, a source that is a channel slice of a wider tensor; the status variant flags a non-finite output and nothing
+    else; the same values as the general kernel (a destination with a channel stride takes that one)."""
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    x = rnd((N, H, W, x_cs), 341) * 3.0
+    xg = gpu(x)
+    exp = orc.resize_bilinear(np.ascontiguousarray(x[..., :2]), (4 * H, 4 * W), 20.0)
+    y = torch.full((N, 4 * H, 4 * W, 2), -5.0, device="cuda")
+    st = torch.zeros(2, dtype=torch.int32, device="cuda")
+    _lib.check(L.pwc_resize_bilinear_status_f32(_p(xg), x_cs, _p(y), 2, N, H, W, 2, 4 * H, 4 * W, 20.0, _p(st), None))
+    torch.cuda.synchronize()
+    close(y, exp, rel=1e-6, floor=1e-6)
+    assert int(st[0]) == 0
+    y2 = torch.empty_like(y)
+    _lib.check(L.pwc_resize_bilinear_f32(_p(xg), x_cs, _p(y2), 2, N, H, W, 2, 4 * H, 4 * W, 20.0, None))
+    wide = torch.full((N, 4 * H, 4 * W, 4), -5.0, device="cuda")          # (channel stride 4: the general kernel)
+    _lib.check(L.pwc_resize_bilinear_f32(_p(xg), x_cs, _p(wide), 4, N, H, W, 2, 4 * H, 4 * W, 20.0, None))
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2) and torch.equal(wide[..., :2], y) and float(wide[..., 2:].max()) == -5.0
+    xg[N - 1, H - 1, W // 2, 1] = float("inf")
+    _lib.check(L.pwc_resize_bilinear_status_f32(_p(xg), x_cs, _p(y), 2, N, H, W, 2, 4 * H, 4 * W, 20.0, _p(st), None))
+    torch.cuda.synchronize()
+    assert int(st[0]) & _lib.STATUS_NONFINITE
 
 
 @pytest.mark.parametrize("N,H,W,C", [(2, 7, 16, 32), (1, 14, 32, 32), (1, 5, 9, 8), (2, 6, 10, 288), (1, 1, 1, 64), (2, 9, 13, 736),
