@@ -506,6 +506,10 @@ def main():
 
     if not args.no_op_leg:
         line["roofline_hbm"] = corr_warp_op_leg(net, B, H, Wd, dev)
+        if "roofline_hbm_in_step" in line:
+            # the same launches inside the timed forward (HIP events around them in sampled steps; flows ~ 0 there): VERDICT r5 1c
+            line["roofline_hbm"]["frac_in_step"] = line["roofline_hbm_in_step"]["frac"]
+            line["roofline_hbm"]["us_per_forward_in_step"] = 1e3 * line["roofline_hbm_in_step"]["ms_per_step"]
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and (B, H, Wd, args.use_dc) == (8, 448, 1024, False):
             t = json.load(open(pmc)).get("op_leg")
@@ -586,10 +590,10 @@ def corr_warp_op_leg(net, B, H, Wd, dev, reps=12):
     totals = collections.OrderedDict()
     per_level = {}
     # Round 6: inside the forward a correlation launch follows matrix-bound launches that hold the chip at
-    # its power cap (sclk ~1.7 GHz, ~1300 W); among its own kind (the chains above) it runs at ~2.35 GHz / 400 W
-    # (profiles/r06_exp_cv_in_context.txt + the sclk / power trace beside it).  "In context" = a chain of [conv3x3_h2 128 -> 128 at
-    # B x 112 x 256 ; the level's launches] minus the chain of the convolutions alone: what the level costs right behind a
-    # matrix-bound launch -- the figure the forward pays, and this leg's headline.
+    # its power cap (sclk ~1.7 GHz, ~1300 W); among its own kind (the chains below) it runs at ~2.35 GHz / 400 W
+    # (profiles/r06_exp_cv_in_context.txt + the sclk / power trace beside it).  Beside each level's own chain the leg therefore
+    # times a chain of [conv3x3_h2 128 -> 128 at B x 112 x 256 ; the level's launches] and subtracts the chain of the convolutions
+    # alone: what the level ADDS behind a matrix-bound launch (a diagnostic, see the return value).
     import ctypes
     from pwcnet_amd import _lib
     Lc = _lib.lib()
@@ -636,6 +640,10 @@ def corr_warp_op_leg(net, B, H, Wd, dev, reps=12):
         # the estimator input buffer of this level, as PWCDCNet lays it out (non-DC geometry)
         lay = net._est_layout(l, B, h, w, C, l > 0, list(range(32)) if l > 0 else None)
         est_cs = lay.n_phys
+        # round 6: levels on the three-tensor estimator input write dense [cv 81 | flow 2 | 0] records (PWCDCNet._level_input)
+        three = l > 0 and net._three_operand_level(l, B, h, w, C, list(range(32)))
+        if three:
+            est_cs = net.of_estimators[l].CVX_CS
         set_bytes = 4 * B * h * w * (3 * C + 2 + est_cs)
         nsets = max(2, int(300e6 // set_bytes) + 1)
         nsets = min(nsets, 64)
@@ -655,6 +663,10 @@ def corr_warp_op_leg(net, B, H, Wd, dev, reps=12):
             v0 = M.View(f0.data_ptr(), C, B, h, w, C)
             v1 = M.View(f1.data_ptr(), C, B, h, w, C)
             Ev = M.View(E.data_ptr(), est_cs, B, h, w, est_cs)
+            if three:
+                net.cv_layer._run(v0, v1, M.View(E.data_ptr(), est_cs, B, h, w, 81), flow=M.View(fl.data_ptr(), 2, B, h, w, 2),
+                                  flow_scale=net.scales[l], concat=True, out_pad_writable=2)
+                return
             cv_out = M.sub_view(Ev, lay.offset("cv"), 81)
             f0_dst = M.sub_view(Ev, lay.offset("f0"), C) if "f0" in lay.segments else None
             flv = M.View(fl.data_ptr(), 2, B, h, w, 2)
@@ -710,30 +722,36 @@ def corr_warp_op_leg(net, B, H, Wd, dev, reps=12):
             t["bytes"] += d["bytes"] / reps
             t["launches"] += d["launches"] / reps
             t["ev_us"] += 1e3 * d["ms"] / reps
-        per_level[l] = dict(h=h, w=w, C=C, sets=nsets, est_buffer_channels=est_cs, f0_in_buffer="f0" in lay.segments,
+        per_level[l] = dict(h=h, w=w, C=C, sets=nsets, est_buffer_channels=est_cs, dense_cv_records=bool(three),
+                            f0_in_buffer=(not three) and "f0" in lay.segments,
                             us_chain=chain_us, us_event_pairs=1e3 * ev_ms / reps, us_in_context=ctx_us,
                             algorithmic_bytes=sum(d["bytes"] for d in lsum.values()) / reps)
         del sets
-    us_alone = sum(t["us"] for t in totals.values())
-    us = sum(t["ctx_us"] for t in totals.values())      # headline: in context (falls back to the plain chains level by level)
+    # HEADLINE = the chains of the launches themselves (a duration per launch).  The "marginal" figure -- chain of [conv3x3_h2 ; level]
+    # minus the chain of the convolutions -- is what a level ADDS to a matrix-bound neighbour: it is a difference of two chains, not a
+    # duration (a small launch starts under the neighbour's tail: the difference can be ~0 or negative), so it is reported as a
+    # diagnostic of the forward's clock / power state only and no bandwidth is derived from it.
+    us = sum(t["us"] for t in totals.values())
+    us_marginal = sum(t["ctx_us"] for t in totals.values())
     by = sum(t["bytes"] for t in totals.values())
     ach = by / (us * 1e-6) / 1e9
     for lv in per_level.values():
-        u = lv["us_in_context"] if lv["us_in_context"] is not None else lv["us_chain"]
-        lv["frac_in_context"] = (lv["algorithmic_bytes"] / (u * 1e-6) / 1e9 / PEAK_HBM_GBS) if u else None
-        lv["frac_alone"] = (lv["algorithmic_bytes"] / (lv["us_chain"] * 1e-6) / 1e9 / PEAK_HBM_GBS) if lv["us_chain"] else None
+        lv["us_marginal_behind_conv"] = lv.pop("us_in_context")
+        lv["frac"] = (lv["algorithmic_bytes"] / (lv["us_chain"] * 1e-6) / 1e9 / PEAK_HBM_GBS) if lv["us_chain"] else None
     return {"kernel": "+".join(totals), "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": ach / PEAK_HBM_GBS, "traffic": None,
             "us_per_forward": us,
-            "headline": "in context: every level's launches timed right behind a matrix-bound launch (chain of [conv3x3_h2 128 -> 128 ; "
-                        "level] minus the chain of the convolutions alone) -- the clock and power state the forward runs them in",
+            "headline": "chains of each level's production launches over rotating operand sets (graph replay, one event pair "
+                        "around the chain): a duration per launch",
             "neighbour_conv_us": conv_us,
-            "us_per_forward_alone": us_alone, "achieved_alone": by / (us_alone * 1e-6) / 1e9,
-            "frac_alone": by / (us_alone * 1e-6) / 1e9 / PEAK_HBM_GBS,
+            "us_per_forward_marginal_behind_conv": us_marginal,
+            "marginal_note": "chain of [conv3x3_h2 128 -> 128 ; level] minus the chain of the convolutions alone: what a level adds "
+                             "behind a matrix-bound launch in the forward's clock / power state; a difference, not a duration (small "
+                             "launches start under the neighbour's tail) -- no bandwidth is derived from it",
             "us_per_forward_event_pairs": sum(t["ev_us"] for t in totals.values()),
             "algorithmic_bytes_per_forward": by,
             "per_kernel": {k: {"avg_us": t["us"] / t["launches"], "avg_us_event_pair": t["ev_us"] / t["launches"],
-                               "avg_us_in_context": t["ctx_us"] / t["launches"],
+                               "marginal_us_behind_conv": t["ctx_us"] / t["launches"],
                                "gbs": t["bytes"] / (t["us"] * 1e-6) / 1e9,
                                "launches_per_forward": t["launches"]} for k, t in totals.items()},
             "per_level": per_level,

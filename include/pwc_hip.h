@@ -135,7 +135,9 @@ int pwc_warp_cost_volume_concat_supported(int H, int W, int C, int search_range,
  * three v_mfma_f32_16x16x32_f16 per (4x4-pixel block pair, 32 channels), fp32 accumulation -- 27 matrix instructions per
  * block where the fp32 form has 72 twice as long, and none of them stalls the vector instructions of its SIMD.  Error
  * against float64: not larger than the fp32 form's (tests).  RANGE: features below 65504 in magnitude (beyond: NaN
- * outputs, see PWC_STATUS_NONFINITE).  Same support set as the fp32 form. */
+ * outputs, see PWC_STATUS_NONFINITE).  Same support set as the fp32 form.  Round 6: out_pad_writable = 2 (flow != NULL) puts
+ * the pixel's flow (x, y), as read, into channels 81, 82 of its record and zero into channel 83: the record is then
+ * [cv | flows_up_prev | 0] of the estimator's input (see pwc_conv3x3_h2_ex3_f32). */
 int pwc_warp_cost_volume_concat_h2_f32(const float* f0, int f0_cs, const float* f1, int f1_cs,
                                        const float* flow, int flow_cs, float flow_scale,
                                        float* out, int out_cs, int out_pad_writable,
@@ -295,6 +297,19 @@ int pwc_conv3x3_h2_ex_f32(const float* x, int x_cs, int Cin_a_phys, const float*
                           const float* packed_w, const float* bias, float* y, int y_cs, int N, int H, int W,
                           int Cin_phys, int Cout, int dilation, int apply_act, float slope, float* workspace,
                           size_t workspace_floats, uint32_t* status, pwc_stream_t stream);
+/* Round 6: the input channels as THREE tensors over the same pixels (dilation 1): physical channels [0, Cin_a_phys) from x, the
+ * next Cin_b_phys from x2, the remaining Cin_phys - Cin_a_phys - Cin_b_phys from x3 (Cin_a_phys, Cin_b_phys % 16 == 0; x2, x3
+ * 16-byte aligned, strides % 4 == 0).  An operand's channel stride may be up to 12 channels SHORT of its 16-channel stage count
+ * (x_cs = 84 with Cin_a_phys = 96): its last stage then reads the first channels of the NEXT pixel's record (zeros behind an
+ * image's last pixel), which must hold finite values, and the caller packs zero weights for those channels (cin_map = -1).
+ * With it `tf.concat([cv, features_0, flows_up_prev, features_up_prev])` (reference modules.py:261-264) is three tensors that
+ * their producers write DENSELY: [cv 81 | flows_up_prev 2 | 0] in 336-byte records (pwc_warp_cost_volume_concat_h2_f32 with
+ * out_pad_writable = 2), features_0 in the pyramid tensor, features_up_prev as a 32-channel tensor -- no producer writes a slice
+ * of a wider record.  The logical channel order of the concat lives in the packed weights. */
+int pwc_conv3x3_h2_ex3_f32(const float* x, int x_cs, int Cin_a_phys, const float* x2, int x2_cs, int Cin_b_phys,
+                           const float* x3, int x3_cs, const float* packed_w, const float* bias, float* y, int y_cs,
+                           int N, int H, int W, int Cin_phys, int Cout, int apply_act, float slope, float* workspace,
+                           size_t workspace_floats, uint32_t* status, pwc_stream_t stream);
 /* TWO chained 3x3 stride-1 'SAME' convolutions of 16 channels each (16 -> 16 -> 16) with a leaky-relu of slope `slope`
  * behind each, in one launch (csrc/conv3x3_c16pair.hip; reference modules.py:62-67, the `fp_extractor/conv2d_1`,
  * `conv2d_2` pair of pyramid level 1): the intermediate stays in LDS instead of making a round trip through memory.

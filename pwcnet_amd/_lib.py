@@ -61,6 +61,7 @@ SIGNATURES = {
     "pwc_conv3x3_h2_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pwc_conv3x3_h2_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "pwc_conv3x3_h2_ex_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp]),
+    "pwc_conv3x3_h2_ex3_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp]),
     "pwc_conv3x3_h2_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "pwc_conv3x3_h2_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "pwc_conv3x3_h2_plan": (_i, [_i, _i, _i, _i, _i, _i]),

@@ -389,18 +389,29 @@ __global__ __launch_bounds__(256) void conv3x3_head2_mfma_kernel(const DirectArg
         }
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.x + (size_t)n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
-    for (int g = wave; g < HM_NG; g += 4) {
-        const int j = g * 16 + fr;
+    // Round 6: ALL of the wave's pixel groups are requested before the first one is used (12 16-byte loads per lane in flight).  The
+    // loop this replaces asked for one group, waited, multiplied, stored, and asked for the next: six memory round trips in
+    // series per workgroup -- the "15 us even on warm operands" of rounds 3-5 was that chain, not the launch.
+    constexpr int GPW = (HM_NG + 3) / 4;                     // groups per wave
+    f32x4 lo[GPW], hi[GPW];
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+        const int j = (wave + 4 * gi) * 16 + fr;
         const int py = j / HM_PW, px = j - py * HM_PW;
         const int yy = y0 - 1 + py, xx = x0 - 1 + px;
-        const bool ok = j < HM_NP && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        const bool ok = wave + 4 * gi < HM_NG && j < HM_NP && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
         const int vo = ok ? ((yy * a.W + xx) * a.x_cs + 8 * kq) * 4 : (int)C3M_OOB;
-        const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, vo, 0, 0));
-        const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, vo, 16, 0));
+        lo[gi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, vo, 0, 0));
+        hi[gi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, vo, 16, 0));
+    }
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+        if (wave + 4 * gi >= HM_NG) break;                   // uniform
+        const int j = (wave + 4 * gi) * 16 + fr;
         f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = z0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float xv = i < 4 ? lo[i & 3] : hi[i & 3];
+            const float xv = i < 4 ? lo[gi][i & 3] : hi[gi][i & 3];
             z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0][i], xv, z0, 0, 0, 0);
             z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][i], xv, z1, 0, 0, 0);
         }

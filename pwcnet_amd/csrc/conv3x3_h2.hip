@@ -89,6 +89,13 @@ struct H2Args {
     // straight from the pyramid tensor: the concat copy of reference modules.py:264 does not exist.  x2 = null: all of x.
     const float* x2;
     int x2_cs, nc16_a;
+    // round 6: a THIRD tensor -- stages c16 >= nc16_a + nc16_b are channels [16 (c16 - nc16_a - nc16_b), ...) of x3 (null: none).
+    // The estimator's first layer then reads [cv | flow] (a dense tensor of 84-channel records), features_0 (the pyramid tensor)
+    // and features_up (a dense 32-channel tensor): no producer writes into a slice of a wider record any more.  An operand whose
+    // channel stride is below its stage count x 16 (84 < 96) lets its LAST stage run into the next pixel's record (beyond the
+    // image: zeros); the packed weights of those channels are zero (cin_map = -1).
+    const float* x3;
+    int x3_cs, nc16_b;
     // round 5: caller-owned status words (null: none): PWC_STATUS_STREAMK_TIMEOUT is OR-ed into [0] when a bounded wait runs out.
     // (The RANGE of the split is not watched here: tracking the largest operand in the split cost every launch 2-3 %
     // (profiles/r05_timeline_range_tracking_cost.txt).  An operand beyond fp16's range makes NaN outputs, NaN survives every later
@@ -203,13 +210,28 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     // tensor a stage reads from when the piece is issued: one v_mad per piece instead of a second set of offsets)
     unsigned p_pix[C::PPW];
     const unsigned p_q16 = (unsigned)(lane & 3) * 16u;
-    __amdgpu_buffer_rsrc_t xrsrc, xrsrc2;
-    const bool two = a.x2 != nullptr;                      // uniform
+    // ONE buffer resource: the tensor (x, x2 or x3) the stages being fetched come from, re-made where the stage sequence enters
+    // another operand or another tile (select_operand; uniform, a few scalar instructions, two or three times per tile).  Round 5
+    // kept one resource per operand and selected per fetch; a third one does not fit: the kernel already spills ~130 SGPRs into
+    // VGPR lanes, six more pushed the 128-cout variants over 256 VGPRs into scratch (2 x slower).
+    __amdgpu_buffer_rsrc_t xrsrc;
+    unsigned x_cs4 = 0;                                    // channel stride of that tensor, bytes
+    int x_c0 = 0;                                          // its first stage
+    auto select_operand = [&](const Tile& tl, int c16) {
+        if constexpr (!S2) {
+            const float* base = a.x;
+            int cs = a.x_cs, c0 = 0;
+            if (c16 >= a.nc16_a + a.nc16_b) { base = a.x3; cs = a.x3_cs; c0 = a.nc16_a + a.nc16_b; }     // (nc16_b = the rest without an x3)
+            else if (c16 >= a.nc16_a) { base = a.x2; cs = a.x2_cs; c0 = a.nc16_a; }
+            xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)tl.n * a.H * a.W * cs), 0, a.H * a.W * cs * 4, 0x00020000);
+            x_cs4 = (unsigned)cs * 4u;
+            x_c0 = c0;
+        }
+    };
     auto patch_tile = [&](const Tile& tl) {
         const int y0 = tl.by * C::TR, x0 = tl.bx * 32;      // output origin of the tile, in sub-lattice coordinates
-        xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)tl.n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
-        xrsrc2 = __builtin_amdgcn_make_buffer_rsrc((void*)(two ? a.x2 + (size_t)tl.n * a.H * a.W * a.x2_cs : a.x), 0,
-                                                   two ? a.H * a.W * a.x2_cs * 4 : 0, 0x00020000);
+        if constexpr (S2)                                   // (one operand: the resource changes with the tile only)
+            xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)tl.n * a.H * a.W * a.x_cs), 0, a.H * a.W * a.x_cs * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < C::PPW; ++i) {
             const int rec = (wave + 8 * i) * 16 + (lane >> 2);
@@ -223,18 +245,17 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     auto issue_patch_piece = [&](int i, int c16) {
         if (ABL & 1) return;
         // (locals: see issue_w_piece)
-        const bool second = !S2 && c16 >= a.nc16_a;        // uniform
         // S2: stage = parity * (channel groups) + channel group -- the 16-channel groups that share a 128-byte line of a pixel are
         // consecutive stages; the same pixel of parity plane (a, b).  (H and W are even: a pixel of plane (0, 0) inside the image
         // has its three neighbours inside too; the marker H W of a pixel outside stays out of range.)
         const int ncc = nc16 >> 2, par = S2 ? c16 / ncc : 0, cc = S2 ? c16 - par * ncc : 0;
-        const int soff = S2 ? cc * 64 : (second ? c16 - a.nc16_a : c16) * 64;
+        const int soff = S2 ? cc * 64 : (c16 - x_c0) * 64;
         const unsigned ppix = S2 ? p_pix[i] + (unsigned)((par >> 1) * a.W + (par & 1)) : p_pix[i];
-        const int voff = (int)(ppix * (unsigned)((second ? a.x2_cs : a.x_cs) * 4) + p_q16);
+        const int voff = (int)(ppix * (S2 ? (unsigned)(a.x_cs * 4) : x_cs4) + p_q16);
         lptr_t dst = (lptr_t)(sm + C::S0 + (wave + 8 * i) * 1024);
-        // ONE fetch instruction on a selected resource (scalar selects), not one per branch: the compiler counts outstanding
-        // fetches along every path, and two paths made its waits conservative (+3-4 % on every launch)
-        const __amdgpu_buffer_rsrc_t rs = second ? xrsrc2 : xrsrc;
+        // ONE fetch instruction on ONE resource (not one per branch: the compiler counts outstanding fetches along every path, and
+        // two paths made its waits conservative, +3-4 % on every launch)
+        const __amdgpu_buffer_rsrc_t rs = xrsrc;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, soff, 0, 0);
     };
     // ---- weights of part (c16, r) for cout block cb: NCT cout tiles x 3 taps x 2 KB, contiguous in the packed image; pieces wave,
@@ -449,6 +470,7 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
 
     // ---- prologue: patch g0, parts (g0, 0) and (g0, 1); split patch g0; patch g0 + 1
     patch_tile(tcur);
+    select_operand(tcur, c16);
 #pragma unroll
     for (int i = 0; i < C::PPW; ++i) issue_patch_piece(i, c16);
 #pragma unroll
@@ -462,6 +484,7 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
     H2_BAR();
     if (g0 + 1 < g1) {
         if (c1 == 0) patch_tile(t1);
+        select_operand(t1, c1);
 #pragma unroll
         for (int i = 0; i < C::PPW; ++i) issue_patch_piece(i, c1);
     }
@@ -497,6 +520,9 @@ __global__ __launch_bounds__(512) void conv3x3_h2_kernel(const H2Args a) {
         constexpr int NSLOT = NMU > NL + NEX ? NMU : NL + NEX;
         f32x4 cvv[3];
         if (do_p && c2 == 0) patch_tile(t2);
+        if constexpr (!S2) {
+            if (do_p && (c2 == 0 || c2 == a.nc16_a || c2 == a.nc16_a + a.nc16_b)) select_operand(t2, c2);    // (another tile or operand)
+        }
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
             if (i < NMU) mfma_i(cur, i, fresh);
@@ -799,12 +825,23 @@ template <int ABL = 0>
 static int h2_run(const float* x, int x_cs, const float* packed_w, const float* bias, float* y, int y_cs, int N, int H, int W,
                   int Cin_phys, int Cout, int dilation, int apply_act, float slope, pwc_stream_t stream, int variant = 0,
                   float* workspace = nullptr, size_t workspace_floats = 0, int stride = 1, const float* x2 = nullptr, int x2_cs = 0,
-                  int Cin_a_phys = 0, uint32_t* status = nullptr) {
+                  int Cin_a_phys = 0, uint32_t* status = nullptr, const float* x3 = nullptr, int x3_cs = 0, int Cin_b_phys = 0) {
     if (!x || !packed_w || !bias || !y) return PWC_EINVAL;
+    if (x3 && !x2) return PWC_EINVAL;
     if (x2) {
-        if (Cin_a_phys <= 0 || Cin_a_phys >= Cin_phys || (Cin_a_phys % 16) || x_cs < Cin_a_phys || x2_cs < Cin_phys - Cin_a_phys) return PWC_EINVAL;
+        // (three operands: an operand's channel stride may be up to 12 channels short of its stage count x 16 -- its last stage then
+        // runs into the next pixel's record, see H2Args::x3)
+        const int slack = x3 ? 12 : 0;
+        const int cb = x3 ? Cin_b_phys : Cin_phys - Cin_a_phys;
+        if (Cin_a_phys <= 0 || Cin_a_phys >= Cin_phys || (Cin_a_phys % 16) || x_cs < Cin_a_phys - slack || x2_cs < cb - slack) return PWC_EINVAL;
         if ((x2_cs & 3) || !pwc_aligned16(x2)) return PWC_EALIGN;
         if ((long)H * W * x2_cs * 4 >= (long)H2_OOB) return PWC_ERANGE;
+    }
+    if (x3) {
+        const int cc = Cin_phys - Cin_a_phys - Cin_b_phys;
+        if (Cin_b_phys <= 0 || (Cin_b_phys % 16) || cc <= 0 || x3_cs < cc - 12 || dilation != 1) return PWC_EINVAL;
+        if ((x3_cs & 3) || !pwc_aligned16(x3)) return PWC_EALIGN;
+        if ((long)H * W * x3_cs * 4 >= (long)H2_OOB) return PWC_ERANGE;
     }
     if (reinterpret_cast<uintptr_t>(status) & 7u) return PWC_EALIGN;
     if (N <= 0 || H <= 0 || W <= 0 || Cin_phys <= 0 || Cout <= 0 || dilation < 1 || (stride != 1 && stride != 2)) return PWC_EINVAL;
@@ -825,6 +862,7 @@ static int h2_run(const float* x, int x_cs, const float* packed_w, const float* 
     a.dil_y = geo.dy; a.dil_x = geo.dx;
     a.dbg = h2_debug_counters;
     a.x2 = x2; a.x2_cs = x2_cs; a.nc16_a = x2 ? Cin_a_phys >> 4 : a.Cin_phys >> 4; a.status = status;
+    a.x3 = x3; a.x3_cs = x3_cs; a.nc16_b = x3 ? Cin_b_phys >> 4 : (a.Cin_phys >> 4) - a.nc16_a;
     const int hs = geo.hs, ws = geo.ws;
     if (variant == 0) variant = h2_plan(N, a.Ho, a.Wo, a.Cin_phys, Cout, dilation, nullptr);
     if (variant < 1 || variant > 5) return PWC_EUNSUPPORTED;
@@ -881,6 +919,20 @@ extern "C" int pwc_conv3x3_h2_ex_f32(const float* x, int x_cs, int Cin_a_phys, c
                                      size_t workspace_floats, uint32_t* status, pwc_stream_t stream) {
     return h2_run<0>(x, x_cs, packed_w, bias, y, y_cs, N, H, W, Cin_phys, Cout, dilation, apply_act, slope, stream, 0,
                      workspace, workspace_floats, 1, x2, x2_cs, Cin_a_phys, status);
+}
+
+// Round 6: the input channels as THREE tensors over the same pixel grid: physical channels [0, Cin_a_phys) from x, the next
+// Cin_b_phys from x2, the rest from x3 (Cin_a_phys, Cin_b_phys multiples of 16; dilation 1).  A channel stride may be up to 12
+// channels SHORT of the operand's stage count x 16 (x_cs = 84 with Cin_a_phys = 96): the operand's last 16-channel stage then
+// reads the first channels of the NEXT pixel's record (zeros behind the image's last pixel) and the caller's packed weights are
+// zero there (cin_map = -1).  That is what makes a dense [cost volume 81 | flow 2 | 0] tensor of 336-byte records an operand.
+extern "C" int pwc_conv3x3_h2_ex3_f32(const float* x, int x_cs, int Cin_a_phys, const float* x2, int x2_cs, int Cin_b_phys,
+                                      const float* x3, int x3_cs, const float* packed_w, const float* bias, float* y, int y_cs,
+                                      int N, int H, int W, int Cin_phys, int Cout, int apply_act, float slope, float* workspace,
+                                      size_t workspace_floats, uint32_t* status, pwc_stream_t stream) {
+    if (!x2 || !x3) return PWC_EINVAL;
+    return h2_run<0>(x, x_cs, packed_w, bias, y, y_cs, N, H, W, Cin_phys, Cout, 1, apply_act, slope, stream, 0,
+                     workspace, workspace_floats, 1, x2, x2_cs, Cin_a_phys, status, x3, x3_cs, Cin_b_phys);
 }
 
 // Stride 2 ('SAME', dilation 1, even H and W: the extractor's down-sampling layers, reference modules.py:57-60): the kernel's S2

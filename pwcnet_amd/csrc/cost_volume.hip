@@ -788,6 +788,7 @@ extern "C" int pwc_warp_cost_volume_concat_f32(const float* f0, int f0_cs, const
     if (rc) return rc;
     if ((flow && flow_cs < 2) || (f0_copy && f0_copy_cs < C)) return PWC_EINVAL;
     if (out_pad_writable && out_cs < 84) return PWC_EINVAL;
+    if (out_pad_writable == 2) return PWC_EUNSUPPORTED;      // (the flow in channels 81, 82: pwc_warp_cost_volume_concat_h2_f32 only)
     if (search_range != 4 || !(C == 32 || C == 64 || C == 96)) return PWC_EUNSUPPORTED;
     if (!cvm_eligible(f0, f0_cs, f1, f1_cs, flow, flow_cs, out, out_cs, f0_copy, f0_copy_cs, H, W, C, search_range))
         return ((long)H * W * (long)(out_cs > f0_cs ? out_cs : f0_cs) * 4 >= (1L << 31)) ? PWC_ERANGE : PWC_EALIGN;
@@ -809,8 +810,11 @@ extern "C" int pwc_warp_cost_volume_concat_h2_f32(const float* f0, int f0_cs, co
     if (search_range != 4 || !(C == 32 || C == 64 || C == 96)) return PWC_EUNSUPPORTED;
     if (!cvm_eligible(f0, f0_cs, f1, f1_cs, flow, flow_cs, out, out_cs, f0_copy, f0_copy_cs, H, W, C, search_range))
         return ((long)H * W * (long)(out_cs > f0_cs ? out_cs : f0_cs) * 4 >= (1L << 31)) ? PWC_ERANGE : PWC_EALIGN;
-    return cvh_launch(f0, f0_cs, f1, f1_cs, flow, flow_cs, flow_scale, out, out_cs, out_pad_writable ? 1 : 0, f0_copy,
-                      f0_copy_cs, N, H, W, C, slope, (hipStream_t)stream);
+    // out_pad_writable == 2 (round 6): channels 81, 82 of every record receive the pixel's flow (cost_volume_h2.hip, FLOWPAD)
+    if (out_pad_writable == 2 && !flow) return PWC_EINVAL;
+    return cvh_launch(f0, f0_cs, f1, f1_cs, flow, flow_cs, flow_scale, out, out_cs,
+                      out_pad_writable == 2 ? 2 : (out_pad_writable ? 1 : 0), f0_copy, f0_copy_cs, N, H, W, C, slope,
+                      (hipStream_t)stream);
 }
 
 // Round 5: the same operation for the small pyramid levels (C = 96 / 128 / 192): one 4 x 4 block per workgroup, the whole
@@ -835,6 +839,7 @@ extern "C" int pwc_warp_cost_volume_concat_blk_f32(const float* f0, int f0_cs, c
     if (rc) return rc;
     if ((flow && flow_cs < 2) || (f0_copy && f0_copy_cs < C)) return PWC_EINVAL;
     if (out_pad_writable && out_cs < 84) return PWC_EINVAL;
+    if (out_pad_writable == 2) return PWC_EUNSUPPORTED;      // (the flow in channels 81, 82: pwc_warp_cost_volume_concat_h2_f32 only)
     if (search_range != 4 || !(C == 64 || C == 96 || C == 128 || C == 192)) return PWC_EUNSUPPORTED;
     if (!cvb_eligible(f0, f0_cs, f1, f1_cs, flow, flow_cs, out, out_cs, f0_copy, f0_copy_cs, H, W, C, search_range))
         return ((long)H * W * (long)(out_cs > f0_cs ? out_cs : f0_cs) * 4 >= (1L << 31)) ? PWC_ERANGE : PWC_EALIGN;

@@ -54,8 +54,13 @@ struct CvhGeom {
 };
 
 // ABL (scripts/exp_cv5.hip only; 0 in the library): 1 = no MFMAs, 2 = no gather loads, 4 = no stores, 8 = s_memtime stamps
-template <int CG, bool WARP, bool PAD, int ABL = 0>
+// FLOWPAD (round 6; needs WARP and PAD): channels 81, 82 of every `out` record receive the pixel's flow (x, y) as read -- the record
+// is then [cv 81 | flows_up_prev 2 | 0] of the estimator's concat (reference modules.py:261-264: the flow keeps its LOGICAL place
+// behind features_0, the first conv's packed weights follow the physical order), `out` can be a dense tensor of 84-channel records
+// (336 contiguous bytes per pixel: no record-strided writes) and the estimator's first conv reads it as one of three operands.
+template <int CG, bool WARP, bool PAD, int ABL = 0, bool FLOWPAD = false>
 __global__ __launch_bounds__(512, 1) void cost_volume_h2_kernel(const CvmArgs a) {
+    static_assert(!FLOWPAD || (WARP && PAD), "the flow rides in the padding channels of a warping launch");
     using G = CvmGeom<CG>;
     using GH = CvhGeom<CG>;
     constexpr int RS = G::RS, PLANE = G::PLANE, BUF = G::BUF, ITEMS = G::ITEMS, NP = CG / 2;
@@ -119,10 +124,12 @@ __global__ __launch_bounds__(512, 1) void cost_volume_h2_kernel(const CvmArgs a)
 
     // copy-out items: e = i * 64 + lane -> (pixel p = e / 21 of the block, quad e % 21)
     unsigned co_rel[6];
+    unsigned q20 = 0;                                                   // bit i: item i is quad 20 of its pixel (channels 80..83)
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int e = i * 64 + lane;
         const int p = (e * 3121) >> 16, qd = e - p * 21;                // e / 21 for e < 336
+        if (qd == 20) q20 |= 1u << i;
         const bool in = e < 16 * 21 && x0 + 4 * wave + (p & 3) < a.W && (PAD || qd < 20);
         co_rel[i] = in ? (unsigned)((((p >> 2) * a.W + (p & 3)) * a.out_cs + qd * 4) * 4) : CVM_OOB;
     }
@@ -358,6 +365,11 @@ __global__ __launch_bounds__(512, 1) void cost_volume_h2_kernel(const CvmArgs a)
                 asm("v_max_f32 %0, %1, %2" : "=v"(yk) : "v"(mv[k]), "v"(sv[k]));
                 y[k] = yk;
             }
+            if constexpr (FLOWPAD) {                                    // channels 81, 82 carry the flow as read: no mean, no activation
+                const bool f = (q20 >> i) & 1u;
+                y[1] = f ? v[i][1] : y[1];
+                y[2] = f ? v[i][2] : y[2];
+            }
             const bool ok = i * 64 + lane < 84 * ylim && !(ABL & 4);    // 84 items per block row
             const unsigned vo = ok ? base + co_rel[i] : CVM_OOB;        // out-of-range + base stays out of range
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cvm_u32x4, y), ro, (int)vo, 0, CVM_STORE_AUX);
@@ -366,6 +378,21 @@ __global__ __launch_bounds__(512, 1) void cost_volume_h2_kernel(const CvmArgs a)
             const float y = pwc_lrelu(x80 * a.inv_c, a.slope);
             const bool ok = (lane >> 2) < ylim && !(ABL & 4);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), ro, (int)(ok ? base + c80_rel : CVM_OOB), 0, CVM_STORE_AUX);
+        }
+    };
+
+    // ---- FLOWPAD: the flow of the P row's 16 pixels (lanes 0-15: one pixel each), requested a step before its copy-out
+    float flx[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    auto load_flow = [&](float* f, int pb) {
+        const bool ok = lane < 16 && a_in && pb >= pb0 && pb < pb1 && 4 * pb + mrow < a.H;
+        const unsigned vo = ok ? (a_rel + (unsigned)(4 * pb * a.W)) * (unsigned)(a.flow_cs * 4) : CVM_OOB;
+        f[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, (int)vo, 0, 0));
+        f[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, (int)vo, 4, 0));
+    };
+    auto flow_to_stage = [&](const float* f) {
+        if (lane < 16) {
+            stg[lane * G::SROW + 81] = f[0];
+            stg[lane * G::SROW + 82] = f[1];
         }
     };
 
@@ -383,6 +410,7 @@ __global__ __launch_bounds__(512, 1) void cost_volume_h2_kernel(const CvmArgs a)
             const bool real = p >= pb0;                                 // uniform: fill steps compute nothing
             stamp();
             load_A(A2[PAR], p + 2);
+            if constexpr (FLOWPAD) load_flow(flx[PAR], p + 1);
             if (real) {
                 reads(I0{}, s_m);
                 if constexpr (NP == 1) { reads(I1{}, s_0); reads(I2{}, s_p); }
@@ -401,6 +429,8 @@ __global__ __launch_bounds__(512, 1) void cost_volume_h2_kernel(const CvmArgs a)
             }
             stamp();
             split_A(A2[1 - PAR], p + 1);                                // (+ its concat copy: stores)
+            if constexpr (FLOWPAD) flow_to_stage(flx[1 - PAR]);        // (row p's, requested in step p - 1; behind the wave sync above
+                                                                        // when the step is real, nothing reads the stage otherwise)
             stamp();
             cvm_wave_sync();
             // Always executed (rows outside the segment store nothing: out-of-range offsets)
@@ -440,19 +470,19 @@ __global__ __launch_bounds__(512, 1) void cost_volume_h2_kernel(const CvmArgs a)
     }
 }
 
-template <int CG, bool WARP, bool PAD>
+template <int CG, bool WARP, bool PAD, bool FLOWPAD = false>
 static int cvh_launch_t(CvmArgs& a, hipStream_t s) {
     using GH = CvhGeom<CG>;
     const size_t lds = (size_t)GH::LDS_F * sizeof(float);
     static PwcDevOnce attr_once;   // the attribute is per device
     if (pwc_first_on_device(&attr_once)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_volume_h2_kernel<CG, WARP, PAD, 0>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_volume_h2_kernel<CG, WARP, PAD, 0, FLOWPAD>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     cvm_plan(a.N, a.H, a.W, 1, &a.nstrips, &a.nseg, &a.seg_brows);
     const long items = (long)a.N * a.nstrips * a.nseg;
     if (items >= (1L << 31)) return PWC_ERANGE;
-    hipLaunchKernelGGL((cost_volume_h2_kernel<CG, WARP, PAD, 0>), dim3((unsigned)items), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((cost_volume_h2_kernel<CG, WARP, PAD, 0, FLOWPAD>), dim3((unsigned)items), dim3(512), lds, s, a);
     return pwc_launch_status();
 }
 
@@ -468,6 +498,7 @@ static int cvh_launch(const float* f0, int f0_cs, const float* f1, int f1_cs, co
     a.pad_ok = pad_ok; a.dbg = nullptr;
 #define CVH_CASE(CGV)                                                                          \
     case CGV * 16:                                                                             \
+        if (flow && pad_ok == 2) return cvh_launch_t<CGV, true, true, true>(a, s);                                  \
         return flow ? (pad_ok ? cvh_launch_t<CGV, true, true>(a, s) : cvh_launch_t<CGV, true, false>(a, s))         \
                     : (pad_ok ? cvh_launch_t<CGV, false, true>(a, s) : cvh_launch_t<CGV, false, false>(a, s));
     switch (C) {

@@ -146,6 +146,7 @@ class PWCDCNet(object):
         self.range_check = range_check
         self.track_max = bool(track_max)
         self.two_operand = True             # features_0 read from the pyramid tensor where the first conv allows (_est_layout)
+        self.three_operand = True           # round 6: [cv | flow], features_0, features_up as three dense tensors (_level_input)
         self.f16x2 = bool(f16x2)
         self._status = {}                   # device -> [device words, pinned host ring (slots x 2), next slot]
         self._pending = collections.deque() # forwards whose status words nobody has looked at: (event, host slot, inputs, their versions, outputs, device)
@@ -531,8 +532,7 @@ class PWCDCNet(object):
             pyramid_0 = [f[:N] for f in stacked]
 
             flows_pyramid = []
-            fu_map = None          # physical->logical map of the feat_up segment
-            nxt = None             # (buffer tensor, layout) prepared for the current level
+            nxt = None             # the estimator input prepared for the current level (_level_input)
             for l, F in enumerate(stacked):
                 _, h, w, C = F.shape
                 f0 = View(F.data_ptr(), C, N, h, w, C)
@@ -540,21 +540,33 @@ class PWCDCNet(object):
                 est = self.of_estimators[l]
                 is_out = (l == self.output_level)
 
-                if nxt is None:
-                    lay = self._est_layout(l, N, h, w, C, l > 0, fu_map)
-                    E_t, E_off, cx = self._level_buffer(l, lay, N, h, w, dev, is_out)
+                inp = nxt if nxt is not None else self._level_input(l, N, h, w, C, None, dev, is_out)
+                lay, cx = inp["lay"], inp["cx"]
+                if inp["three"]:
+                    # Round 6: [cv | flows_up_prev | 0] as a dense tensor of 84-channel records written by the correlation launch,
+                    # features_0 where it is, features_up_prev as a dense tensor: the first conv takes the three of them
+                    cvx, flow_v, fu_v = inp["cvx"], inp["flow"], inp["feat_up"]
+                    self.cv_layer._run(f0, f1, View(cvx.ptr, cvx.cs, N, h, w, (2 * self.s_range + 1) ** 2), flow=flow_v,
+                                       flow_scale=self.scales[l], concat=True, out_pad_writable=2)
+                    E = None
                 else:
-                    E_t, E_off, lay, cx = nxt
-                E = View(E_t.data_ptr() + 4 * E_off, E_t.shape[3], N, h, w, lay.n_phys)
+                    E_t, E_off = inp["E_t"], inp["E_off"]
+                    E = View(E_t.data_ptr() + 4 * E_off, E_t.shape[3], N, h, w, lay.n_phys)
+                    # Warping + cost volume (model.py:105-112).  features_0 either has its segment of the estimator buffer (the
+                    # correlation launch copies it there) or stays where it is: the first conv then reads it from the pyramid
+                    # tensor (_est_layout)
+                    f0_ext = f0 if "f0" in lay.external else None
+                    cv_out = sub_view(E, lay.offset("cv"), (2 * self.s_range + 1) ** 2)
+                    f0_dst = sub_view(E, lay.offset("f0"), C) if f0_ext is None else None
+                    flow_v = sub_view(E, lay.offset("flow"), 2) if l > 0 else None
+                    self._corr_level(l, f0, f1, flow_v, cv_out, f0_dst, E, dev)
 
-                # Warping + cost volume (model.py:105-112).  features_0 either has its segment of the estimator buffer (the
-                # correlation launch copies it there) or stays where it is: the first conv then reads it from the pyramid
-                # tensor (_est_layout)
-                f0_ext = f0 if "f0" in lay.external else None
-                cv_out = sub_view(E, lay.offset("cv"), (2 * self.s_range + 1) ** 2)
-                f0_dst = sub_view(E, lay.offset("f0"), C) if f0_ext is None else None
-                flow_v = sub_view(E, lay.offset("flow"), 2) if l > 0 else None
-                self._corr_level(l, f0, f1, flow_v, cv_out, f0_dst, E, dev)
+                def run_est(flows_out, feat_out=None):
+                    if inp["three"]:
+                        return est._run3(cvx, f0, fu_v, flow_v, flows_out, feat_out=feat_out)
+                    if self.use_dc:
+                        return est._run(E, lay, flows_out)
+                    return est._run(E, lay, flows_out, feat_out=feat_out, f0_ext=f0_ext)
 
                 flows_t = torch.empty((N, h, w, 2), dtype=torch.float32, device=dev)
                 _keep(flows_t)
@@ -563,25 +575,20 @@ class PWCDCNet(object):
                     # Optical flow estimation + x2 upsampling into the next level's buffer
                     # (model.py:114-116, modules.py:282-285)
                     if self.use_dc:
-                        est._run(E, lay, flows_v)
+                        run_est(flows_v)
                         feat_v, nfu = View(E.ptr, E.cs, N, h, w, lay.n_phys), list(lay.phys2log)
                     else:
-                        feat_v, _feat_t = est._run(E, lay, flows_v, f0_ext=f0_ext)
+                        feat_v, _feat_t = run_est(flows_v)
                         nfu = list(range(feat_v.C))
                     Fn = stacked[l + 1]
                     _, h2, w2, C2 = Fn.shape
                     assert (h2, w2) == (2 * h, 2 * w), "pyramid levels must double in size"
-                    nlay = self._est_layout(l + 1, N, h2, w2, C2, True, nfu)
-                    nE_t, nE_off, ncx = self._level_buffer(l + 1, nlay, N, h2, w2, dev,
-                                                           l + 1 == self.output_level)
-                    nE = View(nE_t.data_ptr() + 4 * nE_off, nE_t.shape[3], N, h2, w2, nlay.n_phys)
-                    if feat_v.C % 4 == 0 and feat_v.cs % 4 == 0 and nE.cs % 4 == 0:
-                        _m._resize_pair(flows_v, sub_view(nE, nlay.offset("flow"), 2),
-                                        feat_v, sub_view(nE, nlay.offset("feat_up"), feat_v.C))
+                    nxt = self._level_input(l + 1, N, h2, w2, C2, nfu, dev, l + 1 == self.output_level)
+                    if feat_v.C % 4 == 0 and feat_v.cs % 4 == 0 and nxt["feat_up"].cs % 4 == 0:
+                        _m._resize_pair(flows_v, nxt["flow"], feat_v, nxt["feat_up"])
                     else:
-                        _resize(flows_v, sub_view(nE, nlay.offset("flow"), 2))
-                        _resize(feat_v, sub_view(nE, nlay.offset("feat_up"), feat_v.C))
-                    nxt = (nE_t, nE_off, nlay, ncx)
+                        _resize(flows_v, nxt["flow"])
+                        _resize(feat_v, nxt["feat_up"])
                     flows_pyramid.append(flows_t)
                     continue
 
@@ -590,10 +597,9 @@ class PWCDCNet(object):
                 CX = View(cx_t.data_ptr(), cx_lay.n_phys, N, h, w, cx_lay.n_phys)
                 ctx_flow = sub_view(CX, cx_lay.offset("flow"), 2)
                 if self.use_dc:
-                    est._run(E, lay, ctx_flow)
+                    run_est(ctx_flow)
                 else:
-                    est._run(E, lay, ctx_flow,
-                             feat_out=sub_view(CX, cx_lay.offset("features"), est.filters[-1]), f0_ext=f0_ext)
+                    run_est(ctx_flow, feat_out=sub_view(CX, cx_lay.offset("features"), est.filters[-1]))
                 self.context._run(CX, cx_lay, flows_v)
                 flows_pyramid.append(flows_t)
                 upscale = 2 ** (self.num_levels - self.output_level)
@@ -606,6 +612,54 @@ class PWCDCNet(object):
                     return flows_final, flows_pyramid, pyramid_0
                 else:
                     return flows_final, flows_pyramid
+
+    def _level_input(self, l, N, h, w, C, fu_map, dev, is_out):
+        """The estimator input of level l (fu_map: physical -> logical map of features_up_prev, None at level 0): a dict with
+        the buffers and Views the level's launches use.  "three" (round 6, _three_operand_level): three dense tensors -- `cvx`
+        ([cv | flow | 0] records, written by the correlation launch), features_0 in the pyramid tensor, `feat_up`; `flow` is a
+        2-channel tensor of its own.  Otherwise ONE zero-initialised buffer with a ChannelLayout (`lay`), `flow` and `feat_up`
+        being its segments.  `flow` / `feat_up` are where the previous level's x2 up-sampling writes."""
+        has_flow = l > 0
+        cvc = (2 * self.s_range + 1) ** 2
+        if has_flow and self._three_operand_level(l, N, h, w, C, fu_map):
+            est = self.of_estimators[l]
+            cvx_t = self._zeros(f"cvx{l}", (N, h, w, est.CVX_CS), dev)
+            flow_t = self._zeros(f"flowup{l}", (N, h, w, 2), dev)
+            fu_t = self._zeros(f"featup{l}", (N, h, w, len(fu_map)), dev)
+            cx = None
+            if is_out:                      # the context network's [flows | features] buffer (modules.py:305)
+                cx_lay = ChannelLayout()
+                cx_lay.add("flow", 2)
+                cx_lay.add("features", est.filters[-1])
+                cx_lay.finish(16)
+                cx = (self._zeros(f"ctx{l}", (N, h, w, cx_lay.n_phys), dev), cx_lay)
+            return {"three": True, "lay": None, "cx": cx,
+                    "cvx": View(cvx_t.data_ptr(), est.CVX_CS, N, h, w, 96),
+                    "flow": View(flow_t.data_ptr(), 2, N, h, w, 2),
+                    "feat_up": View(fu_t.data_ptr(), len(fu_map), N, h, w, len(fu_map))}
+        lay = self._est_layout(l, N, h, w, C, has_flow, fu_map)
+        E_t, E_off, cx = self._level_buffer(l, lay, N, h, w, dev, is_out)
+        E = View(E_t.data_ptr() + 4 * E_off, E_t.shape[3], N, h, w, lay.n_phys)
+        return {"three": False, "lay": lay, "cx": cx, "E_t": E_t, "E_off": E_off,
+                "flow": sub_view(E, lay.offset("flow"), 2) if has_flow else None,
+                "feat_up": sub_view(E, lay.offset("feat_up"), len(fu_map)) if has_flow else None}
+
+    def _three_operand_level(self, l, N, h, w, C, fu_map):
+        """True where level l runs on the three-tensor estimator input: non-DC, bilinear warp, the row-walking F16-pipe
+        correlation kernel takes the level (not the block-per-workgroup one of the small levels) and the first conv goes to
+        the F16-pipe kernel at the stage count of that input."""
+        if not (self.three_operand and self.two_operand and self.f16x2 and not self.use_dc and self.concat_cv
+                and self.warp_type == "bilinear" and self.s_range == 4 and fu_map is not None
+                and list(fu_map) == list(range(len(fu_map)))):
+            return False
+        est = self.of_estimators[l]
+        al = 16      # (any aligned address: the tensors are torch allocations)
+        f0 = View(al, C, N, h, w, C)
+        out = View(al, est.CVX_CS, N, h, w, 81)
+        flow = View(al, 2, N, h, w, 2)
+        if self.coarse_cv and (self.cv_layer.blk_ok(f0, f0, out, flow=flow) or self.cv_layer.coarse_ok(f0)):
+            return False
+        return self.cv_layer.concat_ok(f0, f0, out, flow=flow) and est.three_operand_ok(N, h, w, 81, C, len(fu_map))
 
     def _est_layout(self, l, N, h, w, C, has_flow, fu_map):
         """Layout of the estimator buffer of level l.  Where the first conv of the (non-DC) estimator runs on the F16-pipe

@@ -308,10 +308,12 @@ class _ConvRunner:
         return y, y_t
 
     def conv(self, x, cout, y=None, stride=1, dilation=1, slope=0.1, cin_map=None,
-             cin_logical=None, residual=None, tile=-1, split=0, x2=None):
+             cin_logical=None, residual=None, tile=-1, split=0, x2=None, x3=None):
         """x: View over the PHYSICAL input channels.  cin_map: physical->logical map (or
         None = identity).  x2 (round 5): a second View over the same pixels whose channels follow x's in the physical order
-        (cin_map covers both) -- only the F16-pipe kernel takes it: the caller asks h2_two_operand_ok first.
+        (cin_map covers both) -- only the F16-pipe kernel takes it: the caller asks h2_two_operand_ok first.  x3 (round 6): a
+        third one (pwc_conv3x3_h2_ex3_f32); a View's C is then its 16-channel stage count x 16 and may exceed its channel
+        stride by up to 12 (the last stage runs into the next pixel's record; cin_map = -1 there).
         Returns (View y, tensor or None)."""
         name = self.scope + "/conv2d" + ("" if self.k == 0 else f"_{self.k}")
         self.k += 1
@@ -328,7 +330,8 @@ class _ConvRunner:
         s = _lib.current_stream()
         act = 0 if slope is None else 1
         sl = 0.0 if slope is None else float(slope)
-        c_phys = x.C + (x2.C if x2 is not None else 0)
+        assert x3 is None or x2 is not None
+        c_phys = x.C + (x2.C if x2 is not None else 0) + (x3.C if x3 is not None else 0)
         use_mfma = (cout % 16 == 0 and x.C % 16 == 0 and x.cs % 4 == 0 and x.ptr % 16 == 0
                     and residual is None)
         cache = self.owner._cache
@@ -337,8 +340,16 @@ class _ConvRunner:
         use_wino4 = (use_wino and getattr(self.owner, "winograd4", True) and y.cs % 4 == 0 and y.ptr % 16 == 0
                      and L.pwc_conv3x3_wino4_supported(x.N, x.H, x.W, x.C, cout, dilation))
         use_h2 = (use_mfma and getattr(self.owner, "f16x2", True) and stride == 1 and tile < 0 and split == 0
+                  and (x3 is None or dilation == 1)
                   and cout % 32 == 0 and y.cs % 4 == 0 and y.ptr % 16 == 0
                   and L.pwc_conv3x3_h2_supported(x.N, x.H, x.W, c_phys, cout, dilation))
+        # (experiment switch, scripts/exp_ab_model.py h2_relaxed: the F16-pipe kernel wherever it HAS a plan, also below the
+        # tile count its _supported asks for)
+        if (not use_h2 and getattr(self.owner, "h2_relaxed", False) and use_mfma and getattr(self.owner, "f16x2", True)
+                and stride == 1 and dilation == 1 and tile < 0 and split == 0 and cout % 32 == 0 and c_phys >= 32
+                and y.cs % 4 == 0 and y.ptr % 16 == 0 and x.H >= 7 and x.W >= 24
+                and L.pwc_conv3x3_h2_plan(x.N, x.H, x.W, c_phys, cout, 1) != 0):
+            use_h2 = True
         # small launches (round 5): the K dimension dealt to the waves of one workgroup, ONE dispatch (conv3x3_sk.hip)
         use_sk = (use_mfma and getattr(self.owner, "f16x2", True) and getattr(self.owner, "small_conv", True) and x2 is None
                   and tile < 0 and split == 0 and x.C % 32 == 0 and y.cs % 4 == 0 and y.ptr % 16 == 0
@@ -449,10 +460,15 @@ class _ConvRunner:
             status = getattr(self.owner, "status", None)      # the model's status words (stream-K timeout)
             if status is not None:
                 _keep(status)
-            _track_max(self.owner, x)
-            if x2 is not None:
-                _track_max(self.owner, x2)
-            if use_h2:
+            for v in (x, x2, x3):
+                if v is not None:
+                    _track_max(self.owner, v._replace(C=min(v.C, v.cs)))
+            if use_h2 and x3 is not None:
+                fn = L.pwc_conv3x3_h2_ex3_f32
+                args = (_p(x.ptr), x.cs, x.C, _p(x2.ptr), x2.cs, x2.C, _p(x3.ptr), x3.cs,
+                        _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
+                        x.N, x.H, x.W, c_phys, cout, act, sl) + wsa + (_p(status.data_ptr()) if status is not None else None, s)
+            elif use_h2:
                 fn = L.pwc_conv3x3_h2_ex_f32
                 args = (_p(x.ptr), x.cs, x.C if x2 is not None else 0, _p(x2.ptr) if x2 is not None else None,
                         x2.cs if x2 is not None else 0, _p(packed.data_ptr()), _p(bias.value.data_ptr()), _p(y.ptr), y.cs,
@@ -880,7 +896,7 @@ class CostVolumeLayer(_Module):
                 _track_max(self, f1)
             args = (_p(f0.ptr), f0.cs, _p(f1.ptr), f1.cs, _p(flow.ptr) if flow is not None else None,
                     flow.cs if flow is not None else 0, float(flow_scale), _p(out.ptr), out.cs,
-                    1 if out_pad_writable else 0,
+                    int(out_pad_writable),      # (2, round 6: the flow rides in channels 81, 82 of the record)
                     _p(f0_copy.ptr) if f0_copy is not None else None, f0_copy.cs if f0_copy is not None else 0,
                     f0.N, f0.H, f0.W, f0.C, self.s_range, 0.1)
             assert h2 or not blk
@@ -966,6 +982,45 @@ class OpticalFlowEstimator_custom(_Module):
             return False
         lay = self._layout(c_cv, c_f0, has_flow, fu_map, f0_external=True)
         return bool(_lib.lib().pwc_conv3x3_h2_supported(N, h, w, lay.n_phys + c_f0, self.filters[0], 1))
+
+    CVX_CS = 84          # channel stride of the dense [cv 81 | flow 2 | 0] tensor (336-byte records)
+
+    def three_operand_map(self, c_cv, c_f0, c_fu):
+        """Round 6: the first conv's input as THREE dense tensors -- [cv | flows_up_prev | 0] (84-channel records, read as six
+        16-channel stages: the last one runs 12 channels into the next record, zero weights), features_0 (the pyramid tensor),
+        features_up_prev.  Returns (physical -> logical channel map, logical channel count) for the weight packer: the concat
+        order of reference modules.py:261-264, [cv, features_0, flows_up_prev, features_up_prev], is the LOGICAL one."""
+        assert not self.use_dc and c_cv + 2 <= self.CVX_CS and c_f0 % 16 == 0 and c_fu % 16 == 0
+        a_phys = -(-(c_cv + 2) // 16) * 16
+        m = np.full((a_phys + c_f0 + c_fu,), -1, np.int32)
+        m[:c_cv] = np.arange(c_cv)
+        m[c_cv:c_cv + 2] = c_cv + c_f0 + np.arange(2)
+        m[a_phys:a_phys + c_f0] = c_cv + np.arange(c_f0)
+        m[a_phys + c_f0:] = c_cv + c_f0 + 2 + np.arange(c_fu)
+        return m, c_cv + c_f0 + 2 + c_fu
+
+    def three_operand_ok(self, N, h, w, c_cv, c_f0, c_fu):
+        """True where the first conv of this (non-DC) estimator takes the three-tensor input (the F16-pipe kernel, at the stage
+        count that input has)."""
+        if self.use_dc or not getattr(self, "f16x2", True) or not c_f0 or c_f0 % 16 or not c_fu or c_fu % 16 or c_cv != 81:
+            return False
+        return bool(_lib.lib().pwc_conv3x3_h2_supported(N, h, w, 96 + c_f0 + c_fu, self.filters[0], 1))
+
+    def _run3(self, cvx, f0, feat_up, flow_res, flows_out, feat_out=None):
+        """The estimator on the three-tensor input: cvx = View (C = 96 physical, cs = 84) of the [cv | flow | 0] records, f0 and
+        feat_up Views of features_0 / features_up_prev, flow_res the flows_up_prev View the head's residual adds."""
+        run = _ConvRunner(self)
+        cm, cl = self.three_operand_map(81, f0.C, feat_up.C)
+        x, keep = None, []
+        for k, f in enumerate(self.filters):
+            y = feat_out if (k == len(self.filters) - 1 and feat_out is not None) else None
+            if k == 0:
+                x, t = run.conv(cvx, f, y=y, cin_map=cm, cin_logical=cl, x2=f0, x3=feat_up)
+            else:
+                x, t = run.conv(x, f, y=y)
+            keep.append(t)
+        run.conv(x, 2, y=flows_out, slope=None, residual=flow_res)
+        return x, keep[-1]
 
     def _run(self, buf, lay, flows_out, feat_out=None, f0_ext=None):
         """buf: View of the (N,h,w,lay.n_phys) buffer whose cv/f0/flow/feat_up segments

@@ -15,6 +15,8 @@ for val in (True, False):
     net.load_weights(W.init_weights(W.conv_specs(use_dc=False), seed=0))
     for mod in [net.fp_extractor, net.context] + net.of_estimators:
         setattr(mod, attr, val)
+    if hasattr(net, attr):            # (model-level switches: two_operand, three_operand, ...)
+        setattr(net, attr, val)
     nets[val] = net
 im0 = torch.rand((B, 448, 1024, 3), device="cuda"); im1 = torch.rand((B, 448, 1024, 3), device="cuda")
 for net in nets.values():

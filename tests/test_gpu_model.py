@@ -568,6 +568,40 @@ def test_two_operand_first_conv_matches_the_concat_copy(pa):
     assert float(np.abs(a[:1].cpu().numpy() - e_final).max()) <= 1e-3 / 3
 
 
+def test_three_operand_first_conv_matches_the_estimator_buffer(pa):
+    """Round 6: at the levels whose correlation runs on the row-walking F16-pipe kernel, the estimator input is three DENSE tensors
+    -- [cv | flows_up_prev | 0] in 84-channel records (the correlation launch also writes the flow it read), features_0 in the
+    pyramid tensor, features_up_prev -- and the first conv takes all three (pwc_conv3x3_h2_ex3_f32): `tf.concat` (reference
+    modules.py:261-264) moves nothing and no producer writes a slice of a wider record.  Same channels in another order of
+    16-channel stages: the flows agree to fp32 summation order with the one-buffer form, and with the oracle; which levels take
+    the form is checked too (batch 8: levels 2-4; a single pair: level 4 only; never with dense connections)."""
+    w = util.model_weights(False, gain=1.3)
+    im0, im1 = util.smooth_images(8, 448, 1024, seed=96, shift=(3, -2))
+    net_a = pa.PWCDCNet(streams=1)
+    net_a.load_weights(w)
+    net_b = pa.PWCDCNet(streams=1)
+    net_b.load_weights(w)
+    net_b.three_operand = False
+    fu = list(range(32))
+    assert [net_a._three_operand_level(l, 8, 7 << l, 16 << l, c, fu) for l, c in ((1, 128), (2, 96), (3, 64), (4, 32))] == \
+        [False, True, True, True]
+    assert [net_a._three_operand_level(l, 1, 7 << l, 16 << l, c, fu) for l, c in ((2, 96), (3, 64), (4, 32))] == [False, False, True]
+    assert not net_b._three_operand_level(4, 8, 112, 256, 32, fu)
+    assert not pa.PWCDCNet(use_dc=True)._three_operand_level(4, 8, 112, 256, 32, fu)
+    a, pa_ = net_a(gpu(im0), gpu(im1))
+    b, pb_ = net_b(gpu(im0), gpu(im1))
+    assert float((a - b).abs().max()) <= 2e-5, float((a - b).abs().max())
+    for x, y in zip(pa_, pb_):
+        assert float((x - y).abs().max()) <= 2e-6
+    e_final, _ = orc.OraclePWCDCNet(w)(im0[:1], im1[:1])
+    assert float(np.abs(a[:1].cpu().numpy() - e_final).max()) <= 1e-3 / 3
+    # a single pair (level 4 only) and the replayed plan
+    a1, _ = net_a(gpu(im0[:1]), gpu(im1[:1]))
+    a1r, _ = net_a(gpu(im0[:1]), gpu(im1[:1]))
+    assert torch.equal(a1, a1r)
+    assert float(np.abs(a1.cpu().numpy() - e_final).max()) <= 1e-3 / 3
+
+
 def test_channel_split_launches_do_not_change_the_flows(pa, monkeypatch):
     """The coarse estimator levels run their Winograd convs with the channel loop dealt to several workgroups
     (pwc_conv3x3_wino_split_f32); with the split disabled the forward must give the same flows up to fp32 summation order."""

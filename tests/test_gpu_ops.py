@@ -793,6 +793,65 @@ def test_conv_f16x2_two_operand_and_status(pa, N, H, W, ca, cb, cout, with_ws):
                                    1, 0.1, None, 0, None, None) == -1
 
 
+@pytest.mark.parametrize("N,H,W,c0,cout,with_ws", [(2, 24, 40, 32, 128, False), (1, 33, 47, 64, 64, False), (2, 28, 64, 96, 128, False),
+                                                      (8, 112, 256, 32, 128, True)])
+def test_conv_f16x2_three_operands_vs_oracle(pa, N, H, W, c0, cout, with_ws):
+    """pwc_conv3x3_h2_ex3_f32 (round 6): the estimator's first conv on THREE dense tensors -- [cv 81 | flows_up_prev 2 | 0] in
+    84-channel records (six 16-channel stages: the sixth runs 12 channels into the NEXT pixel's record, zero weights there),
+    features_0, features_up_prev -- against the oracle's convolution of tf.concat([cv, features_0, flows_up_prev, features_up_prev])
+    (reference modules.py:261-267) with the logical kernel, and bit for bit against the one-tensor launch of the same physical
+    channel order with zeros in the padding channels; last case: BASELINE configs[1]'s level-4 shape through stream-K.  The
+    garbage behind a record (the next record's first channels) and behind the tensor's end must not reach the result."""
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device="cuda"); g.manual_seed(21)
+    cvx = torch.randn((N, H, W, 84), generator=g, device="cuda")
+    cvx[..., 83] = 0.0
+    f0 = torch.randn((N, H, W, c0 + 8), generator=g, device="cuda")       # a channel slice of a wider tensor
+    fu = torch.randn((N, H, W, 32), generator=g, device="cuda")
+    est = pa.OpticalFlowEstimator_custom(name="optflow_9")
+    cm, cl = est.three_operand_map(81, c0, 32)
+    assert cl == 81 + c0 + 2 + 32 and len(cm) == 96 + c0 + 32 and sorted(cm[cm >= 0].tolist()) == list(range(cl))
+    cin = len(cm)
+    k = gpu(rnd((3, 3, cl, cout), 372) * float(1.0 / np.sqrt(9 * cl)))
+    b = gpu(rnd((cout,), 373) * 0.1)
+    packed = torch.empty(L.pwc_conv3x3_h2_packed_floats(cin, cout), device="cuda")
+    cmg = torch.from_numpy(cm).cuda()
+    _lib.check(L.pwc_conv3x3_h2_pack_f32(_p(k), _p(cmg), cl, cin, cout, _p(packed), None))
+    ws = None
+    if with_ws:
+        n = L.pwc_conv3x3_h2_workspace_floats(N, H, W, cin, cout, 1)
+        assert n > 0
+        ws = torch.full((n,), -1, dtype=torch.int32, device="cuda").view(torch.float32)
+    wsa = (None, 0) if ws is None else (_p(ws), ws.numel())
+    status = torch.zeros(2, dtype=torch.int32, device="cuda")
+    y3 = torch.full((N, H, W, cout), -7.0, device="cuda")
+    _lib.check(L.pwc_conv3x3_h2_ex3_f32(_p(cvx), 84, 96, _p(f0), c0 + 8, c0, _p(fu), 32, _p(packed), _p(b), _p(y3), cout,
+                                        N, H, W, cin, cout, 1, 0.1, *wsa, _p(status), None))
+    # the same physical channels as ONE tensor (padding channels zero)
+    one = torch.zeros((N, H, W, cin), device="cuda")
+    one[..., :84] = cvx
+    one[..., 96:96 + c0] = f0[..., :c0]
+    one[..., 96 + c0:] = fu
+    y1 = torch.full((N, H, W, cout), -7.0, device="cuda")
+    _lib.check(L.pwc_conv3x3_h2_ex_f32(_p(one), cin, 0, None, 0, _p(packed), _p(b), _p(y1), cout, N, H, W, cin, cout, 1,
+                                       1, 0.1, *wsa, None, None))
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y3)
+    assert int(status[0].item()) == 0
+    if with_ws:
+        assert bool((ws.view(torch.int32) == -1).all())
+    if N * H * W <= 4096:
+        logical = torch.cat([cvx[..., :81], f0[..., :c0], cvx[..., 81:83], fu], dim=3).cpu().numpy()
+        close(y3, orc.conv3x3(logical, k.cpu().numpy(), b.cpu().numpy(), 1, 1, 0.1))
+    # argument checks: whole stages, strides that cover the operand (up to the 12 channels of slack), a third tensor needs a second
+    bad = lambda *a: L.pwc_conv3x3_h2_ex3_f32(*a)
+    args = [_p(cvx), 84, 96, _p(f0), c0 + 8, c0, _p(fu), 32, _p(packed), _p(b), _p(y1), cout, N, H, W, cin, cout, 1, 0.1, None, 0, None, None]
+    for pos, val in ((2, 88), (1, 80), (5, c0 - 8), (7, 16), (3, None), (6, None)):
+        a2 = list(args); a2[pos] = val
+        assert bad(*a2) in (-1, -2, -3), (pos, val)
+
+
 def test_conv_f16x2_direct_physical_layout_range_and_plan(pa):
     """Padded / permuted physical input channels through cin_map (the estimator buffers); operands of very different
     magnitudes (the split is relative, not absolute); an input beyond fp16's range poisons exactly the outputs that
@@ -1397,6 +1456,34 @@ def test_concat_cost_volume_kernel_vs_oracle(pa, N, H, W, C, with_flow, copy, pa
     else:
         assert float(E[..., 81:84].min()) == -3.0 and float(E[..., 81:84].max()) == -3.0
     assert float(E[..., 84 + C:].min()) == -3.0 and float(E[..., 84 + C:].max()) == -3.0
+
+
+@pytest.mark.parametrize("N,H,W,C,ecs", [(2, 28, 64, 96, 84), (1, 56, 128, 64, 84), (2, 40, 48, 32, 84), (3, 9, 21, 32, 84),
+                                         (1, 5, 3, 32, 100), (2, 33, 17, 64, 84), (1, 4, 16, 32, 84)])
+def test_concat_cost_volume_flow_in_record(pa, N, H, W, C, ecs):
+    """pwc_warp_cost_volume_concat_h2_f32 with out_pad_writable = 2 (round 6): the record of a pixel is [cv 81 | flow x, y | 0] --
+    the [cv, ..., flows_up_prev] parts of the estimator's concat (reference modules.py:261-264) in one dense tensor of 84-channel
+    records (ecs = 84: what the model runs; ragged block rows / strips; far outliers in the flow).  The cost volume is the
+    oracle's, the flow is the bits that were read, nothing behind channel 83 changes; the other two kernels refuse the mode."""
+    from pwcnet_amd import _lib
+    L = _lib.lib()
+    f0, f1 = rnd((N, H, W, C), 61), rnd((N, H, W, C), 62)
+    flow = util.flow_field(N, H, W, seed=63) / 5.0
+    exp = orc.cost_volume(f0, orc.warp(f1, flow, "bilinear", flow_scale=5.0), 4)
+    for flow_cs in (2, 4):
+        E, _ = _run_concat(pa, f0, f1, flow, 5.0, ecs, False, 2, flow_cs=flow_cs)
+        close(E[..., :81], exp, rel=4e-6, floor=4e-7)
+        assert torch.equal(E[..., 81:83], gpu(flow))
+        assert float(E[..., 83].abs().max()) == 0.0
+        if ecs > 84:
+            assert float(E[..., 84:].min()) == -3.0 and float(E[..., 84:].max()) == -3.0
+    g0, g1, fl = gpu(f0), gpu(f1), gpu(flow)
+    out = torch.zeros((N, H, W, 84), device="cuda")
+    args = (_p(g0), C, _p(g1), C, _p(fl), 2, 5.0, _p(out), 84, 2, None, 0, N, H, W, C, 4, 0.1, None)
+    assert L.pwc_warp_cost_volume_concat_f32(*args) == -4
+    assert L.pwc_warp_cost_volume_concat_blk_f32(*args) == -4
+    noflow = (_p(g0), C, _p(g1), C, None, 0, 1.0, _p(out), 84, 2, None, 0, N, H, W, C, 4, 0.1, None)
+    assert L.pwc_warp_cost_volume_concat_h2_f32(*noflow) == -1
 
 
 @pytest.mark.parametrize("f16x2", [True, False])
