@@ -11,7 +11,11 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
     equal WORLD_SIZE or the run aborts (a silently ignored N measured the wrong thing).
   A step = one PWCDCNet forward over this rank's batch of synthetic pairs (default
   8 x 448x1024 per GPU, BASELINE.json configs[1]); inputs are resident in HBM before the
-  timed region.  Pairs shard across ranks with no data-path collective (weak scaling);
+  timed region.  Round 6: the K steps of the timed region are dealt to the replicas of a
+  pwcnet_amd.ForwardPipeline (--pipeline D, default 3): step i runs on replica i % D, each
+  replica on a HIP stream with a hardware queue of its own, so whole forwards overlap; every
+  step is complete inside the bracket.  `value_one_stream` is the same K steps one after the
+  other on one stream (the round 1-5 form); the per-kernel legs are measured in THAT loop.  Pairs shard across ranks with no data-path collective (weak scaling);
   one RCCL all-gather of per-rank stats per run.  Rank 0 prints ONE JSON line.
   `--config configs3` = PWCDCNet use_dc=True batch 8; `--config configs4` = 960x1920
   batch 8 per GPU on 2 GPUs (BASELINE.json configs[4]; an explicit `--gpus 1` runs one
@@ -100,6 +104,11 @@ def parse(argv=None):
                     help="PWCDCNet(streams=K): the batch runs as K sub-batches on side HIP streams whose kernels overlap; "
                          "0 = the model's default (2 for even batches >= 4 and for 2 large pairs, else 1), 1 = single stream.  The per-kernel "
                          "roofline legs always come from single-stream passes.")
+    ap.add_argument("--pipeline", type=int, default=-1,
+                    help="pwcnet_amd.ForwardPipeline(depth=D): consecutive steps (whole batches) are dealt to D replicas of the "
+                         "model, each on a HIP stream with a hardware queue of its own, so that the launch-bound coarse levels of "
+                         "one step run under the matrix-bound launches of another; -1 = 3 (as deep as hardware queues are found); "
+                         "0 / 1 = the plain one-stream loop.  The per-kernel legs always come from the one-stream loop.")
     ap.add_argument("--persistent-outputs", action="store_true",
                     help="PWCDCNet(persistent_outputs=True): replays write into the plan's own output tensors")
     args = ap.parse_args(argv)
@@ -249,9 +258,19 @@ def main():
     # identical seeded glorot-uniform weights on every rank
     specs = W.conv_specs(use_dc=args.use_dc)
     wts = W.init_weights(specs, seed=0)
-    net = pwcnet_amd.PWCDCNet(use_dc=args.use_dc, persistent_outputs=args.persistent_outputs,
-                              streams=args.streams if args.streams > 0 else None)
-    net.load_weights(wts)
+    depth = args.pipeline if args.pipeline >= 0 else 3
+    if args.persistent_outputs or args.streams > 1:
+        depth = 1                       # (plan-owned outputs / sub-batch streams: the round 2-5 forms, one forward at a time)
+    pipe = None
+    if depth >= 2:
+        from pwcnet_amd.pipeline import ForwardPipeline
+        pipe = ForwardPipeline(depth=depth, device=dev, use_dc=args.use_dc)
+        pipe.load_weights(wts)
+        net = pipe.nets[0]              # the one-stream legs (per-kernel events, op leg, fp32 leg) run on replica 0
+    else:
+        net = pwcnet_amd.PWCDCNet(use_dc=args.use_dc, persistent_outputs=args.persistent_outputs,
+                                  streams=args.streams if args.streams > 0 else None)
+        net.load_weights(wts)
     eff_streams = 1 if args.persistent_outputs else net.effective_streams((args.batch, args.height, args.width, 3))
     if args.op_leg_only:
         if rank == 0:
@@ -267,6 +286,14 @@ def main():
     for _ in range(args.warmup):
         net(im0, im1)
     torch.cuda.synchronize()
+    if pipe is not None:
+        # every replica records its launch plan on its first forward and replays it from the second on: two untimed forwards
+        # per lane (on top of the W warm-up steps above, which ran on replica 0 on this stream)
+        for _ in range(2 * depth):
+            pipe.submit(im0, im1)
+        torch.cuda.synchronize()
+        if getattr(pipe, "effective_depth", 1) < 2:
+            pipe = None                 # no second hardware queue was found: the plain loop
     # the model's own verdict on its side streams (device-timed queue probe); no vetted stream -> it ran single-stream
     ss_report = net.side_stream_report
     if eff_streams > 1 and (ss_report is None or ss_report.get("verdict") != "vetted"):
@@ -306,21 +333,40 @@ def main():
     timer = None if (dominant is None or overlapped) else OpTimer(only=(dominant, "cost_volume", "warp_kernel"))
     # sampled steps: the middle one of every SAMPLE_EVERY (at least one)
     sampled = set(i for i in range(args.steps) if i % SAMPLE_EVERY == SAMPLE_EVERY // 2) or {args.steps - 1}
-    sync_all()
-    t0 = time.perf_counter()
-    if timer is not None:
-        with timer:
-            for i in range(args.steps):
-                timer.enabled = i in sampled
+
+    def one_stream_loop():
+        """K steps one after the other on this stream, HIP events around the dominant kernel's and the correlation's launches in
+        the sampled steps -> (seconds, host seconds to issue)"""
+        sync_all()
+        t0 = time.perf_counter()
+        if timer is not None:
+            with timer:
+                for i in range(args.steps):
+                    timer.enabled = i in sampled
+                    out = net(im0, im1)
+        else:
+            for _ in range(args.steps):
                 out = net(im0, im1)
-    else:
+        issue = time.perf_counter() - t0              # host time to ISSUE the K forwards (the GPU runs behind)
+        sync_all()
+        return time.perf_counter() - t0, issue
+
+    one_stream = None
+    if pipe is not None:
+        # THE TIMED REGION: K steps, step i on replica i % depth (each a whole batch through the whole network); the bracket is the
+        # contract's -- synchronize + barrier on both sides, every step complete inside it
+        sync_all()
+        t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = net(im0, im1)
-    issue_elapsed = time.perf_counter() - t0          # host time to ISSUE the K forwards (the GPU runs behind)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    del out
-    st_rep = net.status()                             # the kernels' status words (fp16 range / stream-K): nothing may have fired
+            ticket = pipe.submit(im0, im1)
+        issue_elapsed = time.perf_counter() - t0
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        del ticket
+        st_rep = pipe.status()
+    else:
+        elapsed, issue_elapsed = one_stream_loop()
+        st_rep = net.status()                         # the kernels' status words (fp16 range / stream-K): nothing may have fired
 
     stats = gather_stats(dict(pairs=float(B * args.steps), seconds=elapsed, issue_seconds=issue_elapsed), dist, dev)
     value, ms_per_step, total_pairs, n_ranks = aggregate_throughput(stats, args.steps)
@@ -337,6 +383,13 @@ def main():
     if rank != 0:
         return
 
+    if pipe is not None:
+        # the plain loop beside it: K more steps one after the other on one stream (rank 0), with the HIP events the per-kernel
+        # legs need -- in the pipelined region the kernels of two steps overlap and a launch has no duration of its own
+        e1, i1 = one_stream_loop()
+        one_stream = {"value": B * args.steps / e1, "ms_per_step": 1e3 * e1 / args.steps,
+                      "host_issue_ms_per_step": 1e3 * i1 / args.steps}
+        net.status()
     cfg_idx = None
     if (B, H, Wd) == (8, 448, 1024):
         cfg_idx = 3 if args.use_dc else (1 if world == 1 else (2 if world == 8 else None))
@@ -375,6 +428,15 @@ def main():
             "gpus_from": ("--gpus" if getattr(args, "gpus_given", True) or not args.config
                           else f"implied by --config {args.config}"),
             "streams": eff_streams,
+            "pipeline": ({"depth": pipe.effective_depth, "asked": depth,
+                          "what": "pwcnet_amd.ForwardPipeline: step i runs on replica i % depth of the model (own activations, "
+                                  "stream-K workspace and status words), each replica on a HIP stream with a hardware queue of "
+                                  "its own; every step is a whole batch through the whole network and all K steps complete "
+                                  "inside the timed bracket; results are bit-identical to the one-stream loop "
+                                  "(tests/test_gpu_model.py::test_pipeline_matches_single_stream); value_one_stream = the same "
+                                  "K steps one after the other on one stream",
+                          "streams": pipe.stream_report.get("verdict") if pipe.stream_report else None}
+                         if pipe is not None else None),
             "conv3x3_arithmetic": ("fp32 tensors throughout; the big stride-1 layers (pwc_conv3x3_h2_supported) form each fp32 "
                                    "product from exact-to-22-bit fp16 operand pairs on the F16 matrix pipe with fp32 accumulation "
                                    "(more accurate than an fp32 MFMA chain, tolerances unchanged; PWCDCNet(f16x2=False) = fp32 "
@@ -385,12 +447,21 @@ def main():
         },
     }
 
+    if one_stream is not None:
+        line["value_one_stream"] = one_stream["value"] * (world if world > 1 else 1)
+        line["ms_per_step_one_stream"] = one_stream["ms_per_step"]
+        line["one_stream_note"] = ("the same K steps one after the other on one stream (PWCDCNet.__call__ in a loop, rank 0"
+                                   + (f"; x {world} ranks" if world > 1 else "") + "): the round 1-5 headline form, and the "
+                                   "loop the per-kernel roofline legs are measured in")
     if dominant is not None:
         if timer is not None:
             summ = timer.summary()          # events recorded INSIDE the timed region (sampled steps)
             n_sampled = len(sampled)
             where = (f"HIP events around each launch of this kernel in one step of every {SAMPLE_EVERY} of the "
-                     f"timed region ({n_sampled} of {args.steps} steps)")
+                     + (f"timed region ({n_sampled} of {args.steps} steps)" if pipe is None else
+                        f"ONE-STREAM loop of the same {args.steps} steps ({n_sampled} sampled; ms_per_step_one_stream): in the "
+                        f"pipelined timed region the kernels of {pipe.effective_depth} steps overlap and a launch has no "
+                        "duration of its own"))
         else:
             summ = full_summary             # overlapped timed region: the untimed single-stream profile pass
             n_sampled = full_steps

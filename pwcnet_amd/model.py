@@ -145,6 +145,7 @@ class PWCDCNet(object):
         assert range_check in ("lazy", "sync", "off")
         self.range_check = range_check
         self.track_max = bool(track_max)
+        self.status_copy_on_caller_stream = False   # ForwardPipeline sets it (see _record)
         self.two_operand = True             # features_0 read from the pyramid tensor where the first conv allows (_est_layout)
         self.three_operand = True           # round 6: [cv | flow], features_0, features_up as three dense tensors (_level_input)
         self.f16x2 = bool(f16x2)
@@ -278,16 +279,23 @@ class PWCDCNet(object):
         # the 8-byte copy runs on a stream of its own behind an event: on the caller's stream it is a 4-5 us blit dispatch at the
         # end of every forward (profiles/r05_forward_trace_b8.txt, row 63).  The words are sticky, so a copy that is overtaken by
         # the next forward can only show a flag EARLY -- _examine then repeats one innocent forward more, never one less.
-        if len(st) < 4:
-            st.append(torch.cuda.Stream(device=images_0.device))
-        side = st[3]
-        done = torch.cuda.Event()
-        done.record()
-        side.wait_event(done)
-        with torch.cuda.stream(side):
+        # (ForwardPipeline: the caller's stream IS a side stream with a hardware queue of its own -- a second stream per replica
+        # could land on ANOTHER replica's queue and hold its launches back behind this forward's end: the copy stays in line)
+        if self.status_copy_on_caller_stream:
             host.copy_(words, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
+        else:
+            if len(st) < 4:
+                st.append(torch.cuda.Stream(device=images_0.device))
+            side = st[3]
+            done = torch.cuda.Event()
+            done.record()
+            side.wait_event(done)
+            with torch.cuda.stream(side):
+                host.copy_(words, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
         vers = (getattr(images_0, "_version", None), getattr(images_1, "_version", None))
         self._pending.append((ev, host, images_0, images_1, vers, out, images_0.device))
 

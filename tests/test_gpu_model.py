@@ -377,6 +377,12 @@ def test_bench_json_contract(pa):
     assert d["dtype"].startswith("f32") and "fp16x2" in d["dtype"]          # the arithmetic is named, not just the tensor type
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
     assert "workload" in d["config"] and "model" not in d["config"]
+    # round 6: the timed region deals its K steps to the replicas of a ForwardPipeline (whole forwards overlap); the plain loop's
+    # figure and the loop the per-kernel events were taken in stand beside it
+    pl = d["config"]["pipeline"]
+    assert pl["asked"] == 3 and 2 <= pl["depth"] <= 3 and pl["streams"] == "vetted"
+    assert d["value_one_stream"] > 0 and abs(d["value_one_stream"] - 2 * 1e3 / d["ms_per_step_one_stream"]) <= 1e-6 * d["value_one_stream"]
+    assert "ONE-STREAM loop" in d["roofline"]["measured"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_algorithmic", "frac_executed"):
         assert k in r, k
@@ -784,3 +790,72 @@ def test_fallback_refreshes_the_returned_pyramid_too(pa, streams):
             got = net(big0, big1)
         torch.cuda.synchronize()
         assert torch.equal(got[0], want[0]) and all(torch.equal(g, e) for g, e in zip(got[1], want[1]))
+
+
+# ------------------------------------------------------------------ round 6: whole forwards in flight (pwcnet_amd.ForwardPipeline)
+@pytest.mark.parametrize("depth", [2, 3])
+def test_pipeline_matches_single_stream(pa, depth):
+    """Consecutive forwards dealt to `depth` replicas on HIP streams of their own (the launch-bound coarse levels of one forward
+    under the matrix-bound launches of another) give, ticket by ticket, the tensors the plain PWCDCNet loop gives -- bit for bit:
+    same kernels, same launch plans, nothing shared between replicas but the weights.  Seven DIFFERENT batches, so that a ticket
+    handed the wrong replica's tensors, or a replica reading frames of another submission, cannot pass; the frames of a
+    submission are dropped by the caller right behind submit() (the allocator may not recycle them under the lane)."""
+    from pwcnet_amd.pipeline import ForwardPipeline
+    w = util.model_weights(False)
+    net = pa.PWCDCNet()
+    net.load_weights(w)
+    pipe = ForwardPipeline(depth=depth)
+    pipe.load_weights(w)
+    frames = [util.smooth_images(2, 128, 192, seed=100 + i, shift=(1 + i % 3, -(i % 2))) for i in range(7)]
+    want = []
+    for im0, im1 in frames:
+        f, pyr = net(gpu(im0), gpu(im1))
+        want.append((f.clone(), [p.clone() for p in pyr]))
+    torch.cuda.synchronize()
+    tickets = []
+    for im0, im1 in frames:
+        a, b = gpu(im0), gpu(im1)
+        tickets.append(pipe.submit(a, b))
+        del a, b
+        poison = [torch.full((2, 128, 192, 3), float("nan"), device="cuda") for _ in range(4)]      # (a recycled block would be poisoned here)
+        del poison
+    assert pipe.effective_depth >= 1
+    for tk, (f, pyr) in zip(tickets, want):
+        got_f, got_pyr = tk.result()
+        torch.cuda.current_stream().synchronize()
+        assert torch.equal(got_f, f)
+        assert len(got_pyr) == len(pyr) and all(torch.equal(g, e) for g, e in zip(got_pyr, pyr))
+    rep = pipe.synchronize()
+    assert rep["flags"] == 0 and rep["f16x2"] is True and len(rep["replicas"]) == depth
+    # the drop-in form: submit + result
+    f, _ = pipe(gpu(frames[0][0]), gpu(frames[0][1]))
+    torch.cuda.synchronize()
+    assert torch.equal(f, want[0][0])
+    # against the oracle too (the tolerance of the forward)
+    e, _ = orc.OraclePWCDCNet(w)(*frames[0])
+    assert float(np.abs(f.cpu().numpy() - e).max()) <= 1e-3
+
+
+def test_pipeline_falls_back_to_fp32_like_the_model(pa):
+    """A replica whose forward leaves fp16's range repeats it on the fp32 kernels into the tensors its ticket holds, exactly as
+    PWCDCNet does (every replica keeps its own status words)."""
+    import warnings
+    from pwcnet_amd.pipeline import ForwardPipeline
+    w = util.model_weights(False)
+    im0, im1 = util.smooth_images(4, 192, 256, seed=31, shift=(2, -1))
+    ref = pa.PWCDCNet(f16x2=False)
+    ref.load_weights(w)
+    pipe = ForwardPipeline(depth=2)
+    pipe.load_weights(w)
+    big0, big1 = gpu(im0 * 1e7), gpu(im1 * 1e7)
+    want, _ = ref(big0, big1)
+    ok_want, _ = ref(gpu(im0), gpu(im1))
+    t_ok = pipe.submit(gpu(im0), gpu(im1))
+    t_big = pipe.submit(big0, big1)
+    with pytest.warns(RuntimeWarning, match="fp16's range"):
+        rep = pipe.synchronize()
+    assert rep["f16x2"] is False and sum(1 for r in rep["replicas"] if not r["f16x2"]) == 1
+    torch.cuda.synchronize()
+    assert torch.equal(t_big.result()[0], want)
+    assert float((t_ok.result()[0] - ok_want).abs().max()) <= 1e-4
+    torch.cuda.synchronize()
