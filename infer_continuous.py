@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--out", type=str, default="./test_figure")
     ap.add_argument("--batch", type=int, default=8, help="pairs per forward")
     ap.add_argument("--gpu", type=int, default=0)
+    ap.add_argument("--pipeline", type=int, default=3, help="forwards in flight (pwcnet_amd.ForwardPipeline depth; 1 = one at a time)")
     args = ap.parse_args()
     paths = []
     for p in args.input_images:                      # expand wild-cards (test_continuous.py:75-78)
@@ -53,7 +54,11 @@ def main():
     from pwcnet_amd import ckpt, flow_io
 
     torch.cuda.set_device(args.gpu)
-    model = pwcnet_amd.PWCDCNet(range_check="sync")      # results are final when a call returns (fp16-range check + fp32 repeat)
+    # Round 6: the batches of a sequence are independent forwards -- dealt to the replicas of a ForwardPipeline (HIP streams with
+    # hardware queues of their own) the launch-bound coarse levels of one batch run under the matrix-bound launches of another.
+    # Results are read behind pipeline.synchronize(): every forward has then passed its fp16-range check (a flagged one has been
+    # repeated on the fp32 kernels), which is what range_check="sync" gave the one-forward-at-a-time loop.
+    model = pwcnet_amd.ForwardPipeline(depth=args.pipeline)
     if args.resume is not None:
         print(f"Loading learned model from checkpoint {args.resume}")
         model.load_weights(ckpt.load_weights(args.resume))
@@ -61,26 +66,36 @@ def main():
         print("!!! Test with un-learned model !!!")
 
     frames = [flow_io.factor_crop(np.asarray(Image.open(p).convert("RGB"))) for p in paths]
+    # runs of consecutive pairs whose frames all have one size: one batch each
+    jobs = []
     i = 0
     while i < len(frames) - 1:
-        # a run of consecutive pairs whose frames all have one size
         j = i
         while j < len(frames) - 1 and j - i < args.batch and frames[j + 1].shape == frames[i].shape:
             j += 1
         if j == i:
             raise ValueError(f"{paths[i]} and {paths[i + 1]} differ in size after cropping")
-        seq = torch.from_numpy(np.stack(frames[i:j + 1]).astype(np.float32) / 255.0).cuda()
-        flow_final, flows = model(seq[:-1].contiguous(), seq[1:].contiguous())
-        flow_final = flow_final.cpu().numpy()
-        flows = [f.cpu().numpy() for f in flows]
-        for k in range(j - i):
-            parts = re.split("[/.]", paths[i + k])
-            dname, fname = (parts[-3:-1] if len(parts) >= 3 else ("", parts[-2]))
-            os.makedirs(os.path.join(args.out, dname), exist_ok=True)
-            pyr = [f[k] * (20.0 / 2 ** (model.num_levels - l)) for l, f in enumerate(flows)]
-            Image.fromarray(pyramid_montage(frames[i + k], pyr)).save(os.path.join(args.out, dname, fname + ".png"))
-            flow_io.write_flo(os.path.join(args.out, dname, fname + ".flo"), flow_final[k])
+        jobs.append((i, j))
         i = j
+    num_levels = model.nets[0].num_levels
+    window = 2 * max(1, args.pipeline)               # batches submitted before the first one is read back
+    for w0 in range(0, len(jobs), window):
+        tickets = []
+        for i, j in jobs[w0:w0 + window]:
+            seq = torch.from_numpy(np.stack(frames[i:j + 1]).astype(np.float32) / 255.0).cuda()
+            tickets.append((i, j, model.submit(seq[:-1].contiguous(), seq[1:].contiguous())))
+        model.synchronize()
+        for i, j, ticket in tickets:
+            flow_final, flows = ticket.result()
+            flow_final = flow_final.cpu().numpy()
+            flows = [f.cpu().numpy() for f in flows]
+            for k in range(j - i):
+                parts = re.split("[/.]", paths[i + k])
+                dname, fname = (parts[-3:-1] if len(parts) >= 3 else ("", parts[-2]))
+                os.makedirs(os.path.join(args.out, dname), exist_ok=True)
+                pyr = [f[k] * (20.0 / 2 ** (num_levels - l)) for l, f in enumerate(flows)]
+                Image.fromarray(pyramid_montage(frames[i + k], pyr)).save(os.path.join(args.out, dname, fname + ".png"))
+                flow_io.write_flo(os.path.join(args.out, dname, fname + ".flo"), flow_final[k])
     print("Figure saved")
 
 

@@ -764,6 +764,13 @@ static inline bool h2_split_pays(long ntiles, int nc16, int cus) {
     return ntiles < cus && ntiles * nc16 >= (long)H2_MIN_STAGES * cus && 2L * nc16 * (cus - ntiles) >= 11L * cus;
 }
 
+#ifdef PWC_HARNESS
+static int h2_reserve_cus = 0;     // libpwc_hip_harness.so only (pwc_debug_h2_reserve_cus, scripts/exp_pipeline_reserve.py): CUs a stream-K launch leaves free
+extern "C" void pwc_debug_h2_reserve_cus(int n) { h2_reserve_cus = n < 0 ? 0 : n; }
+#else
+constexpr int h2_reserve_cus = 0;
+#endif
+
 static int h2_cu_count() {
     static int cus[64] = {0};
     int dev = 0;
@@ -773,7 +780,7 @@ static int h2_cu_count() {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         cus[dev] = n;
     }
-    return cus[dev];
+    return cus[dev] - h2_reserve_cus > 0 ? cus[dev] - h2_reserve_cus : 1;
 }
 
 // 1 where this kernel is the faster one for the shape (measured against conv3x3_wino4.hip / conv3x3_wino.hip on isolated layers:
