@@ -18,7 +18,8 @@ CSRC = os.path.join(_HERE, "csrc")
 # (tile pinning, ablations).  The production library exports none of them (tests/test_host.py checks).
 HARNESS = os.environ.get("PWC_HARNESS", "") == "1"
 LIB_PATH = os.path.join(CSRC, "libpwc_hip_harness.so" if HARNESS else "libpwc_hip.so")
-HARNESS_SIGNATURES_NAMES = ("pwc_debug_cost_volume_blk_rows", "pwc_debug_conv3x3_sk_tile", "pwc_debug_conv3x3_t32")
+HARNESS_SIGNATURES_NAMES = ("pwc_debug_cost_volume_blk_rows", "pwc_debug_conv3x3_sk_tile", "pwc_debug_conv3x3_t32",
+                            "pwc_debug_h2_reserve_cus")
 SOURCES = ["conv3x3_mfma.hip", "conv3x3_wino.hip", "conv3x3_direct.hip", "cost_volume.hip", "pwc_ops.hip",
            "pwc_backward.hip", "conv3x3_wgrad.hip", "conv3x3_h2.hip", "conv3x3_c16pair.hip", "conv3x3_sk.hip", "conv3x3_t32.hip", "conv3x3_w32.hip"]
 HEADERS = ["pwc_common.h", "cost_volume_roll.hip", "cost_volume_mfma.hip", "cost_volume_h2.hip", "cost_volume_blk.hip", "conv3x3_wino4.hip", os.path.join("..", "..", "include", "pwc_hip.h")]
