@@ -328,6 +328,26 @@ def test_load_weights_strict_rejects_wrong_variable_sets():
         net.load_weights(bad)
 
 
+def test_forward_pipeline_host_side():
+    """pwcnet_amd.ForwardPipeline (round 6) without a GPU: `depth` replicas of PWCDCNet that keep their status copy in line,
+    the model's kwargs passed through, the pipeline's own business (`streams`, `persistent_outputs`) refused, load_weights
+    fanned out with the model's strictness, nothing of the oracle imported."""
+    import pwcnet_amd
+    from pwcnet_amd import pipeline
+    pipe = pwcnet_amd.ForwardPipeline(depth=3, device="cuda:0", use_dc=True, output_level=3)
+    assert len(pipe.nets) == 3 and pipe.depth == 3 and pipe.effective_depth == 0
+    assert all(n.use_dc and n.output_level == 3 and n.streams == 1 and n.status_copy_on_caller_stream for n in pipe.nets)
+    assert pwcnet_amd.PWCDCNet().status_copy_on_caller_stream is False
+    assert len({id(n.store) for n in pipe.nets}) == 3            # replicas share no state
+    for bad in ({"streams": 2}, {"persistent_outputs": True}):
+        with pytest.raises(AssertionError):
+            pwcnet_amd.ForwardPipeline(depth=2, device="cuda:0", **bad)
+    with pytest.raises(ValueError, match="missing"):
+        pipe.load_weights({})
+    src = open(pipeline.__file__).read()
+    assert "oracle" not in src and "subprocess" not in src
+
+
 # ------------------------------------------------------------------ sharding
 def test_shard_range_partitions():
     for n, world in [(64, 8), (8, 8), (10, 4), (3, 8), (0, 2)]:
