@@ -859,3 +859,28 @@ def test_pipeline_falls_back_to_fp32_like_the_model(pa):
     assert torch.equal(t_big.result()[0], want)
     assert float((t_ok.result()[0] - ok_want).abs().max()) <= 1e-4
     torch.cuda.synchronize()
+
+
+def test_pipeline_at_bench_size_with_stream_k_launches_in_flight(pa):
+    """The bench shape (8 x 448 x 1024): here the big layers run as stream-K launches (one workgroup per CU, partial sums exchanged
+    through a workspace per stream) and three of them can be in flight at once.  24 forwards over 3 lanes, two different batches
+    alternating: every ticket equals the one-stream result of ITS batch bit for bit, no status flag (a stream-K wait that ran out
+    would raise PWC_STATUS_STREAMK_TIMEOUT and move the replica to the fp32 kernels)."""
+    import warnings
+    from pwcnet_amd.pipeline import ForwardPipeline
+    w = util.model_weights(False)
+    net = pa.PWCDCNet()
+    net.load_weights(w)
+    pairs = [tuple(gpu(x) for x in util.smooth_images(8, 448, 1024, seed=300 + i, shift=(2 + i, -1 - i))) for i in range(2)]
+    want = [net(a, b)[0].clone() for a, b in pairs]
+    torch.cuda.synchronize()
+    pipe = ForwardPipeline(depth=3)
+    pipe.load_weights(w)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        tickets = [pipe.submit(*pairs[i % 2]) for i in range(24)]
+        rep = pipe.synchronize()
+    assert rep["flags"] == 0 and rep["f16x2"] is True
+    for i, tk in enumerate(tickets):
+        assert torch.equal(tk.result()[0], want[i % 2]), i
+    torch.cuda.synchronize()
