@@ -1486,6 +1486,38 @@ def test_concat_cost_volume_flow_in_record(pa, N, H, W, C, ecs):
     assert L.pwc_warp_cost_volume_concat_h2_f32(*noflow) == -1
 
 
+@pytest.mark.parametrize("N,H,W,with_flow,copy,pad", [
+    (9, 110, 250, True, True, True), (9, 110, 250, True, False, False), (10, 106, 244, False, True, True),
+    (10, 106, 244, False, False, False), (9, 110, 250, True, False, 2), (8, 112, 256, True, False, 2), (16, 57, 255, True, True, 1)])
+def test_big_ragged_c32_cost_volume_vs_oracle(pa, N, H, W, with_flow, copy, pad):
+    """The 1/4-resolution level's launch (C = 32) at full-size pixel counts with ragged right / bottom edges (W % 16, H % 4, an odd
+    number of block rows), every combination of warp / f0 copy / padding / the flow in the record (pad = 2), flows with far
+    outliers -- the shapes round 6's tile-form experiment (scripts/experiments/cost_volume_tile.hip, profiles/
+    r06_exp_cost_volume_tile.txt) was checked on, kept as tests of the entry point.  Same contract as
+    test_concat_cost_volume_kernel_vs_oracle: the oracle's cost volume, the copy bit for bit, nothing outside the declared slices
+    changes."""
+    C = 32
+    f0, f1 = rnd((N, H, W, C), 71), rnd((N, H, W, C), 72)
+    flow = util.flow_field(N, H, W, seed=73) / 5.0
+    f1w = orc.warp(f1, flow, "bilinear", flow_scale=5.0) if with_flow else f1
+    exp = orc.cost_volume(f0, f1w, 4)
+    ecs = 84 if pad == 2 else 84 + C + 8
+    E, g0 = _run_concat(pa, f0, f1, flow if with_flow else None, 5.0, ecs, copy, pad)
+    close(E[..., :81], exp, rel=4e-6, floor=4e-7)
+    if pad == 2:
+        assert torch.equal(E[..., 81:83], gpu(flow)) and float(E[..., 83].abs().max()) == 0.0
+        return
+    if copy:
+        assert torch.equal(E[..., 84:84 + C], g0)
+    else:
+        assert float(E[..., 84:84 + C].max()) == -3.0 and float(E[..., 84:84 + C].min()) == -3.0
+    if pad:
+        assert float(E[..., 81:84].abs().max()) == 0.0
+    else:
+        assert float(E[..., 81:84].min()) == -3.0 and float(E[..., 81:84].max()) == -3.0
+    assert float(E[..., 84 + C:].min()) == -3.0 and float(E[..., 84 + C:].max()) == -3.0
+
+
 @pytest.mark.parametrize("f16x2", [True, False])
 def test_concat_cost_volume_known_answers(pa, f16x2):
     """Zero flow = plain cost volume; a constant integer flow = the cost volume of the shifted map (edge
