@@ -456,7 +456,8 @@ class PWCDCNet(object):
             return self._hand_over(self._forward(iv0, iv1, dev, with_features), into, with_features)
         # (the alignment of the frames is part of the key: the fused level-1 launch of the extractor takes 16-byte aligned
         # frames only, and a plan recorded with it must not be replayed on a view that is not -- ADVICE r4)
-        key = (iv0[1:], str(dev), stream, bool(with_features), self.store.version, iv0.ptr % 16, iv1.ptr % 16)
+        key = (iv0[1:], str(dev), stream, bool(with_features), self.store.version, iv0.ptr % 16, iv1.ptr % 16,
+               self._frames_shared(iv0, iv1))     # (a plan recorded on a sequence reads images_1 through images_0's pointer)
         plan = self._plans.get(key)
         if plan is not None:
             self._plans.move_to_end(key)
@@ -533,10 +534,25 @@ class PWCDCNet(object):
             patch[f"out{i}"] = t.data_ptr()
         return new[0], new[1:]
 
+    @staticmethod
+    def _frames_shared(iv0, iv1):
+        """True where the two image batches are frames[:-1] and frames[1:] of one dense tensor (same sizes and strides, images_1
+        exactly one frame behind images_0)."""
+        return (iv0[1:] == iv1[1:] and iv0.cs == iv0.C
+                and iv1.ptr == iv0.ptr + 4 * iv0.H * iv0.W * iv0.cs)
+
     def _forward(self, iv0, iv1, dev, with_features):
         N = iv0.N
         with variable_scope(self.name, store=self.store):
-            stacked = self.fp_extractor._run([iv0, iv1], dev)[::-1]   # deep -> shallow, 2N batch
+            # Round 6: images_1 = images_0 shifted by one frame of the SAME tensor (frames[:-1], frames[1:] -- a sequence, reference
+            # test_continuous.py:55-62 feeds its consecutive pairs one by one): the N + 1 frames go through the extractor once, not
+            # as 2 N images; the second pyramid of pair i is the first of pair i + 1.
+            f1_off = N
+            if self._frames_shared(iv0, iv1):
+                stacked = self.fp_extractor._run([View(iv0.ptr, iv0.cs, N + 1, iv0.H, iv0.W, iv0.C)], dev)[::-1]
+                f1_off = 1
+            else:
+                stacked = self.fp_extractor._run([iv0, iv1], dev)[::-1]   # deep -> shallow, 2N batch
             pyramid_0 = [f[:N] for f in stacked]
 
             flows_pyramid = []
@@ -544,7 +560,7 @@ class PWCDCNet(object):
             for l, F in enumerate(stacked):
                 _, h, w, C = F.shape
                 f0 = View(F.data_ptr(), C, N, h, w, C)
-                f1 = View(F.data_ptr() + 4 * N * h * w * C, C, N, h, w, C)
+                f1 = View(F.data_ptr() + 4 * f1_off * h * w * C, C, N, h, w, C)
                 est = self.of_estimators[l]
                 is_out = (l == self.output_level)
 

@@ -884,3 +884,43 @@ def test_pipeline_at_bench_size_with_stream_k_launches_in_flight(pa):
     for i, tk in enumerate(tickets):
         assert torch.equal(tk.result()[0], want[i % 2]), i
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------ round 6: a sequence's shared frames go through the extractor once
+@pytest.mark.parametrize("use_dc", [False, True])
+def test_sequence_frames_share_the_extractor(pa, use_dc):
+    """net(frames[:-1], frames[1:]) on ONE tensor of N + 1 frames (what infer_continuous.py feeds; reference test_continuous.py:55-62
+    runs the pairs one by one): the model notices that images_1 is images_0 one frame on and runs the extractor over N + 1 frames
+    instead of 2 N.  Same flows as the two-tensor call (the extractor's tile plans see another image count: equal to rounding, not
+    bit for bit) and as the oracle pair by pair; a launch plan recorded on a sequence is not replayed on two separate tensors of the
+    same shape (and vice versa); with_features returns the first frames' pyramid."""
+    w = util.model_weights(use_dc)
+    net = pa.PWCDCNet(use_dc=use_dc)
+    net.load_weights(w)
+    ims = [util.smooth_images(1, 128, 192, seed=400 + i, shift=(2, -1))[0][0] for i in range(5)]
+    frames = gpu(np.stack(ims))
+    a0, a1 = frames[:-1], frames[1:]
+    from pwcnet_amd.modules import as_view
+    assert net._frames_shared(as_view(a0)[0], as_view(a1)[0]) and not net._frames_shared(as_view(a0)[0], as_view(a0.clone())[0])
+    seq_f, seq_pyr = net(a0, a1)                                   # records the sequence plan
+    seq_f2, _ = net(a0, a1)                                        # ... and replays it
+    b0, b1 = a0.clone(), a1.clone()
+    two_f, two_pyr = net(b0, b1)                                   # separate tensors: the 2 N path, its own plan
+    seq_f3, _ = net(a0, a1)
+    torch.cuda.synchronize()
+    assert torch.equal(seq_f, seq_f2) and torch.equal(seq_f, seq_f3)
+    assert float((seq_f - two_f).abs().max()) <= 2e-5
+    for s_, t_ in zip(seq_pyr, two_pyr):
+        assert float((s_ - t_).abs().max()) <= 2e-6
+    e, _ = orc.OraclePWCDCNet(w, use_dc=use_dc)(np.stack(ims[:-1]), np.stack(ims[1:]))
+    assert float(np.abs(seq_f.cpu().numpy() - e).max()) <= 1e-3
+    # other frames in the same storage: the replayed sequence plan follows the pointers
+    frames2 = gpu(np.stack(ims[::-1]))
+    r_f, _ = net(frames2[:-1], frames2[1:])
+    e2, _ = orc.OraclePWCDCNet(w, use_dc=use_dc)(np.stack(ims[::-1][:-1]), np.stack(ims[::-1][1:]))
+    assert float(np.abs(r_f.cpu().numpy() - e2).max()) <= 1e-3
+    _, _, feats = net(a0, a1, with_features=True)
+    _, _, feats2 = net(b0, b1, with_features=True)
+    for x, y in zip(feats, feats2):
+        assert x.shape == y.shape and float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max()))
+    assert net.status()["flags"] == 0
