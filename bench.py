@@ -88,6 +88,11 @@ def parse(argv=None):
                     help="preset of BASELINE.json `configs` (overrides height/width/use-dc; configs2 / configs4 also imply "
                          "--gpus 8 / 2 unless --gpus is given)")
     ap.add_argument("--spawn", action="store_true", help="go through torch.distributed.run even for --gpus 1")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST form of --gpus N on a box with fewer GPUs: rank r runs on device r %% (visible GPUs) and the ranks' "
+                         "statistics are gathered over gloo (RCCL refuses two ranks on one device).  Exercises the N > 1 branch "
+                         "(barriers, per-rank timing, aggregation, rank-0-only legs) on real hardware; its pairs/s is NOT a "
+                         "scaling figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget")
     ap.add_argument("--no-op-timing", action="store_true", help="skip the per-launch HIP events")
@@ -136,7 +141,7 @@ def spawn(args):
     """Re-launch this script with one rank per GPU under torch.distributed.run; rank 0's
     stdout (the JSON line) is this process's stdout."""
     n_dev = torch.cuda.device_count()
-    if args.gpus > n_dev:
+    if args.gpus > n_dev and not args.share_gpu:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -224,14 +229,18 @@ def main():
     if env_world is not None:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
+        dev_index = local_rank % max(1, torch.cuda.device_count()) if args.share_gpu else local_rank
+        torch.cuda.set_device(dev_index)
         # RCCL prints a version banner on stdout when the communicator is created: keep stdout for the ONE JSON
         # line (file descriptor 1 points at stderr while the process group comes up)
         sys.stdout.flush()
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl = RCCL on ROCm
+            if args.share_gpu:
+                dist.init_process_group("gloo")           # (test form: ranks may share a device, which RCCL refuses)
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl = RCCL on ROCm
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -248,6 +257,9 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     if args.mode == "train":
+        if args.share_gpu:
+            raise SystemExit("bench.py: --share-gpu is a test form of the inference bench only (the training step's all-reduce "
+                             "runs on device tensors: RCCL)")
         return train_mode(args, dist, dev, rank, world)
 
     import pwcnet_amd
@@ -368,7 +380,8 @@ def main():
         elapsed, issue_elapsed = one_stream_loop()
         st_rep = net.status()                         # the kernels' status words (fp16 range / stream-K): nothing may have fired
 
-    stats = gather_stats(dict(pairs=float(B * args.steps), seconds=elapsed, issue_seconds=issue_elapsed), dist, dev)
+    stats = gather_stats(dict(pairs=float(B * args.steps), seconds=elapsed, issue_seconds=issue_elapsed), dist,
+                         "cpu" if args.share_gpu else dev)
     value, ms_per_step, total_pairs, n_ranks = aggregate_throughput(stats, args.steps)
     assert n_ranks == world
     # every rank's own step time next to the job's (= the slowest rank's): a straggler shows as a rank, not as a mystery
@@ -423,7 +436,9 @@ def main():
             "height": H,
             "width": Wd,
             "parallelism": f"dp{world}: pairs sharded across ranks, no data-path collective"
-                           + ("; RCCL all-gather of per-rank stats" if used_rccl else ""),
+                           + (("; gloo all-gather of per-rank stats, ranks SHARE GPUs (--share-gpu: a test of the N > 1 branch, not a "
+                               "scaling figure)") if (used_rccl and args.share_gpu) else
+                              ("; RCCL all-gather of per-rank stats" if used_rccl else "")),
             "outputs": "persistent (plan-owned)" if args.persistent_outputs else "fresh tensors per call",
             "gpus_from": ("--gpus" if getattr(args, "gpus_given", True) or not args.config
                           else f"implied by --config {args.config}"),

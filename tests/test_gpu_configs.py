@@ -218,6 +218,25 @@ def test_bench_spawns_its_ranks_with_rccl(pa):
     assert d["parity"]["max_abs_flows_final"] <= d["parity"]["tolerance"]
 
 
+def test_bench_two_ranks_on_one_gpu(pa):
+    """`bench.py --gpus 2 --share-gpu`: the N > 1 branch of the bench on a 1-GPU box -- two
+    torch.distributed.run ranks that share device 0 and gather their statistics over gloo (RCCL refuses two ranks on one
+    device): barriers on both sides of the timed region, a ForwardPipeline per rank, per-rank timings, value = all pairs over
+    the slowest rank, the one-stream loop / op-level leg / parity on rank 0 only, one JSON line."""
+    out = _run_bench(["--gpus", "2", "--share-gpu"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["per_gpu_batch"] == 2
+    assert len(d["per_rank_ms_per_step"]) == 2 and d["scaling"] == "weak"
+    assert abs(d["ms_per_step"] - max(d["per_rank_ms_per_step"])) <= 1e-9 * d["ms_per_step"]
+    assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    assert "SHARE GPUs" in d["config"]["parallelism"] and "dp2" in d["config"]["parallelism"]
+    assert d["range_status"]["flags"] == 0 and d["roofline"]["frac"] <= 1.0 and d["value_one_stream"] > 0
+    assert "cpu_baseline" not in d and "parity" not in d          # (rank 0 at N = 1 only, by the contract)
+
+
 def test_bench_train_mode_through_the_rccl_launch(pa):
     """`bench.py --mode train --gpus 1 --spawn`: training steps under torch.distributed.run -- the gradient all-reduce
     runs on the nccl (= RCCL) process group (world 1), the loss falls on the repeated batch."""
