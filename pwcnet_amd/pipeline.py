@@ -104,6 +104,9 @@ class ForwardPipeline(object):
 
     # ------------------------------------------------------------------ forwards
     def submit(self, images_0, images_1):
+        if not (isinstance(images_0, torch.Tensor) and images_0.is_cuda and images_0.device == self.device):
+            raise ValueError(f"ForwardPipeline.submit: images must be CUDA tensors on {self.device} (the lanes' streams live there), "
+                             f"got {getattr(images_0, 'device', type(images_0))}")
         lanes = self._streams()
         k = self._next % len(lanes)
         self._next += 1

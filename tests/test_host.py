@@ -344,6 +344,9 @@ def test_forward_pipeline_host_side():
             pwcnet_amd.ForwardPipeline(depth=2, device="cuda:0", **bad)
     with pytest.raises(ValueError, match="missing"):
         pipe.load_weights({})
+    import torch
+    with pytest.raises(ValueError, match="CUDA tensors"):      # (CPU tensors are refused like PWCDCNet refuses them: no fallback path)
+        pipe.submit(torch.zeros((1, 64, 64, 3)), torch.zeros((1, 64, 64, 3)))
     src = open(pipeline.__file__).read()
     assert "oracle" not in src and "subprocess" not in src
 
